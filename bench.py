@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""
+bench.py -- objective evaluations per second of the MI355X swarm generation.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2] / configs[3]): 24 peaks, 65536-point grid, 4096 particles
+PER GPU (weak scaling: N GPUs evaluate a 4096*N swarm; N=8 is config C4).  One "step" is one
+swarm generation on device-resident state: velocity/position update -> batched objective
+(the hot path, one launch) -> personal-best update -> local argmin -> [N>1: one RCCL
+all-gather of the (D+1)-double candidate] -> global-best fold.  Inputs are resident in HBM
+before the timed region; stopping tests are disabled so every timed generation does full work.
+
+metric  = particle*gridpoint*peak evaluations per second, whole job.
+roofline: SURVEY.md 8(d)(i) streaming-operand byte model (32/P bytes per unit) against
+          8 TB/s, from the objective kernel's own average duration measured with HIP events on
+          its stream (a second pass of K objective-only launches on the final swarm);
+          `valu` carries the honest binding figure (fp64 vector-ALU issue) -- see DESIGN.md.
+cpu_baseline: the oracle (numpy restatement of the reference, 1 core = the reference's
+          default processes=1) on a bounded sample of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X spec: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", help="C3 (default, the metric's config) or C2")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    ap.add_argument("--variant", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(spec, lower, upper, P, budget_s):
+    """Reference-plumbing baseline: the numpy oracle, one particle per call, 1 core."""
+    from oracle import nmrfit_oracle as onp
+    from nmrfit_amd import synth
+    N = spec["w"].size
+    X = synth.make_swarm(lower, upper, 4096, seed=2, x_true=spec["x_true"])
+    t0 = time.perf_counter()
+    n = 0
+    while n < X.shape[0]:
+        onp.objective(X[n], spec["w"], spec["u"], spec["v"], spec["weights"])
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    out = {"value": n * N * P / dt, "unit": "particle*gridpoint*peak/s", "cores": 1, "kind": "port",
+           "sample": "%d particles of the same workload (N=%d, P=%d), numpy oracle one call per particle, %.1f s"
+                     % (n, N, P, dt)}
+    # strong-CPU line: plain-C oracle, OpenMP over particles, all host cores
+    try:
+        from oracle import c_oracle
+        th = os.cpu_count() or 1
+        m = min(X.shape[0], max(th, 4 * th))
+        t0 = time.perf_counter()
+        c_oracle.objective_batch(X[:m], spec["w"], spec["u"], spec["v"], spec["weights"], threads=th)
+        dt = time.perf_counter() - t0
+        out["c_openmp"] = {"value": m * N * P / dt, "cores": th, "sample": "%d particles, %.2f s" % (m, dt)}
+    except Exception as e:  # the C oracle is optional for the baseline
+        out["c_openmp"] = {"error": str(e)}
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+    from nmrfit_amd import synth, _cabi
+    from nmrfit_amd.equations import Evaluator
+    from nmrfit_amd.pso import DeviceSwarm, TorchExchange
+
+    cfg = synth.CONFIGS[args.workload]
+    S_local, N, P = cfg.S, cfg.N, cfg.P
+    D = 4 + 3 * P
+    spec = synth.make_spectrum(N, P, seed=1)
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ev = Evaluator(spec["w"], spec["u"], spec["v"], spec["weights"], device=local_rank)
+    ev.set_variant(args.variant)
+    sw = DeviceSwarm(ev, spec["lower"], spec["upper"], swarmsize=S_local * world, offset=rank * S_local,
+                     S_local=S_local, seed=1234, minstep=-1.0, minfunc=-1.0)   # never stop while timing
+
+    if world > 1:
+        # run our launches on torch's current stream so they order with the RCCL all-gather
+        ev.set_stream(torch.cuda.current_stream().cuda_stream)
+        send = torch.zeros(D + 1, dtype=torch.float64, device="cuda")
+        recv = torch.zeros((world, D + 1), dtype=torch.float64, device="cuda")
+        sw.set_candidate_dev(send.data_ptr())
+        ex = TorchExchange()
+
+        def fold():
+            ex.gather_device(send, recv)
+            sw.apply_global_dev(recv.data_ptr(), world)
+
+        def sync():
+            torch.cuda.synchronize()
+    else:
+        cand = sw.candidate_dev()
+
+        def fold():
+            sw.apply_global_dev(cand, 1)
+
+        def sync():
+            ev.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    sw.init()
+    fold()
+    for _ in range(args.warmup):
+        sw.step_local()
+        fold()
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sw.step_local()
+        fold()
+    sync()
+    barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # objective kernel alone, HIP events on its stream, same swarm positions
+    st = sw.status()
+    d_x = ev.dev_alloc(S_local * D * 8)
+    d_f = ev.dev_alloc(S_local * 8)
+    ev.upload(d_x, sw.state()["x"])
+    for _ in range(2):
+        ev.objective_batch_dev(S_local, P, d_x, d_f)
+    ev.synchronize()
+    ev.timer_begin()
+    for _ in range(args.steps):
+        ev.objective_batch_dev(S_local, P, d_x, d_f)
+    t_kernel_ms = ev.timer_end() / args.steps
+    geom = ev.last_launch()
+
+    units_step = float(S_local) * world * N * P
+    value = units_step * args.steps / dt
+    if rank == 0:
+        units_launch = float(S_local) * N * P
+        bytes_launch = S_local * (4 * N * 8) + S_local * D * 8 + S_local * 8
+        ach = bytes_launch / (t_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "objective evals/sec (swarm x grid x peaks)",
+            "value": value, "unit": "particle*gridpoint*peak/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d peaks, %d-pt grid, swarm %d per GPU (%d total), one PSO generation per step"
+                                   % (cfg.name, P, N, S_local, S_local * world),
+                       "peaks": P, "grid": N, "swarm_per_gpu": S_local, "swarm_total": S_local * world,
+                       "exchange": "rccl all_gather of %d doubles per generation" % (D + 1) if world > 1 else "none",
+                       "variant": args.variant, "generations_done": st["iteration"]},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "model": "streaming-operand bytes S*(4*N*8)+S*D*8+S*8 per launch (SURVEY 8(d)(i)); "
+                                  "w/u/v/weights are shared by all particles and L2-resident, so this is an "
+                                  "effective rate, not physical HBM traffic",
+                         "kernel": "objective_kernel", "kernel_ms": t_kernel_ms,
+                         "bytes_per_launch": bytes_launch, "units_per_launch": units_launch,
+                         "launch": geom},
+            "valu": {"units_per_s_kernel": units_launch / (t_kernel_ms * 1e-3),
+                     "fp64_lane_ops_peak_per_s": FP64_VALU_PEAK_TFLOPS * 1e12 / 2,
+                     "note": "binding resource is fp64 vector-ALU issue; see DESIGN.md for the per-unit "
+                             "instruction count and the measured per-instruction costs"},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(spec, spec["lower"], spec["upper"], P, args.cpu_seconds)
+        print(json.dumps(line))
+        sys.stdout.flush()
+    ev.dev_free(d_x)
+    ev.dev_free(d_f)
+    sw.close()
+    ev.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

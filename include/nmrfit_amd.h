@@ -1,0 +1,159 @@
+/*
+ * nmrfit_amd.h -- C-ABI of libnmrfit_amd.so: the MI355X (gfx950) batched evaluator for
+ * nmrfit's objective function and the swarm loop that drives it.
+ *
+ * The reference (pnnl/nmrfit) is pure Python and has no FFI of its own; the entry points
+ * below are what a ctypes binding for the hot path binds (INTEGRATION.md shows the stub a
+ * maintainer would add to the reference).  Each entry point cites the reference interface
+ * it replaces, as file:line relative to the reference repository root.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  No exceptions cross the boundary.
+ *   - Every function returns an int status: NMRFIT_OK (0) or a negative NMRFIT_E_* code;
+ *     nmrfit_last_error() returns a thread-local message for the last failure.
+ *   - float64 everywhere ("double"), arrays contiguous.  Parameter vectors are laid out as
+ *     the reference lays them out (nmrfit/equations.py:177,188-192;
+ *     nmrfit/containers.py:193-217):
+ *         x = [p0, p1, r, yoff, width_1, loc_1, area_1, ..., width_P, loc_P, area_P]
+ *     so a swarm is a row-major S x (4 + 3P) matrix.
+ *   - Host-pointer calls are synchronous (results are in the output buffer on return).
+ *     "_dev" calls take device pointers, enqueue on the context's HIP stream and return
+ *     immediately; nmrfit_ctx_synchronize() waits for them.
+ *   - A context is bound to one GPU and is NOT thread-safe; different contexts may be
+ *     driven from different host threads.  One process per GPU is the intended use.
+ *   - There is no CPU fallback: every call fails with NMRFIT_E_NO_DEVICE when no gfx950
+ *     device is usable.
+ */
+#ifndef NMRFIT_AMD_H
+#define NMRFIT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMRFIT_ABI_VERSION 1
+
+enum {
+    NMRFIT_OK = 0,
+    NMRFIT_E_INVALID = -1,      /* bad argument (NULL pointer, negative size, P out of range) */
+    NMRFIT_E_NO_DEVICE = -2,    /* no usable HIP device / device index out of range         */
+    NMRFIT_E_HIP = -3,          /* a HIP runtime call failed; see nmrfit_last_error()       */
+    NMRFIT_E_UNSUPPORTED = -4,  /* fit_im != 0 (Kramers-Kronig path, equations.py:197-209)  */
+    NMRFIT_E_STATE = -5         /* call sequence error (e.g. pso step before init)          */
+};
+
+/* Kernel variants (numerics identical to <= 1e-12 relative; for A/B measurement). */
+enum {
+    NMRFIT_VARIANT_DEFAULT = 0,   /* the tuned fp64 kernel                                  */
+    NMRFIT_VARIANT_BASELINE = 1,  /* plain fp64: IEEE divide + libdevice exp2, no skipping  */
+    NMRFIT_VARIANT_NOSKIP = 2     /* tuned arithmetic, Gaussian evaluated everywhere        */
+};
+
+typedef struct nmrfit_ctx nmrfit_ctx;
+typedef struct nmrfit_pso nmrfit_pso;
+
+/* ---- library ------------------------------------------------------------------------- */
+int nmrfit_abi_version(void);
+const char *nmrfit_last_error(void);
+int nmrfit_device_count(int *count);
+/* name (<= len-1 chars), compute units, and gcnArchName of a device */
+int nmrfit_device_info(int device, char *name, int name_len, int *compute_units, char *arch, int arch_len);
+
+/* ---- context: the per-fit constant arrays ---------------------------------------------
+ * Replaces the `args=(data.w, data.u, data.v, weights, fit_im)` tuple that
+ * FitUtility.fit hands to pyswarm for every objective call (nmrfit/utils.py:176): the four
+ * length-N arrays are copied to the GPU once.  The caller keeps ownership of its host
+ * arrays. */
+int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, const double *v,
+                      const double *weights, nmrfit_ctx **out);
+int nmrfit_ctx_destroy(nmrfit_ctx *ctx);
+/* new weights, same N (FitUtility.fit: weights = ones when dynamic_weighting is False,
+ * nmrfit/utils.py:171-173) */
+int nmrfit_ctx_set_weights(nmrfit_ctx *ctx, const double *weights);
+int nmrfit_ctx_synchronize(nmrfit_ctx *ctx);
+/* Run this context's launches on an externally owned HIP stream (a hipStream_t passed as
+ * void*; NULL restores the context's own stream).  Lets the caller order the swarm kernels
+ * with an RCCL collective on the same stream with no host synchronisation. */
+int nmrfit_ctx_set_stream(nmrfit_ctx *ctx, void *hip_stream);
+int nmrfit_ctx_set_variant(nmrfit_ctx *ctx, int variant);
+int nmrfit_ctx_n(const nmrfit_ctx *ctx, int64_t *N);
+
+/* ---- the hot path -----------------------------------------------------------------------
+ * nmrfit_objective_batch replaces the per-particle loop
+ *     fx[i] = equations.objective(x[i, :], w, u, v, weights, fit_im)
+ * (nmrfit/equations.py:152-212, called by pyswarm from nmrfit/utils.py:176-182) by one
+ * batched launch: f_out[i] = sqrt(mean_j (weights_j * (V_data_ij - V_fit_ij))^2).
+ * fit_im must be 0 (NMRFIT_E_UNSUPPORTED otherwise).  S == 0 is a no-op.           */
+int nmrfit_objective_batch(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *X, int fit_im,
+                           double *f_out);
+/* R_out[b*N + j] = weights_j * (V_data_bj - V_fit_bj): the vector inside the mean of
+ * nmrfit/equations.py:202.  f_out (may be NULL) receives the matching objective values. */
+int nmrfit_residual_batch(nmrfit_ctx *ctx, int64_t B, int32_t P, const double *X, double *R_out,
+                          double *f_out);
+
+/* device-pointer forms (asynchronous on the context's stream) */
+int nmrfit_objective_batch_dev(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df_out);
+int nmrfit_residual_batch_dev(nmrfit_ctx *ctx, int64_t B, int32_t P, const double *dX, double *dR_out,
+                              double *df_out);
+
+/* ---- device memory + timing helpers (so callers need no HIP binding of their own) ------ */
+int nmrfit_dev_alloc(nmrfit_ctx *ctx, int64_t bytes, void **dptr);
+int nmrfit_dev_free(nmrfit_ctx *ctx, void *dptr);
+int nmrfit_memcpy_h2d(nmrfit_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes);
+int nmrfit_memcpy_d2h(nmrfit_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes);
+/* HIP events recorded on the context's stream; elapsed_ms covers everything enqueued
+ * between begin and end (end synchronizes). */
+int nmrfit_timer_begin(nmrfit_ctx *ctx);
+int nmrfit_timer_end(nmrfit_ctx *ctx, double *elapsed_ms);
+/* launch geometry the last objective/residual launch used (for reports) */
+int nmrfit_last_launch(const nmrfit_ctx *ctx, int64_t *waves, int32_t *segments, int64_t *segment_len);
+
+/* ---- swarm loop ---------------------------------------------------------------------------
+ * Replaces pyswarm.pso as FitUtility.fit calls it (nmrfit/utils.py:176-182): the swarm
+ * state (x, v, personal bests) lives on the GPU, one generation is
+ * [velocity/position update -> nmrfit_objective_batch_dev -> personal-best update ->
+ * local argmin], and only the (f_best, x_best[D]) candidate leaves the device.  The swarm
+ * axis shards across ranks: this rank owns particles [offset, offset + S_local) of
+ * S_global; random numbers are a counter-based function of (seed, generation, GLOBAL
+ * particle index, dimension), so any sharding produces the same swarm. */
+typedef struct nmrfit_pso_params {
+    double omega, phip, phig;     /* utils.py:179-181 defaults -0.2134, -0.3344, 2.3259 */
+    double minstep, minfunc;      /* pyswarm defaults 1e-8, 1e-8                        */
+    uint64_t seed;
+} nmrfit_pso_params;
+
+int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_t offset, int32_t P,
+                      const double *lower, const double *upper, const nmrfit_pso_params *params,
+                      nmrfit_pso **out);
+int nmrfit_pso_destroy(nmrfit_pso *pso);
+/* generation 0: x ~ U(lb,ub), evaluate, personal bests, v ~ U(-|ub-lb|,|ub-lb|);
+ * leaves this rank's candidate in the candidate buffer. */
+int nmrfit_pso_init(nmrfit_pso *pso);
+/* one generation on this rank's shard; leaves the local candidate in the buffer */
+int nmrfit_pso_step_local(nmrfit_pso *pso);
+/* device pointer to this rank's candidate record: (D+1) doubles = [f_best, x_best[0..D)] */
+int nmrfit_pso_candidate_dev(nmrfit_pso *pso, double **dptr);
+/* make the swarm write its candidate record into caller-owned device memory ((D+1) doubles,
+ * e.g. the send buffer of an all-gather); NULL restores the internal buffer */
+int nmrfit_pso_set_candidate_dev(nmrfit_pso *pso, double *dptr);
+/* fold `nranks` gathered candidate records (device pointer, nranks x (D+1) doubles, rank
+ * order) into the global best with pyswarm's rule (lowest rank wins ties) and evaluate
+ * the minfunc / minstep stopping tests.  Single-rank callers pass their own candidate. */
+int nmrfit_pso_apply_global_dev(nmrfit_pso *pso, const double *d_candidates, int32_t nranks);
+/* status: iteration counter, stop code (0 running, 1 minfunc, 2 minstep), current fg */
+int nmrfit_pso_status(nmrfit_pso *pso, int64_t *iteration, int32_t *stop_code, double *fg);
+/* best position (D doubles) and value; after a stop these are pyswarm's return values */
+int nmrfit_pso_best(nmrfit_pso *pso, double *x_best, double *f_best);
+/* single-rank convenience: init (if needed) + up to maxiter generations, polling the stop
+ * flag every `check_every` generations (generations after a stop are no-ops on the GPU). */
+int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every);
+/* copy swarm state to host for inspection/tests (any pointer may be NULL):
+ * x, v, p are S_local x D; fx, fp are S_local */
+int nmrfit_pso_get_state(nmrfit_pso *pso, double *x, double *v, double *p, double *fx, double *fp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMRFIT_AMD_H */

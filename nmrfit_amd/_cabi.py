@@ -1,0 +1,133 @@
+"""
+ctypes binding of libnmrfit_amd.so (include/nmrfit_amd.h).  This is the whole Python <-> GPU
+boundary: plain pointers and sizes, no torch types.  There is no CPU fallback: if the
+library is missing or no gfx950 device is visible the calls raise ``NmrfitError``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnmrfit_amd.so")
+BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
+
+OK = 0
+E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4, -5
+VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP = 0, 1, 2
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+
+class NmrfitError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libnmrfit_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class PsoParams(ctypes.Structure):
+    _fields_ = [("omega", ctypes.c_double), ("phip", ctypes.c_double), ("phig", ctypes.c_double),
+                ("minstep", ctypes.c_double), ("minfunc", ctypes.c_double), ("seed", ctypes.c_uint64)]
+
+
+# name -> (argtypes) ; every entry returns int except nmrfit_last_error
+_I64, _I32, _INT = ctypes.c_int64, ctypes.c_int32, ctypes.c_int
+_VP = ctypes.c_void_p
+SIGNATURES = {
+    "nmrfit_abi_version": [],
+    "nmrfit_device_count": [ctypes.POINTER(_INT)],
+    "nmrfit_device_info": [_INT, ctypes.c_char_p, _INT, ctypes.POINTER(_INT), ctypes.c_char_p, _INT],
+    "nmrfit_ctx_create": [_INT, _I64, _VP, _VP, _VP, _VP, _c_void_pp],
+    "nmrfit_ctx_destroy": [_VP],
+    "nmrfit_ctx_set_weights": [_VP, _VP],
+    "nmrfit_ctx_synchronize": [_VP],
+    "nmrfit_ctx_set_variant": [_VP, _INT],
+    "nmrfit_ctx_set_stream": [_VP, _VP],
+    "nmrfit_ctx_n": [_VP, ctypes.POINTER(_I64)],
+    "nmrfit_objective_batch": [_VP, _I64, _I32, _VP, _INT, _VP],
+    "nmrfit_residual_batch": [_VP, _I64, _I32, _VP, _VP, _VP],
+    "nmrfit_objective_batch_dev": [_VP, _I64, _I32, _VP, _VP],
+    "nmrfit_residual_batch_dev": [_VP, _I64, _I32, _VP, _VP, _VP],
+    "nmrfit_dev_alloc": [_VP, _I64, _c_void_pp],
+    "nmrfit_dev_free": [_VP, _VP],
+    "nmrfit_memcpy_h2d": [_VP, _VP, _VP, _I64],
+    "nmrfit_memcpy_d2h": [_VP, _VP, _VP, _I64],
+    "nmrfit_timer_begin": [_VP],
+    "nmrfit_timer_end": [_VP, _c_double_p],
+    "nmrfit_last_launch": [_VP, ctypes.POINTER(_I64), ctypes.POINTER(_I32), ctypes.POINTER(_I64)],
+    "nmrfit_pso_create": [_VP, _I64, _I64, _I64, _I32, _VP, _VP, ctypes.POINTER(PsoParams), _c_void_pp],
+    "nmrfit_pso_destroy": [_VP],
+    "nmrfit_pso_init": [_VP],
+    "nmrfit_pso_step_local": [_VP],
+    "nmrfit_pso_candidate_dev": [_VP, _c_void_pp],
+    "nmrfit_pso_set_candidate_dev": [_VP, _VP],
+    "nmrfit_pso_apply_global_dev": [_VP, _VP, _I32],
+    "nmrfit_pso_status": [_VP, ctypes.POINTER(_I64), ctypes.POINTER(_I32), _c_double_p],
+    "nmrfit_pso_best": [_VP, _VP, _c_double_p],
+    "nmrfit_pso_run": [_VP, _I64, _I32],
+    "nmrfit_pso_get_state": [_VP, _VP, _VP, _VP, _VP, _VP],
+}
+
+_LIB = None
+
+
+def build(verbose=False):
+    """Compile libnmrfit_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    out = subprocess.run(["bash", BUILD_SCRIPT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise RuntimeError("building libnmrfit_amd.so failed")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) when it is not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise NmrfitError(E_NO_DEVICE, "%s not found: build it with nmrfit_amd/csrc/build.sh "
+                              "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        L.nmrfit_last_error.argtypes = []
+        L.nmrfit_last_error.restype = ctypes.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != OK:
+        raise NmrfitError(rc, lib().nmrfit_last_error().decode("utf-8", "replace"))
+
+
+def f64(a):
+    """Contiguous float64 copy/view: the reference hands out negative-stride views
+    (nmrfit/core.py:60) and possibly float32 data; the ABI takes contiguous float64."""
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = lib().nmrfit_device_count(ctypes.byref(n))
+    if rc == E_NO_DEVICE:
+        return 0
+    check(rc)
+    return n.value
+
+
+def device_info(device=0):
+    name = ctypes.create_string_buffer(256)
+    arch = ctypes.create_string_buffer(256)
+    cu = ctypes.c_int(0)
+    check(lib().nmrfit_device_info(device, name, 256, ctypes.byref(cu), arch, 256))
+    return dict(name=name.value.decode(), compute_units=cu.value, arch=arch.value.decode())

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Builds libnmrfit_amd.so for gfx950 (cross-compiles without a GPU).
+# Usage: nmrfit_amd/csrc/build.sh [extra hipcc flags]
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$ROOT/nmrfit_amd/lib"
+mkdir -p "$OUT"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+    -ffp-contract=on -fno-fast-math \
+    -I"$ROOT/include" -I"$HERE" \
+    "$HERE/objective.hip" "$HERE/pso.hip" "$HERE/cabi.hip" \
+    -o "$OUT/libnmrfit_amd.so" "$@"
+echo "built $OUT/libnmrfit_amd.so"

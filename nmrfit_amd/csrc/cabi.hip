@@ -1,0 +1,416 @@
+// cabi.hip -- the extern "C" surface of libnmrfit_amd.so (include/nmrfit_amd.h): context
+// life-cycle, host-pointer and device-pointer forms of the objective / residual calls,
+// device memory and HIP-event timing helpers.  No exception leaves this file.
+#include "nmrfit_internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace nmrfit {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_last_error = buf;
+    return NMRFIT_E_HIP;
+}
+
+int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need)
+{
+    if (need <= *cap) return NMRFIT_OK;
+    // the old buffer may still be in use by work enqueued on the stream
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    if (*buf) NMRFIT_HIP(hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    int64_t n = need + need / 4 + 64;
+    NMRFIT_HIP(hipMalloc((void **)buf, (size_t)n * sizeof(double)));
+    *cap = n;
+    return NMRFIT_OK;
+}
+
+static int bind(const nmrfit_ctx *ctx)
+{
+    if (!ctx) {
+        set_error("null context");
+        return NMRFIT_E_INVALID;
+    }
+    NMRFIT_HIP(hipSetDevice(ctx->device));
+    return NMRFIT_OK;
+}
+
+static int check_batch(const nmrfit_ctx *ctx, int64_t S, int32_t P, const void *X, const void *out)
+{
+    if (S < 0 || P < 0) {
+        set_error("negative batch size or peak count");
+        return NMRFIT_E_INVALID;
+    }
+    if (P > kMaxPeaks) {
+        set_error("P exceeds the supported maximum of 1024 peaks");
+        return NMRFIT_E_INVALID;
+    }
+    if (S > 0 && (!X || !out)) {
+        set_error("null parameter/output pointer");
+        return NMRFIT_E_INVALID;
+    }
+    (void)ctx;
+    return NMRFIT_OK;
+}
+
+}  // namespace nmrfit
+
+using namespace nmrfit;
+
+extern "C" {
+
+int nmrfit_abi_version(void) { return NMRFIT_ABI_VERSION; }
+
+const char *nmrfit_last_error(void) { return g_last_error.c_str(); }
+
+int nmrfit_device_count(int *count)
+{
+    if (!count) {
+        set_error("null count pointer");
+        return NMRFIT_E_INVALID;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        (void)hipGetLastError();
+        set_error(std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e));
+        return NMRFIT_E_NO_DEVICE;
+    }
+    *count = n;
+    return NMRFIT_OK;
+}
+
+int nmrfit_device_info(int device, char *name, int name_len, int *compute_units, char *arch, int arch_len)
+{
+    int n = 0;
+    int rc = nmrfit_device_count(&n);
+    if (rc != NMRFIT_OK) return rc;
+    if (device < 0 || device >= n) {
+        set_error("device index out of range");
+        return NMRFIT_E_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    NMRFIT_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) {
+        strncpy(name, prop.name, (size_t)name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (arch && arch_len > 0) {
+        strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    return NMRFIT_OK;
+}
+
+int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, const double *v,
+                      const double *weights, nmrfit_ctx **out)
+{
+    if (!out) {
+        set_error("null out pointer");
+        return NMRFIT_E_INVALID;
+    }
+    *out = nullptr;
+    if (N <= 0 || !w || !u || !v || !weights) {
+        set_error("nmrfit_ctx_create: N must be > 0 and w, u, v, weights non-null");
+        return NMRFIT_E_INVALID;
+    }
+    int n = 0;
+    int rc = nmrfit_device_count(&n);
+    if (rc != NMRFIT_OK) return rc;
+    if (n == 0) {
+        set_error("no HIP device visible: libnmrfit_amd has no CPU fallback");
+        return NMRFIT_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device index out of range");
+        return NMRFIT_E_NO_DEVICE;
+    }
+    NMRFIT_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    NMRFIT_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        return NMRFIT_E_NO_DEVICE;
+    }
+    nmrfit_ctx *ctx = new (std::nothrow) nmrfit_ctx();
+    if (!ctx) {
+        set_error("out of host memory");
+        return NMRFIT_E_INVALID;
+    }
+    ctx->device = device;
+    ctx->compute_units = prop.multiProcessorCount;
+    ctx->N = N;
+    ctx->n_chunks = (N + kChunk - 1) / kChunk;
+    ctx->w0 = w[N / 2];
+    const size_t bytes = (size_t)N * sizeof(double);
+    double *d_w_raw = nullptr;
+#define CTX_HIP(call)                                                              \
+    do {                                                                           \
+        hipError_t _e = (call);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            int _rc = hip_fail(_e, #call, __FILE__, __LINE__);                     \
+            if (d_w_raw) (void)hipFree(d_w_raw);                                   \
+            nmrfit_ctx_destroy(ctx);                                               \
+            return _rc;                                                            \
+        }                                                                          \
+    } while (0)
+    CTX_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    CTX_HIP(hipEventCreate(&ctx->ev0));
+    CTX_HIP(hipEventCreate(&ctx->ev1));
+    CTX_HIP(hipMalloc((void **)&ctx->d_wc, bytes));
+    CTX_HIP(hipMalloc((void **)&ctx->d_u, bytes));
+    CTX_HIP(hipMalloc((void **)&ctx->d_v, bytes));
+    CTX_HIP(hipMalloc((void **)&ctx->d_wt, bytes));
+    CTX_HIP(hipMalloc((void **)&ctx->d_chunk, (size_t)ctx->n_chunks * sizeof(double2)));
+    CTX_HIP(hipMalloc((void **)&d_w_raw, bytes));
+    CTX_HIP(hipMemcpyAsync(d_w_raw, w, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CTX_HIP(hipMemcpyAsync(ctx->d_u, u, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CTX_HIP(hipMemcpyAsync(ctx->d_v, v, bytes, hipMemcpyHostToDevice, ctx->stream));
+    CTX_HIP(hipMemcpyAsync(ctx->d_wt, weights, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = prepare_grid(ctx, d_w_raw);
+    if (rc != NMRFIT_OK) {
+        (void)hipFree(d_w_raw);
+        nmrfit_ctx_destroy(ctx);
+        return rc;
+    }
+    CTX_HIP(hipStreamSynchronize(ctx->stream));
+    CTX_HIP(hipFree(d_w_raw));
+    d_w_raw = nullptr;
+#undef CTX_HIP
+    *out = ctx;
+    return NMRFIT_OK;
+}
+
+int nmrfit_ctx_destroy(nmrfit_ctx *ctx)
+{
+    if (!ctx) return NMRFIT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
+    void *bufs[] = {ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, ctx->d_X, ctx->d_f, ctx->d_partial, ctx->d_R};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return NMRFIT_OK;
+}
+
+int nmrfit_ctx_set_weights(nmrfit_ctx *ctx, const double *weights)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (!weights) {
+        set_error("null weights");
+        return NMRFIT_E_INVALID;
+    }
+    NMRFIT_HIP(hipMemcpyAsync(ctx->d_wt, weights, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    return NMRFIT_OK;
+}
+
+int nmrfit_ctx_synchronize(nmrfit_ctx *ctx)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    return NMRFIT_OK;
+}
+
+int nmrfit_ctx_set_stream(nmrfit_ctx *ctx, void *hip_stream)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));   // drain work queued on the old stream
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return NMRFIT_OK;
+}
+
+int nmrfit_ctx_set_variant(nmrfit_ctx *ctx, int variant)
+{
+    if (!ctx || variant < 0 || variant > NMRFIT_VARIANT_NOSKIP) {
+        set_error("bad context or variant");
+        return NMRFIT_E_INVALID;
+    }
+    ctx->variant = variant;
+    return NMRFIT_OK;
+}
+
+int nmrfit_ctx_n(const nmrfit_ctx *ctx, int64_t *N)
+{
+    if (!ctx || !N) {
+        set_error("null argument");
+        return NMRFIT_E_INVALID;
+    }
+    *N = ctx->N;
+    return NMRFIT_OK;
+}
+
+int nmrfit_objective_batch_dev(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df_out)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    rc = check_batch(ctx, S, P, dX, df_out);
+    if (rc != NMRFIT_OK) return rc;
+    return launch_objective(ctx, S, P, dX, df_out, nullptr);
+}
+
+int nmrfit_residual_batch_dev(nmrfit_ctx *ctx, int64_t B, int32_t P, const double *dX, double *dR_out, double *df_out)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    rc = check_batch(ctx, B, P, dX, dR_out);
+    if (rc != NMRFIT_OK) return rc;
+    if (B == 0) return NMRFIT_OK;
+    if (!df_out) {
+        rc = ensure(ctx, &ctx->d_f, &ctx->cap_f, B);
+        if (rc != NMRFIT_OK) return rc;
+        df_out = ctx->d_f;
+    }
+    return launch_objective(ctx, B, P, dX, df_out, dR_out);
+}
+
+int nmrfit_objective_batch(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *X, int fit_im, double *f_out)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (fit_im) {
+        set_error("fit_im=True (Kramers-Kronig imaginary fit, equations.py:197-209) is not supported by this library");
+        return NMRFIT_E_UNSUPPORTED;
+    }
+    rc = check_batch(ctx, S, P, X, f_out);
+    if (rc != NMRFIT_OK) return rc;
+    if (S == 0) return NMRFIT_OK;
+    const int64_t D = 4 + 3 * (int64_t)P;
+    if ((rc = ensure(ctx, &ctx->d_X, &ctx->cap_X, S * D)) != NMRFIT_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->d_f, &ctx->cap_f, S)) != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipMemcpyAsync(ctx->d_X, X, (size_t)(S * D) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_objective(ctx, S, P, ctx->d_X, ctx->d_f, nullptr)) != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipMemcpyAsync(f_out, ctx->d_f, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    return NMRFIT_OK;
+}
+
+int nmrfit_residual_batch(nmrfit_ctx *ctx, int64_t B, int32_t P, const double *X, double *R_out, double *f_out)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    rc = check_batch(ctx, B, P, X, R_out);
+    if (rc != NMRFIT_OK) return rc;
+    if (B == 0) return NMRFIT_OK;
+    const int64_t D = 4 + 3 * (int64_t)P;
+    if ((rc = ensure(ctx, &ctx->d_X, &ctx->cap_X, B * D)) != NMRFIT_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->d_f, &ctx->cap_f, B)) != NMRFIT_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->d_R, &ctx->cap_R, B * ctx->N)) != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipMemcpyAsync(ctx->d_X, X, (size_t)(B * D) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_objective(ctx, B, P, ctx->d_X, ctx->d_f, ctx->d_R)) != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipMemcpyAsync(R_out, ctx->d_R, (size_t)(B * ctx->N) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (f_out)
+        NMRFIT_HIP(hipMemcpyAsync(f_out, ctx->d_f, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    return NMRFIT_OK;
+}
+
+int nmrfit_dev_alloc(nmrfit_ctx *ctx, int64_t bytes, void **dptr)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (!dptr || bytes < 0) {
+        set_error("bad arguments to nmrfit_dev_alloc");
+        return NMRFIT_E_INVALID;
+    }
+    *dptr = nullptr;
+    if (bytes == 0) return NMRFIT_OK;
+    NMRFIT_HIP(hipMalloc(dptr, (size_t)bytes));
+    return NMRFIT_OK;
+}
+
+int nmrfit_dev_free(nmrfit_ctx *ctx, void *dptr)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (!dptr) return NMRFIT_OK;
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    NMRFIT_HIP(hipFree(dptr));
+    return NMRFIT_OK;
+}
+
+int nmrfit_memcpy_h2d(nmrfit_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (bytes < 0 || (bytes > 0 && (!dst_dev || !src_host))) {
+        set_error("bad arguments to nmrfit_memcpy_h2d");
+        return NMRFIT_E_INVALID;
+    }
+    if (bytes == 0) return NMRFIT_OK;
+    NMRFIT_HIP(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    return NMRFIT_OK;
+}
+
+int nmrfit_memcpy_d2h(nmrfit_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (bytes < 0 || (bytes > 0 && (!dst_host || !src_dev))) {
+        set_error("bad arguments to nmrfit_memcpy_d2h");
+        return NMRFIT_E_INVALID;
+    }
+    if (bytes == 0) return NMRFIT_OK;
+    NMRFIT_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    return NMRFIT_OK;
+}
+
+int nmrfit_timer_begin(nmrfit_ctx *ctx)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return NMRFIT_OK;
+}
+
+int nmrfit_timer_end(nmrfit_ctx *ctx, double *elapsed_ms)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (!elapsed_ms) {
+        set_error("null elapsed_ms");
+        return NMRFIT_E_INVALID;
+    }
+    NMRFIT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    NMRFIT_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    NMRFIT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *elapsed_ms = (double)ms;
+    return NMRFIT_OK;
+}
+
+int nmrfit_last_launch(const nmrfit_ctx *ctx, int64_t *waves, int32_t *segments, int64_t *segment_len)
+{
+    if (!ctx) {
+        set_error("null context");
+        return NMRFIT_E_INVALID;
+    }
+    if (waves) *waves = ctx->last.waves;
+    if (segments) *segments = ctx->last.nseg;
+    if (segment_len) *segment_len = ctx->last.seg_len;
+    return NMRFIT_OK;
+}
+
+}  // extern "C"

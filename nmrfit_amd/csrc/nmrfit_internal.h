@@ -1,0 +1,77 @@
+// Internal declarations shared by the .hip translation units of libnmrfit_amd.so.
+// Nothing here is part of the ABI (that is include/nmrfit_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "nmrfit_amd.h"
+
+namespace nmrfit {
+
+constexpr int kWave = 64;            // gfx950 wavefront
+constexpr int kWavesPerBlock = 4;    // 256-thread workgroups: one wave per SIMD of a CU
+constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kPointsPerLane = 8;    // grid points register-blocked per lane per chunk
+constexpr int kChunk = kWave * kPointsPerLane;   // 512 grid points per wave per chunk
+constexpr int kMaxPeaks = 1024;      // LDS: 4 waves x P x 48 B <= 192 KiB -> capped below
+
+// Per-(particle, peak) constants staged in LDS (48 B): see objective.hip.
+struct PeakRec {
+    double ihw;   // 2/width
+    double c;     // -(loc - w0) * ihw        so that t = (w_j - w0)*ihw + c
+    double al;    // area*r*(2/(pi*width))    Lorentzian amplitude
+    double ag2;   // 2*area*(1-r)*(2/width)*sqrt(ln2/pi)   Gaussian amplitude, factor 2 folds exp2(1)
+    double glo;   // (loc - w0) - G*width     the Gaussian is < 2^-kSkipExp outside [glo, ghi]
+    double ghi;
+};
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define NMRFIT_HIP(call)                                                        \
+    do {                                                                        \
+        hipError_t _e = (call);                                                 \
+        if (_e != hipSuccess) return ::nmrfit::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+struct LaunchGeom {
+    int64_t waves = 0;
+    int32_t nseg = 1;
+    int64_t seg_len = 0;
+};
+
+}  // namespace nmrfit
+
+struct nmrfit_ctx {
+    int device = -1;
+    int compute_units = 0;
+    hipStream_t stream = nullptr;      // the stream launches go to (own_stream unless overridden)
+    hipStream_t own_stream = nullptr;
+    int64_t N = 0;
+    double w0 = 0.0;             // centring offset: d_wc[j] = w[j] - w0
+    double *d_wc = nullptr;      // centred grid
+    double *d_u = nullptr, *d_v = nullptr, *d_wt = nullptr;
+    double2 *d_chunk = nullptr;  // per 512-point chunk: (min, max) of the centred grid
+    int64_t n_chunks = 0;
+    // grow-on-demand workspace for the host-pointer entry points
+    double *d_X = nullptr;
+    int64_t cap_X = 0;           // doubles
+    double *d_f = nullptr;
+    int64_t cap_f = 0;
+    double *d_partial = nullptr;
+    int64_t cap_partial = 0;
+    double *d_R = nullptr;
+    int64_t cap_R = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int variant = NMRFIT_VARIANT_DEFAULT;
+    nmrfit::LaunchGeom last;
+};
+
+namespace nmrfit {
+// Enqueue the objective (R_out == nullptr) or residual launch on ctx->stream.
+int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR);
+int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need);
+// centred grid + per-chunk (min,max) table from the raw device copy of w
+int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw);
+}  // namespace nmrfit

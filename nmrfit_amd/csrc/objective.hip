@@ -1,0 +1,368 @@
+// objective.hip -- the hot path: batched nmrfit objective / residual for gfx950 (CDNA4).
+//
+// What it computes (reference: nmrfit/equations.py:152-212 `objective`, :115-149 `voigt`,
+// nmrfit/proc_autophase.py:9-36 `ps2`), for every particle i of a swarm X[S, 4+3P]:
+//
+//     phi_j   = p0 + (p1*j)/N                                    proc_autophase.py:31
+//     Vd_j    = cos(phi_j)*u_j - sin(phi_j)*v_j                  proc_autophase.py:35 (real part)
+//     Vf_j    = sum_k [ yoff + a_k*( r*L_k(w_j) + (1-r)*G_k(w_j) ) ]   equations.py:141-147,195
+//     f_i     = sqrt( mean_j ( weights_j*(Vd_j - Vf_j) )^2 )     equations.py:202
+//
+// MI355X mapping (no MFMA: there is no contraction here; the kernel is bound by the fp64
+// vector-ALU issue rate):
+//   * one WAVE owns one (particle, grid-segment); its 64 lanes stride the grid points so
+//     the w/u/v/weights reads are coalesced 512-B rows that stay L2-resident (the four
+//     arrays are shared by every particle: <= 2 MiB at N = 65536);
+//   * each lane register-blocks 8 grid points, so the per-peak constants are fetched once
+//     per 8 points.  They are wave-uniform and live in LDS (48 B per peak, read as three
+//     broadcast ds_read_b128), staged once per wave from the particle's row of X;
+//   * algebra (derived from equations.py:141-147, exact in real arithmetic): with
+//     t = (w-loc)*(2/width), s = 1 + t^2:  L = (2/(pi*width))/s  and
+//     exp(-((w-loc)/(width/(2 sqrt(ln2))))^2) = 2^(-t^2) = 2*2^(-s), so one fma chain per
+//     point and peak: t = fma(wc, ihw, c); s = fma(t, t, 1); acc += AL*rcp(s) + AG2*exp2(-s);
+//   * rcp(s): v_rcp_f32 seed + one fp64 Newton step (relative error <= 2^-45);
+//     exp2(-s): round-to-nearest split + degree-11 polynomial + v_ldexp_f64 (<= 3e-16);
+//   * the Gaussian term is < 2^-64 of its amplitude once |w-loc| > 3.97*width; a wave
+//     skips it for a whole 512-point chunk when the chunk's [min,max] of w (precomputed
+//     at context creation) misses that window -- a wave-uniform branch, exact to fp64
+//     rounding, and the common case (a line is ~100x narrower than the spectrum);
+//   * the phase ramp is a complex rotation recurrence z <- z*rho (4 fp64 ops per point)
+//     seeded once per lane by sincos;
+//   * sum of squares: per-lane fp64 accumulation, then a wave64 shuffle tree.  With one
+//     segment per particle the wave writes f directly; otherwise a tiny second kernel adds
+//     the per-segment partial sums in fixed order (deterministic, no atomics).
+#include "nmrfit_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace nmrfit {
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kInvPi = 0.31830988618379067154;
+constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
+constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
+
+// ---- fp64 helpers (coefficients: tools/gen_poly.py) ---------------------------------------
+
+// 1/s for finite s >= 1: f32 hardware reciprocal (1 ulp) refined by one Newton step.
+__device__ __forceinline__ double rcp_refined(double s)
+{
+    const double r0 = (double)__builtin_amdgcn_rcpf((float)s);
+    const double e = __builtin_fma(-s, r0, 1.0);
+    return __builtin_fma(r0, e, r0);
+}
+
+// 2^x for x <= 0.  n = rint(x), f = x - n in [-1/2, 1/2], degree-11 interpolant of 2^f
+// (max relative error 2.2e-16 in float64 Horner form), scaled by v_ldexp_f64.
+__device__ __forceinline__ double exp2_neg(double x)
+{
+    x = fmax(x, -1100.0);   // 2^-1100 == 0 in fp64; keeps n inside int range
+    const double n = __builtin_rint(x);
+    const double f = x - n;
+    double p = 4.455817908336064493e-10;
+    p = __builtin_fma(p, f, 7.0741942972885210056e-9);
+    p = __builtin_fma(p, f, 1.0178057087733941105e-7);
+    p = __builtin_fma(p, f, 1.3215432535912376166e-6);
+    p = __builtin_fma(p, f, 1.5252733841556772589e-5);
+    p = __builtin_fma(p, f, 1.5403530463724354209e-4);
+    p = __builtin_fma(p, f, 1.3333558146406470697e-3);
+    p = __builtin_fma(p, f, 9.6181291075872566681e-3);
+    p = __builtin_fma(p, f, 5.5504108664821627039e-2);
+    p = __builtin_fma(p, f, 2.4022650695910159567e-1);
+    p = __builtin_fma(p, f, 6.9314718055994530925e-1);
+    p = __builtin_fma(p, f, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
+// sin and cos of phi.  |phi| < 1e6: 3-term Cody-Waite reduction by pi/2 (33-bit pieces,
+// k*piece exact for |k| < 2^20) + polynomials on [-pi/4, pi/4] (<= 3e-16); otherwise the
+// libdevice routine (Payne-Hanek).  The branch is wave-uniform in practice (phi = p0 + p1*j/N).
+__device__ __forceinline__ void sincos_fast(double phi, double *s_out, double *c_out)
+{
+    if (!(fabs(phi) < 1.0e6)) {
+        sincos(phi, s_out, c_out);
+        return;
+    }
+    const double k = __builtin_rint(phi * 0.6366197723675814);
+    double r = __builtin_fma(-k, 1.5707963267341256, phi);
+    r = __builtin_fma(-k, 6.077100506303966e-11, r);
+    r = __builtin_fma(-k, 2.0222662487959506e-21, r);
+    const double y = r * r;
+    double ps = 1.5894736651849095259e-10;
+    ps = __builtin_fma(ps, y, -2.5050716974102745028e-8);
+    ps = __builtin_fma(ps, y, 2.7557313376400129128e-6);
+    ps = __builtin_fma(ps, y, -1.9841269828650300013e-4);
+    ps = __builtin_fma(ps, y, 8.3333333333203624567e-3);
+    ps = __builtin_fma(ps, y, -1.6666666666666616666e-1);
+    const double sn = __builtin_fma(r * y, ps, r);
+    double pc = -1.1353379638297574126e-11;
+    pc = __builtin_fma(pc, y, 2.0875582380663953044e-9);
+    pc = __builtin_fma(pc, y, -2.7557313097790086271e-7);
+    pc = __builtin_fma(pc, y, 2.4801587283881153004e-5);
+    pc = __builtin_fma(pc, y, -1.3888888888861094596e-3);
+    pc = __builtin_fma(pc, y, 4.1666666666666452389e-2);
+    pc = __builtin_fma(pc, y, -0.5);
+    const double cs = __builtin_fma(pc, y, 1.0);
+    const int q = (int)k & 3;
+    const double s1 = (q & 1) ? cs : sn;
+    const double c1 = (q & 1) ? sn : cs;
+    *s_out = (q & 2) ? -s1 : s1;
+    *c_out = ((q + 1) & 2) ? -c1 : c1;
+}
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
+    return x;
+}
+
+// ---- the kernel ----------------------------------------------------------------------------
+// VARIANT: NMRFIT_VARIANT_DEFAULT (tuned + Gaussian window skip), _BASELINE (IEEE divide and
+// libdevice exp2, no skip: the obviously-right form the tuned ones are A/B-checked against),
+// _NOSKIP (tuned arithmetic, Gaussian everywhere).
+// Wave g = blockIdx.x*4 + wave  ->  particle g / nseg, segment g % nseg;
+// a segment is seg_len (multiple of 512) consecutive grid points.
+template <int VARIANT, bool WRITE_R>
+__global__ __launch_bounds__(kBlock) void objective_kernel(
+    const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
+    const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax,
+    const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, int nseg, int64_t seg_len,
+    double *__restrict__ out,       // nseg == 1: f[S];  else partial sums [S*nseg]
+    double *__restrict__ R_out)     // WRITE_R: residual rows [S*N]
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    PeakRec *recs = reinterpret_cast<PeakRec *>(lds_raw) + (size_t)wave * P;
+
+    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    const bool active = g < S * nseg;
+    const int64_t particle = active ? g / nseg : 0;
+    const int seg = active ? (int)(g % nseg) : 0;
+    const int64_t D = 4 + 3 * (int64_t)P;
+    const double *x = X + particle * D;
+
+    const double p0 = x[0], p1 = x[1], r = x[2], yoff = x[3];   // equations.py:177
+
+    // stage this particle's per-peak constants in the wave's LDS slice
+    for (int k = lane; k < P; k += kWave) {
+        const double width = x[4 + 3 * k], loc = x[5 + 3 * k], a = x[6 + 3 * k];
+        const double ihw = 2.0 / width;
+        const double locc = loc - w0;
+        PeakRec rec;
+        rec.ihw = ihw;
+        rec.c = -locc * ihw;
+        rec.al = a * r * ihw * kInvPi;                            // a*r*(2/(pi*width))
+        rec.ag2 = 2.0 * a * (1.0 - r) * ihw * kSqrtLn2OverPi;     // 2 * a*(1-r)*(2/width)*sqrt(ln2/pi)
+        const double gw = kGaussWindow * fabs(width);
+        rec.glo = locc - gw;
+        rec.ghi = locc + gw;
+        recs[k] = rec;
+    }
+    __syncthreads();
+    if (!active) return;
+
+    const int64_t j0 = (int64_t)seg * seg_len;
+    const int64_t j1 = (j0 + seg_len < N) ? j0 + seg_len : N;
+
+    // phase ramp: z = exp(i*phi_j) for this lane's current point, rho = exp(i*p1*64/N)
+    double zr, zi, rr, ri;
+    {
+        const double invN = 1.0 / (double)N;
+        sincos_fast(p0 + (p1 * (double)(j0 + lane)) * invN, &zi, &zr);
+        sincos_fast((p1 * 64.0) * invN, &ri, &rr);
+    }
+    const double base = (double)P * yoff;     // yoff is added once per peak (equations.py:147,195)
+    double ss = 0.0;
+
+    for (int64_t jb = j0; jb < j1; jb += kChunk) {
+        double wv[kPointsPerLane], acc[kPointsPerLane];
+#pragma unroll
+        for (int q = 0; q < kPointsPerLane; ++q) {
+            const int64_t j = jb + q * kWave + lane;
+            wv[q] = (j < j1) ? wc[j] : 0.0;
+            acc[q] = base;
+        }
+        double2 mm = make_double2(0.0, 0.0);
+        if (VARIANT == NMRFIT_VARIANT_DEFAULT) mm = chunk_minmax[jb / kChunk];
+
+        for (int k = 0; k < P; ++k) {
+            const PeakRec rec = recs[k];
+            if (VARIANT == NMRFIT_VARIANT_BASELINE) {
+#pragma unroll
+                for (int q = 0; q < kPointsPerLane; ++q) {
+                    const double t = __builtin_fma(wv[q], rec.ihw, rec.c);
+                    const double s = __builtin_fma(t, t, 1.0);
+                    acc[q] = __builtin_fma(rec.al, 1.0 / s, acc[q]);
+                    acc[q] = __builtin_fma(rec.ag2, exp2(-s), acc[q]);
+                }
+            } else {
+                double sv[kPointsPerLane];
+#pragma unroll
+                for (int q = 0; q < kPointsPerLane; ++q) {
+                    const double t = __builtin_fma(wv[q], rec.ihw, rec.c);
+                    sv[q] = __builtin_fma(t, t, 1.0);
+                    acc[q] = __builtin_fma(rec.al, rcp_refined(sv[q]), acc[q]);
+                }
+                int gauss = 1;
+                if (VARIANT == NMRFIT_VARIANT_DEFAULT)   // operands are wave-uniform: make the branch scalar
+                    gauss = __builtin_amdgcn_readfirstlane((int)((mm.y >= rec.glo) && (mm.x <= rec.ghi)));
+                if (gauss) {
+#pragma unroll
+                    for (int q = 0; q < kPointsPerLane; ++q)
+                        acc[q] = __builtin_fma(rec.ag2, exp2_neg(-sv[q]), acc[q]);
+                }
+            }
+        }
+
+#pragma unroll
+        for (int q = 0; q < kPointsPerLane; ++q) {
+            const int64_t j = jb + q * kWave + lane;
+            const bool ok = j < j1;
+            const double uj = ok ? u[j] : 0.0;
+            const double vj = ok ? v[j] : 0.0;
+            const double wj = ok ? wt[j] : 0.0;
+            const double vd = __builtin_fma(zr, uj, -(zi * vj));        // Re((zr + i zi)(u + i v))
+            const double e = wj * (vd - acc[q]);                         // equations.py:202
+            ss = __builtin_fma(e, e, ss);
+            if (WRITE_R && ok) R_out[particle * N + j] = e;
+            const double nzr = __builtin_fma(zr, rr, -(zi * ri));        // z *= rho
+            zi = __builtin_fma(zr, ri, zi * rr);
+            zr = nzr;
+        }
+    }
+
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        if (nseg == 1)
+            out[particle] = sqrt(ss / (double)N);
+        else
+            out[particle * nseg + seg] = ss;
+    }
+}
+
+// f[i] = sqrt( (sum of the particle's segment partials, in segment order) / N )
+__global__ void finalize_kernel(const double *__restrict__ partial, int64_t S, int nseg, int64_t N,
+                                double *__restrict__ f)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    double ss = 0.0;
+    for (int s = 0; s < nseg; ++s) ss += partial[i * nseg + s];
+    f[i] = sqrt(ss / (double)N);
+}
+
+// per-chunk (min, max) of the centred grid: one wave per chunk
+__global__ void chunk_minmax_kernel(const double *__restrict__ wc, int64_t N, int64_t n_chunks,
+                                    double2 *__restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t c = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    double lo = INFINITY, hi = -INFINITY;
+    for (int q = 0; q < kPointsPerLane; ++q) {
+        const int64_t j = c * kChunk + q * kWave + lane;
+        if (j < N) {
+            const double x = wc[j];
+            lo = fmin(lo, x);
+            hi = fmax(hi, x);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, off, kWave));
+        hi = fmax(hi, __shfl_down(hi, off, kWave));
+    }
+    if (lane == 0) out[c] = make_double2(lo, hi);
+}
+
+__global__ void centre_kernel(const double *__restrict__ w, int64_t N, double w0, double *__restrict__ wc)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < N) wc[j] = w[j] - w0;
+}
+
+template <int VARIANT>
+int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *out, double *dR,
+                   int nseg, int64_t seg_len, int64_t blocks, size_t lds)
+{
+    if (dR)
+        hipLaunchKernelGGL((objective_kernel<VARIANT, true>), dim3((unsigned)blocks), dim3(kBlock), lds,
+                           ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,
+                           ctx->N, ctx->w0, nseg, seg_len, out, dR);
+    else
+        hipLaunchKernelGGL((objective_kernel<VARIANT, false>), dim3((unsigned)blocks), dim3(kBlock), lds,
+                           ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,
+                           ctx->N, ctx->w0, nseg, seg_len, out, dR);
+    NMRFIT_HIP(hipGetLastError());
+    return NMRFIT_OK;
+}
+
+}  // namespace
+
+// Builds the derived device arrays of a context (centred grid, chunk table).
+int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw)
+{
+    const int64_t N = ctx->N;
+    hipLaunchKernelGGL(centre_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_w_raw, N,
+                       ctx->w0, ctx->d_wc);
+    NMRFIT_HIP(hipGetLastError());
+    const int waves_per_block = 4;
+    hipLaunchKernelGGL(chunk_minmax_kernel, dim3((unsigned)((ctx->n_chunks + waves_per_block - 1) / waves_per_block)),
+                       dim3(kWave * waves_per_block), 0, ctx->stream, ctx->d_wc, N, ctx->n_chunks, ctx->d_chunk);
+    NMRFIT_HIP(hipGetLastError());
+    return NMRFIT_OK;
+}
+
+int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR)
+{
+    if (S == 0) return NMRFIT_OK;
+    const int64_t N = ctx->N;
+    // Segmenting: aim for >= 4 waves per SIMD across the chip; a segment is a whole number
+    // of 512-point chunks.  Large swarms get nseg = 1 (one wave per particle, f written
+    // directly); small ones split the grid.
+    const int64_t target_waves = (int64_t)ctx->compute_units * 4 * 4;
+    const int64_t max_seg = (N + kChunk - 1) / kChunk;
+    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(max_seg, (target_waves + S - 1) / S));
+    int64_t seg_len = ((N + nseg - 1) / nseg + kChunk - 1) / kChunk * kChunk;
+    nseg = (N + seg_len - 1) / seg_len;
+    const int64_t waves = S * nseg;
+    const int64_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 0x7fffffffLL) {
+        set_error("swarm too large for one launch");
+        return NMRFIT_E_INVALID;
+    }
+    const size_t lds = (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(PeakRec);
+    double *out = df;
+    if (nseg > 1) {
+        int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, waves);
+        if (rc != NMRFIT_OK) return rc;
+        out = ctx->d_partial;
+    }
+    int rc;
+    switch (ctx->variant) {
+        case NMRFIT_VARIANT_BASELINE:
+            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            break;
+        case NMRFIT_VARIANT_NOSKIP:
+            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            break;
+        default:
+            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            break;
+    }
+    if (rc != NMRFIT_OK) return rc;
+    if (nseg > 1) {
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->d_partial, S, (int)nseg, N, df);
+        NMRFIT_HIP(hipGetLastError());
+    }
+    ctx->last.waves = waves;
+    ctx->last.nseg = (int32_t)nseg;
+    ctx->last.seg_len = seg_len;
+    return NMRFIT_OK;
+}
+
+}  // namespace nmrfit

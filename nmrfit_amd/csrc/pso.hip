@@ -1,0 +1,529 @@
+// pso.hip -- device-resident particle-swarm loop around the batched objective.
+//
+// Replaces pyswarm.pso as nmrfit calls it (nmrfit/utils.py:176-182; pyswarm is a third-party
+// dependency that is not vendored in the reference, github.com/tisimst/pyswarm master,
+// pso.py -- its published algorithm is restated here).  pyswarm evaluates one particle per
+// Python call; here the whole swarm state stays in HBM and a generation is five launches:
+//
+//   update   v = omega*v + phip*rp*(p-x) + phig*rg*(g-x);  x = clip(x+v, lb, ub)
+//   evaluate fx = objective_batch(x)                        (objective.hip)
+//   pbest    where fx < fp:  p = x, fp = fx
+//   argmin   candidate = (min fp, p[argmin])  of THIS rank's shard   -> (D+1) doubles
+//   apply    fold the gathered candidates of all ranks into (g, fg) with pyswarm's
+//            minfunc/minstep stopping rule; every rank computes the same answer
+//
+// Only the candidate record crosses ranks (one RCCL all-gather per generation, done by the
+// caller on the candidate buffer).  Random numbers are Philox4x32-10 keyed by the seed with
+// counter (generation, dimension, GLOBAL particle index): the swarm's trajectory does not
+// depend on how it is sharded.  After a stop is flagged on the device every later launch is
+// a no-op, so the host may poll the flag every k generations without changing the result.
+#include "nmrfit_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <new>
+
+struct nmrfit_pso {
+    nmrfit_ctx *ctx = nullptr;
+    int64_t S = 0, S_global = 0, offset = 0;
+    int32_t P = 0;
+    int64_t D = 0;
+    nmrfit_pso_params prm{};
+    double *d_lb = nullptr, *d_ub = nullptr;
+    double *d_x = nullptr, *d_v = nullptr, *d_p = nullptr;
+    double *d_fx = nullptr, *d_fp = nullptr;
+    double *d_cand = nullptr;          // (D+1): f_best, x_best (own buffer or caller's)
+    double *d_cand_own = nullptr;
+    long long *d_flags = nullptr;      // [0] completed generations, [1] stop code
+    double *d_best = nullptr;          // [0] fg, [1] best_f, [2..2+D) g, [2+D..2+2D) best_x
+    bool initialized = false;    // nmrfit_pso_init has run
+    bool seeded = false;         // the generation-0 candidates have been folded into (g, fg)
+};
+
+namespace nmrfit {
+namespace {
+
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// two uniforms in [0,1) with 53 random bits each
+__device__ __forceinline__ void uniform2(uint64_t seed, uint32_t gen, uint32_t dim, uint64_t particle, double *a,
+                                         double *b)
+{
+    U4 c{gen, dim, (uint32_t)particle, (uint32_t)(particle >> 32)};
+    const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint64_t ua = ((uint64_t)o.y << 32) | o.x;
+    const uint64_t ub = ((uint64_t)o.w << 32) | o.z;
+    *a = (double)(ua >> 11) * 0x1.0p-53;
+    *b = (double)(ub >> 11) * 0x1.0p-53;
+}
+
+// The swarm arithmetic is written without fused multiply-add so that it is bit-identical to
+// the numpy mirror in nmrfit_amd/pso.py (IEEE mul/add in numpy's evaluation order).
+#pragma clang fp contract(off)
+
+__global__ void pso_init_kernel(int64_t S, int64_t D, int64_t offset, uint64_t seed, const double *__restrict__ lb,
+                                const double *__restrict__ ub, double *__restrict__ x, double *__restrict__ v,
+                                double *__restrict__ p, double *__restrict__ fp)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * D) return;
+    const int64_t i = idx / D;
+    const int d = (int)(idx - i * D);
+    double r0, r1;
+    uniform2(seed, 0u, (uint32_t)d, (uint64_t)(offset + i), &r0, &r1);
+    const double lo = lb[d], hi = ub[d];
+    const double vhigh = fabs(hi - lo), vlow = -vhigh;
+    x[idx] = lo + r0 * (hi - lo);
+    v[idx] = vlow + r1 * (vhigh - vlow);
+    p[idx] = 0.0;
+    if (d == 0) fp[i] = INFINITY;
+}
+
+__global__ void pso_update_kernel(int64_t S, int64_t D, int64_t offset, uint64_t seed, double omega, double phip,
+                                  double phig, const long long *__restrict__ flags, const double *__restrict__ best,
+                                  const double *__restrict__ lb, const double *__restrict__ ub,
+                                  const double *__restrict__ p, double *__restrict__ x, double *__restrict__ v)
+{
+    if (flags[1] != 0) return;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * D) return;
+    const int64_t i = idx / D;
+    const int d = (int)(idx - i * D);
+    const uint32_t gen = (uint32_t)(flags[0] + 1);
+    double rp, rg;
+    uniform2(seed, gen, (uint32_t)d, (uint64_t)(offset + i), &rp, &rg);
+    const double g = best[2 + d];
+    const double xo = x[idx];
+    const double a = omega * v[idx];
+    const double b = (phip * rp) * (p[idx] - xo);
+    const double c = (phig * rg) * (g - xo);
+    const double vn = (a + b) + c;
+    double xn = xo + vn;
+    const double lo = lb[d], hi = ub[d];
+    if (xn < lo) xn = lo;
+    if (xn > hi) xn = hi;
+    v[idx] = vn;
+    x[idx] = xn;
+}
+
+// one wave per particle: personal-best update (pyswarm: i_update = fx < fp)
+__global__ void pso_pbest_kernel(int64_t S, int64_t D, const long long *__restrict__ flags,
+                                 const double *__restrict__ x, const double *__restrict__ fx, double *__restrict__ p,
+                                 double *__restrict__ fp)
+{
+    if (flags[1] != 0) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
+    if (i >= S) return;
+    const double f = fx[i];
+    if (!(f < fp[i])) return;
+    for (int64_t d = lane; d < D; d += kWave) p[i * D + d] = x[i * D + d];
+    if (lane == 0) fp[i] = f;
+}
+
+// single block: first index of the minimum of fp (np.argmin) -> candidate record
+__global__ __launch_bounds__(1024) void pso_argmin_kernel(int64_t S, int64_t D, const long long *__restrict__ flags,
+                                                          const double *__restrict__ fp, const double *__restrict__ p,
+                                                          double *__restrict__ cand)
+{
+    if (flags[1] != 0) return;
+    __shared__ double s_val[16];
+    __shared__ long long s_idx[16];
+    double best = INFINITY;
+    long long bi = 0x7fffffffffffffffLL;
+    for (int64_t i = threadIdx.x; i < S; i += blockDim.x) {
+        const double f = fp[i];
+        if (f < best) {   // strict: the first (lowest) index wins ties within a thread's stride
+            best = f;
+            bi = i;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(best, off, kWave);
+        const long long oi = __shfl_down(bi, off, kWave);
+        if (ob < best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_val[wave] = best;
+        s_idx[wave] = bi;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int nw = blockDim.x / kWave;
+        best = (lane < nw) ? s_val[lane] : INFINITY;
+        bi = (lane < nw) ? s_idx[lane] : 0x7fffffffffffffffLL;
+        for (int off = 8; off > 0; off >>= 1) {
+            const double ob = __shfl_down(best, off, kWave);
+            const long long oi = __shfl_down(bi, off, kWave);
+            if (ob < best || (ob == best && oi < bi)) {
+                best = ob;
+                bi = oi;
+            }
+        }
+        bi = __shfl(bi, 0, kWave);
+        best = __shfl(best, 0, kWave);
+        if (bi >= S) bi = 0;   // every fp is +inf (or S == 0 handled by the host): np.argmin -> 0
+        if (lane == 0) cand[0] = (S > 0) ? fp[bi] : INFINITY;
+        for (int64_t d = lane; d < D; d += kWave) cand[1 + d] = (S > 0) ? p[bi * D + d] : 0.0;
+    }
+}
+
+// single wave: fold candidates, apply pyswarm's acceptance / stopping rule
+__global__ void pso_apply_kernel(int64_t D, int nranks, int is_init, double minstep, double minfunc,
+                                 const double *__restrict__ cands, long long *__restrict__ flags,
+                                 double *__restrict__ best)
+{
+    if (flags[1] != 0) return;
+    const int lane = threadIdx.x;
+    // lowest value wins, lowest rank wins ties (every rank sees the same records)
+    int win = 0;
+    double fc = cands[0];
+    for (int r = 1; r < nranks; ++r) {
+        const double f = cands[(int64_t)r * (D + 1)];
+        if (f < fc) {
+            fc = f;
+            win = r;
+        }
+    }
+    const double *pc = cands + (int64_t)win * (D + 1) + 1;
+    double *g = best + 2, *bx = best + 2 + D;
+    const double fg = best[0];
+    if (is_init) {
+        for (int64_t d = lane; d < D; d += kWave) {
+            g[d] = pc[d];
+            bx[d] = pc[d];
+        }
+        if (lane == 0) {
+            best[0] = fc;
+            best[1] = fc;
+            flags[0] = 0;
+        }
+        return;
+    }
+    int code = 0;   // 0: not better, 1: stop minfunc, 2: stop minstep, 3: accept
+    if (fc < fg) {
+        double acc = 0.0;
+        for (int64_t d = lane; d < D; d += kWave) {
+            const double df = g[d] - pc[d];
+            acc += df * df;
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
+        acc = __shfl(acc, 0, kWave);
+        const double stepsize = sqrt(acc);
+        if (fabs(fg - fc) <= minfunc)
+            code = 1;
+        else if (stepsize <= minstep)
+            code = 2;
+        else
+            code = 3;
+    }
+    if (code == 1 || code == 2) {
+        for (int64_t d = lane; d < D; d += kWave) bx[d] = pc[d];
+        if (lane == 0) {
+            best[1] = fc;
+            flags[1] = code;
+        }
+    } else if (code == 3) {
+        for (int64_t d = lane; d < D; d += kWave) {
+            g[d] = pc[d];
+            bx[d] = pc[d];
+        }
+        if (lane == 0) {
+            best[0] = fc;
+            best[1] = fc;
+        }
+    }
+    if (lane == 0) flags[0] = flags[0] + 1;
+}
+
+int bind_pso(const nmrfit_pso *pso)
+{
+    if (!pso || !pso->ctx) {
+        set_error("null swarm handle");
+        return NMRFIT_E_INVALID;
+    }
+    NMRFIT_HIP(hipSetDevice(pso->ctx->device));
+    return NMRFIT_OK;
+}
+
+int evaluate_and_select(nmrfit_pso *pso)
+{
+    nmrfit_ctx *ctx = pso->ctx;
+    const int64_t S = pso->S, D = pso->D;
+    int rc = launch_objective(ctx, S, pso->P, pso->d_x, pso->d_fx, nullptr);
+    if (rc != NMRFIT_OK) return rc;
+    if (S > 0) {
+        const int wpb = 4;
+        hipLaunchKernelGGL(pso_pbest_kernel, dim3((unsigned)((S + wpb - 1) / wpb)), dim3(kWave * wpb), 0, ctx->stream, S,
+                           D, pso->d_flags, pso->d_x, pso->d_fx, pso->d_p, pso->d_fp);
+        NMRFIT_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(pso_argmin_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, D, pso->d_flags, pso->d_fp, pso->d_p,
+                       pso->d_cand);
+    NMRFIT_HIP(hipGetLastError());
+    return NMRFIT_OK;
+}
+
+}  // namespace
+}  // namespace nmrfit
+
+using namespace nmrfit;
+
+extern "C" {
+
+int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_t offset, int32_t P,
+                      const double *lower, const double *upper, const nmrfit_pso_params *params, nmrfit_pso **out)
+{
+    if (!out) {
+        set_error("null out pointer");
+        return NMRFIT_E_INVALID;
+    }
+    *out = nullptr;
+    if (!ctx || !lower || !upper || !params || S_local < 0 || S_global <= 0 || offset < 0 ||
+        offset + S_local > S_global || P < 0 || P > kMaxPeaks) {
+        set_error("nmrfit_pso_create: bad arguments");
+        return NMRFIT_E_INVALID;
+    }
+    const int64_t D = 4 + 3 * (int64_t)P;
+    for (int64_t d = 0; d < D; ++d) {
+        if (!(upper[d] > lower[d])) {   // pyswarm: assert np.all(ub > lb)
+            set_error("All upper-bound values must be greater than lower-bound values");
+            return NMRFIT_E_INVALID;
+        }
+    }
+    NMRFIT_HIP(hipSetDevice(ctx->device));
+    nmrfit_pso *pso = new (std::nothrow) nmrfit_pso();
+    if (!pso) {
+        set_error("out of host memory");
+        return NMRFIT_E_INVALID;
+    }
+    pso->ctx = ctx;
+    pso->S = S_local;
+    pso->S_global = S_global;
+    pso->offset = offset;
+    pso->P = P;
+    pso->D = D;
+    pso->prm = *params;
+    const size_t sd = (size_t)std::max<int64_t>(S_local * D, 1) * sizeof(double);
+    const size_t s1 = (size_t)std::max<int64_t>(S_local, 1) * sizeof(double);
+#define PSO_HIP(call)                                                   \
+    do {                                                                \
+        hipError_t _e = (call);                                         \
+        if (_e != hipSuccess) {                                         \
+            int _rc = hip_fail(_e, #call, __FILE__, __LINE__);          \
+            nmrfit_pso_destroy(pso);                                    \
+            return _rc;                                                 \
+        }                                                               \
+    } while (0)
+    PSO_HIP(hipMalloc((void **)&pso->d_lb, (size_t)D * sizeof(double)));
+    PSO_HIP(hipMalloc((void **)&pso->d_ub, (size_t)D * sizeof(double)));
+    PSO_HIP(hipMalloc((void **)&pso->d_x, sd));
+    PSO_HIP(hipMalloc((void **)&pso->d_v, sd));
+    PSO_HIP(hipMalloc((void **)&pso->d_p, sd));
+    PSO_HIP(hipMalloc((void **)&pso->d_fx, s1));
+    PSO_HIP(hipMalloc((void **)&pso->d_fp, s1));
+    PSO_HIP(hipMalloc((void **)&pso->d_cand_own, (size_t)(D + 1) * sizeof(double)));
+    pso->d_cand = pso->d_cand_own;
+    PSO_HIP(hipMalloc((void **)&pso->d_flags, 2 * sizeof(long long)));
+    PSO_HIP(hipMalloc((void **)&pso->d_best, (size_t)(2 + 2 * D) * sizeof(double)));
+    PSO_HIP(hipMemcpyAsync(pso->d_lb, lower, (size_t)D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PSO_HIP(hipMemcpyAsync(pso->d_ub, upper, (size_t)D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PSO_HIP(hipMemsetAsync(pso->d_flags, 0, 2 * sizeof(long long), ctx->stream));
+    PSO_HIP(hipMemsetAsync(pso->d_best, 0, (size_t)(2 + 2 * D) * sizeof(double), ctx->stream));
+    PSO_HIP(hipStreamSynchronize(ctx->stream));
+#undef PSO_HIP
+    *out = pso;
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_destroy(nmrfit_pso *pso)
+{
+    if (!pso) return NMRFIT_OK;
+    if (pso->ctx) {
+        (void)hipSetDevice(pso->ctx->device);
+        (void)hipStreamSynchronize(pso->ctx->stream);
+    }
+    void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_p, pso->d_fx, pso->d_fp, pso->d_cand_own, pso->d_flags, pso->d_best};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    delete pso;
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_init(nmrfit_pso *pso)
+{
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    nmrfit_ctx *ctx = pso->ctx;
+    const int64_t n = pso->S * pso->D;
+    NMRFIT_HIP(hipMemsetAsync(pso->d_flags, 0, 2 * sizeof(long long), ctx->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(pso_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pso->S, pso->D,
+                           pso->offset, pso->prm.seed, pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_p, pso->d_fp);
+        NMRFIT_HIP(hipGetLastError());
+    }
+    rc = evaluate_and_select(pso);
+    if (rc != NMRFIT_OK) return rc;
+    pso->initialized = true;
+    pso->seeded = false;
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_step_local(nmrfit_pso *pso)
+{
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    if (!pso->initialized) {
+        set_error("nmrfit_pso_step_local before nmrfit_pso_init");
+        return NMRFIT_E_STATE;
+    }
+    nmrfit_ctx *ctx = pso->ctx;
+    const int64_t n = pso->S * pso->D;
+    if (n > 0) {
+        hipLaunchKernelGGL(pso_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pso->S,
+                           pso->D, pso->offset, pso->prm.seed, pso->prm.omega, pso->prm.phip, pso->prm.phig,
+                           pso->d_flags, pso->d_best, pso->d_lb, pso->d_ub, pso->d_p, pso->d_x, pso->d_v);
+        NMRFIT_HIP(hipGetLastError());
+    }
+    return evaluate_and_select(pso);
+}
+
+int nmrfit_pso_candidate_dev(nmrfit_pso *pso, double **dptr)
+{
+    if (!pso || !dptr) {
+        set_error("null argument");
+        return NMRFIT_E_INVALID;
+    }
+    *dptr = pso->d_cand;
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_set_candidate_dev(nmrfit_pso *pso, double *dptr)
+{
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipStreamSynchronize(pso->ctx->stream));
+    double *next = dptr ? dptr : pso->d_cand_own;
+    if (next != pso->d_cand) {   // carry the current record over
+        NMRFIT_HIP(hipMemcpy(next, pso->d_cand, (size_t)(pso->D + 1) * sizeof(double), hipMemcpyDeviceToDevice));
+        pso->d_cand = next;
+    }
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_apply_global_dev(nmrfit_pso *pso, const double *d_candidates, int32_t nranks)
+{
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    if (!d_candidates || nranks < 1) {
+        set_error("nmrfit_pso_apply_global_dev: bad arguments");
+        return NMRFIT_E_INVALID;
+    }
+    if (!pso->initialized) {
+        set_error("nmrfit_pso_apply_global_dev before nmrfit_pso_init");
+        return NMRFIT_E_STATE;
+    }
+    const int is_init = pso->seeded ? 0 : 1;   // first fold after init sets (g, fg) with no stop test
+    hipLaunchKernelGGL(pso_apply_kernel, dim3(1), dim3(kWave), 0, pso->ctx->stream, pso->D, (int)nranks, is_init,
+                       pso->prm.minstep, pso->prm.minfunc, d_candidates, pso->d_flags, pso->d_best);
+    NMRFIT_HIP(hipGetLastError());
+    pso->seeded = true;
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_status(nmrfit_pso *pso, int64_t *iteration, int32_t *stop_code, double *fg)
+{
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    long long flags[2];
+    double head[2];
+    hipStream_t st = pso->ctx->stream;
+    NMRFIT_HIP(hipMemcpyAsync(flags, pso->d_flags, sizeof flags, hipMemcpyDeviceToHost, st));
+    NMRFIT_HIP(hipMemcpyAsync(head, pso->d_best, sizeof head, hipMemcpyDeviceToHost, st));
+    NMRFIT_HIP(hipStreamSynchronize(st));
+    if (iteration) *iteration = flags[0];
+    if (stop_code) *stop_code = (int32_t)flags[1];
+    if (fg) *fg = head[0];
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_best(nmrfit_pso *pso, double *x_best, double *f_best)
+{
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    hipStream_t st = pso->ctx->stream;
+    if (x_best)
+        NMRFIT_HIP(hipMemcpyAsync(x_best, pso->d_best + 2 + pso->D, (size_t)pso->D * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (f_best) NMRFIT_HIP(hipMemcpyAsync(f_best, pso->d_best + 1, sizeof(double), hipMemcpyDeviceToHost, st));
+    NMRFIT_HIP(hipStreamSynchronize(st));
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
+{
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    if (maxiter < 0 || check_every < 1) {
+        set_error("nmrfit_pso_run: maxiter must be >= 0 and check_every >= 1");
+        return NMRFIT_E_INVALID;
+    }
+    if (!pso->initialized) {
+        if ((rc = nmrfit_pso_init(pso)) != NMRFIT_OK) return rc;
+    }
+    if (!pso->seeded) {
+        if ((rc = nmrfit_pso_apply_global_dev(pso, pso->d_cand, 1)) != NMRFIT_OK) return rc;
+    }
+    for (int64_t it = 1; it <= maxiter; ++it) {
+        if ((rc = nmrfit_pso_step_local(pso)) != NMRFIT_OK) return rc;
+        if ((rc = nmrfit_pso_apply_global_dev(pso, pso->d_cand, 1)) != NMRFIT_OK) return rc;
+        if (it % check_every == 0 || it == maxiter) {
+            int32_t stop = 0;
+            if ((rc = nmrfit_pso_status(pso, nullptr, &stop, nullptr)) != NMRFIT_OK) return rc;
+            if (stop) break;
+        }
+    }
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_get_state(nmrfit_pso *pso, double *x, double *v, double *p, double *fx, double *fp)
+{
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    hipStream_t st = pso->ctx->stream;
+    const size_t sd = (size_t)(pso->S * pso->D) * sizeof(double), s1 = (size_t)pso->S * sizeof(double);
+    if (sd) {
+        if (x) NMRFIT_HIP(hipMemcpyAsync(x, pso->d_x, sd, hipMemcpyDeviceToHost, st));
+        if (v) NMRFIT_HIP(hipMemcpyAsync(v, pso->d_v, sd, hipMemcpyDeviceToHost, st));
+        if (p) NMRFIT_HIP(hipMemcpyAsync(p, pso->d_p, sd, hipMemcpyDeviceToHost, st));
+        if (fx) NMRFIT_HIP(hipMemcpyAsync(fx, pso->d_fx, s1, hipMemcpyDeviceToHost, st));
+        if (fp) NMRFIT_HIP(hipMemcpyAsync(fp, pso->d_fp, s1, hipMemcpyDeviceToHost, st));
+    }
+    NMRFIT_HIP(hipStreamSynchronize(st));
+    return NMRFIT_OK;
+}
+
+}  // extern "C"

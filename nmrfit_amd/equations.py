@@ -1,0 +1,178 @@
+"""
+Host-side mirror of the reference's operator interface for the hot path
+(nmrfit/equations.py): same names and argument meaning, evaluated on the MI355X through
+libnmrfit_amd.so.
+
+    objective(x, w, u, v, weights, fit_im=False) -> float      nmrfit/equations.py:152
+    Evaluator(w, u, v, weights).objective_batch(X) -> f[S]     the batched form of the above
+    Evaluator(...).residual_batch(X) -> R[B, N]                weights*(V_data - V_fit), eq.py:202
+    laplace1d(x, n=10, omega=0.33333333)                       nmrfit/equations.py:215-238
+
+There is no CPU fallback in this module: without the HIP library and a gfx950 device every
+evaluation raises ``NmrfitError``.
+"""
+import ctypes
+import zlib
+
+import numpy as np
+
+from . import _cabi
+from ._cabi import NmrfitError  # noqa: F401  (re-export)
+
+
+class Evaluator:
+    """GPU-resident (w, u, v, weights) + the batched objective.  One per device/process.
+
+    Replaces the ``args=(w, u, v, weights, fit_im)`` tuple FitUtility.fit passes to the
+    optimiser for every call (nmrfit/utils.py:176)."""
+
+    def __init__(self, w, u, v, weights, device=0):
+        self._lib = _cabi.lib()
+        self._ctx = ctypes.c_void_p()
+        w, u, v, weights = (_cabi.f64(a) for a in (w, u, v, weights))
+        if not (w.ndim == u.ndim == v.ndim == weights.ndim == 1 and w.size == u.size == v.size == weights.size):
+            raise ValueError("w, u, v, weights must be 1-D arrays of equal length")
+        self.N = int(w.size)
+        self.device = device
+        _cabi.check(self._lib.nmrfit_ctx_create(device, self.N, _cabi.ptr(w), _cabi.ptr(u), _cabi.ptr(v),
+                                                _cabi.ptr(weights), ctypes.byref(self._ctx)))
+
+    # -- life cycle ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.nmrfit_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._ctx
+
+    # -- configuration ------------------------------------------------------------------
+    def set_weights(self, weights):
+        weights = _cabi.f64(weights)
+        if weights.shape != (self.N,):
+            raise ValueError("weights must have length N")
+        _cabi.check(self._lib.nmrfit_ctx_set_weights(self._ctx, _cabi.ptr(weights)))
+
+    def set_variant(self, variant):
+        _cabi.check(self._lib.nmrfit_ctx_set_variant(self._ctx, int(variant)))
+
+    def set_stream(self, stream_handle):
+        """Run on an externally owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream)
+        so that launches order with a collective library's work without host syncs."""
+        _cabi.check(self._lib.nmrfit_ctx_set_stream(self._ctx, ctypes.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        _cabi.check(self._lib.nmrfit_ctx_synchronize(self._ctx))
+
+    # -- the hot path, host pointers ------------------------------------------------------
+    @staticmethod
+    def _as_batch(X):
+        X = _cabi.f64(X)
+        if X.ndim == 1:
+            X = X[None, :]
+        if X.ndim != 2 or X.shape[1] < 4 or (X.shape[1] - 4) % 3:
+            raise ValueError("parameter matrix must be S x (4 + 3P)")
+        return X, (X.shape[1] - 4) // 3
+
+    def objective_batch(self, X, fit_im=False):
+        X, P = self._as_batch(X)
+        f = np.empty(X.shape[0], dtype=np.float64)
+        _cabi.check(self._lib.nmrfit_objective_batch(self._ctx, X.shape[0], P, _cabi.ptr(X), 1 if fit_im else 0,
+                                                     _cabi.ptr(f)))
+        return f
+
+    def residual_batch(self, X, return_f=False):
+        X, P = self._as_batch(X)
+        R = np.empty((X.shape[0], self.N), dtype=np.float64)
+        f = np.empty(X.shape[0], dtype=np.float64)
+        _cabi.check(self._lib.nmrfit_residual_batch(self._ctx, X.shape[0], P, _cabi.ptr(X), _cabi.ptr(R),
+                                                    _cabi.ptr(f)))
+        return (R, f) if return_f else R
+
+    # -- device-resident helpers (bench / swarm) ------------------------------------------
+    def dev_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        _cabi.check(self._lib.nmrfit_dev_alloc(self._ctx, int(nbytes), ctypes.byref(p)))
+        return p
+
+    def dev_free(self, dptr):
+        _cabi.check(self._lib.nmrfit_dev_free(self._ctx, dptr))
+
+    def upload(self, dptr, host):
+        host = np.ascontiguousarray(host)
+        _cabi.check(self._lib.nmrfit_memcpy_h2d(self._ctx, dptr, _cabi.ptr(host), host.nbytes))
+
+    def download(self, dptr, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype)
+        _cabi.check(self._lib.nmrfit_memcpy_d2h(self._ctx, _cabi.ptr(out), dptr, out.nbytes))
+        return out
+
+    def objective_batch_dev(self, S, P, dX, df):
+        _cabi.check(self._lib.nmrfit_objective_batch_dev(self._ctx, S, P, dX, df))
+
+    def residual_batch_dev(self, B, P, dX, dR, df=None):
+        _cabi.check(self._lib.nmrfit_residual_batch_dev(self._ctx, B, P, dX, dR, df))
+
+    def timer_begin(self):
+        _cabi.check(self._lib.nmrfit_timer_begin(self._ctx))
+
+    def timer_end(self):
+        ms = ctypes.c_double(0.0)
+        _cabi.check(self._lib.nmrfit_timer_end(self._ctx, ctypes.byref(ms)))
+        return ms.value
+
+    def last_launch(self):
+        waves, nseg, seg_len = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int64(0)
+        _cabi.check(self._lib.nmrfit_last_launch(self._ctx, ctypes.byref(waves), ctypes.byref(nseg),
+                                                 ctypes.byref(seg_len)))
+        return dict(waves=waves.value, segments=nseg.value, segment_len=seg_len.value)
+
+
+# ---- scalar shim with the reference signature ---------------------------------------------
+_shim_cache = {}
+_SHIM_CACHE_MAX = 4
+
+
+def _key(*arrays):
+    return tuple((a.size, zlib.adler32(a.view(np.uint8))) for a in arrays)
+
+
+def objective(x, w, u, v, weights, fit_im=False):
+    """Drop-in for nmrfit.equations.objective (equations.py:152): one particle, one float.
+    The constant arrays are cached on the GPU between calls (keyed by content), so a
+    third-party optimiser that calls this per particle still avoids re-uploading them; use
+    ``Evaluator.objective_batch`` to evaluate a whole swarm per launch."""
+    if fit_im:
+        raise NmrfitError(_cabi.E_UNSUPPORTED, "fit_im=True (Kramers-Kronig path, equations.py:197-209) "
+                                               "is not supported")
+    arrays = tuple(_cabi.f64(a) for a in (w, u, v, weights))
+    k = _key(*arrays)
+    ev = _shim_cache.get(k)
+    if ev is None:
+        if len(_shim_cache) >= _SHIM_CACHE_MAX:
+            _, old = _shim_cache.popitem()
+            old.close()
+        ev = Evaluator(*arrays)
+        _shim_cache[k] = ev
+    return float(ev.objective_batch(np.asarray(x, dtype=np.float64))[0])
+
+
+def laplace1d(x, n=10, omega=0.33333333):
+    """In-place 1-D Laplacian smoothing, end points fixed (equations.py:215-238).  Host code
+    in the reference too: it runs once per fit to build ``weights``."""
+    for _ in range(n):
+        x[1:-1] = (1. - omega) * x[1:-1] + omega * 0.5 * (x[2:] + x[:-2])
+    return x

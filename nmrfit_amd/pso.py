@@ -1,0 +1,329 @@
+"""
+Batched particle-swarm driver: the replacement for ``pyswarm.pso`` as the reference calls it
+(nmrfit/utils.py:176-182).  pyswarm (github.com/tisimst/pyswarm, unpinned master; not
+vendored in the reference) evaluates one particle per Python call; here a generation is one
+batched objective launch and the swarm state never leaves the GPU.
+
+Two implementations of the same generation, bit-compatible in the swarm arithmetic:
+
+``DeviceSwarm``   the product path: nmrfit_pso_* entry points of libnmrfit_amd.so
+                  (csrc/pso.hip).  State in HBM, Philox4x32-10 counter RNG on the device.
+``HostSwarm``     a numpy mirror of those kernels with an injectable ``evaluate(X) -> f``.
+                  Used to drive third-party evaluators and by the CPU tests of the sharding
+                  / exchange logic; it is NOT a fallback for DeviceSwarm (nothing selects it
+                  automatically).
+
+Sharding: rank q of G owns particles [offset, offset+S_local); the
+only cross-rank traffic is one all-gather of a (D+1)-double candidate record per generation
+(``TorchExchange``: RCCL when the process group is "nccl", gloo on CPU).  Random numbers are
+a function of (seed, generation, dimension, GLOBAL particle index), so the trajectory does
+not depend on the number of ranks.
+
+Stopping rule, restated from pyswarm: with (fc, pc) the best personal best after a
+generation, if fc < fg: stop when |fg - fc| <= minfunc, else stop when |g - pc| <= minstep,
+else accept (g, fg) = (pc, fc).  On a stop pyswarm returns (pc, fc).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _cabi
+
+DEFAULTS = dict(swarmsize=204, maxiter=2000, omega=-0.2134, phip=-0.3344, phig=2.3259,   # utils.py:177-181
+                minstep=1e-8, minfunc=1e-8)                                                 # pyswarm defaults
+
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = 0x9E3779B9, 0xBB67AE85
+_MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 (counter words c0..c3 as uint64 arrays holding 32-bit values)."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & _MASK for c in (c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)) & _MASK
+        n1 = p1 & _MASK
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)) & _MASK
+        n3 = p0 & _MASK
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + _W0) & 0xFFFFFFFF
+        k1 = (k1 + _W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def uniform2(seed, gen, S, D, offset):
+    """Two U[0,1) matrices [S, D] for generation ``gen`` -- identical to csrc/pso.hip uniform2."""
+    part = (np.arange(S, dtype=np.uint64) + np.uint64(offset))[:, None] + np.zeros((1, D), dtype=np.uint64)
+    dim = np.zeros((S, 1), dtype=np.uint64) + np.arange(D, dtype=np.uint64)[None, :]
+    gen_a = np.full((S, D), gen, dtype=np.uint64)
+    o0, o1, o2, o3 = philox4x32_10(gen_a, dim, part & _MASK, part >> np.uint64(32),
+                                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    ua = (o1 << np.uint64(32)) | o0
+    ub = (o3 << np.uint64(32)) | o2
+    scale = 2.0 ** -53
+    return (ua >> np.uint64(11)).astype(np.float64) * scale, (ub >> np.uint64(11)).astype(np.float64) * scale
+
+
+def shard(S_global, rank, world):
+    """Contiguous split of the swarm axis; the first S_global % world ranks get one extra."""
+    base, extra = divmod(S_global, world)
+    n = base + (1 if rank < extra else 0)
+    off = rank * base + min(rank, extra)
+    return off, n
+
+
+# ---- candidate exchange ---------------------------------------------------------------------
+class LocalExchange:
+    """Single rank: the gathered set is the rank's own candidate."""
+    world = 1
+    rank = 0
+
+    def gather_host(self, cand):
+        return cand[None, :]
+
+
+class TorchExchange:
+    """One all-gather of (D+1) doubles per generation over a torch.distributed group
+    (backend "nccl" = RCCL over xGMI on MI355X; "gloo" on CPU).  torch is plumbing only."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def gather_host(self, cand):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(cand))
+        out = torch.empty((self.world, t.numel()), dtype=t.dtype)
+        self._dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.numpy()
+
+    def gather_device(self, send, recv):
+        """send: cuda tensor (D+1), recv: cuda tensor (world, D+1); ordered on torch's current stream."""
+        self._dist.all_gather_into_tensor(recv, send, group=self.group)
+
+
+# ---- numpy mirror -----------------------------------------------------------------------------
+class HostSwarm:
+    def __init__(self, evaluate, lower, upper, swarmsize, offset=0, S_local=None, seed=0,
+                 omega=DEFAULTS["omega"], phip=DEFAULTS["phip"], phig=DEFAULTS["phig"],
+                 minstep=DEFAULTS["minstep"], minfunc=DEFAULTS["minfunc"]):
+        self.lb = np.array(lower, dtype=np.float64)
+        self.ub = np.array(upper, dtype=np.float64)
+        assert len(self.lb) == len(self.ub), 'Lower- and upper-bounds must be the same length'
+        assert np.all(self.ub > self.lb), 'All upper-bound values must be greater than lower-bound values'
+        self.evaluate = evaluate
+        self.S_global = int(swarmsize)
+        self.offset = int(offset)
+        self.S = self.S_global if S_local is None else int(S_local)
+        self.D = self.lb.size
+        self.seed = int(seed)
+        self.omega, self.phip, self.phig = omega, phip, phig
+        self.minstep, self.minfunc = minstep, minfunc
+        self.iteration, self.stop = 0, 0
+        self.fg = np.inf
+        self.g = np.zeros(self.D)
+        self.best_x, self.best_f = np.zeros(self.D), np.inf
+
+    def _select(self):
+        if self.S:
+            self.fx = np.asarray(self.evaluate(self.x), dtype=np.float64)
+            upd = self.fx < self.fp
+            self.p[upd, :] = self.x[upd, :]
+            self.fp[upd] = self.fx[upd]
+            i = int(np.argmin(self.fp))
+            self.cand = np.concatenate(([self.fp[i]], self.p[i, :]))
+        else:
+            self.fx = np.zeros(0)
+            self.cand = np.concatenate(([np.inf], np.zeros(self.D)))
+
+    def init(self):
+        r0, r1 = uniform2(self.seed, 0, self.S, self.D, self.offset)
+        vhigh = np.abs(self.ub - self.lb)
+        vlow = -vhigh
+        self.x = self.lb + r0 * (self.ub - self.lb)
+        self.v = vlow + r1 * (vhigh - vlow)
+        self.p = np.zeros_like(self.x)
+        self.fp = np.full(self.S, np.inf)
+        self.iteration, self.stop, self._seeded = 0, 0, False
+        self._select()
+
+    def step_local(self):
+        if self.stop:
+            return
+        rp, rg = uniform2(self.seed, self.iteration + 1, self.S, self.D, self.offset)
+        self.v = (self.omega * self.v + (self.phip * rp) * (self.p - self.x)) + (self.phig * rg) * (self.g - self.x)
+        x = self.x + self.v
+        x = np.where(x < self.lb, self.lb, x)
+        x = np.where(x > self.ub, self.ub, x)
+        self.x = x
+        self._select()
+
+    def candidate(self):
+        return self.cand
+
+    def apply_global(self, cands):
+        if self.stop:
+            return
+        cands = np.asarray(cands, dtype=np.float64).reshape(-1, self.D + 1)
+        win = int(np.argmin(cands[:, 0]))          # first minimum: lowest rank wins ties
+        fc, pc = cands[win, 0], cands[win, 1:]
+        if not self._seeded:
+            self.g, self.fg = pc.copy(), fc
+            self.best_x, self.best_f = pc.copy(), fc
+            self._seeded = True
+            self.iteration = 0
+            return
+        if fc < self.fg:
+            stepsize = np.sqrt(np.sum((self.g - pc) ** 2))
+            if np.abs(self.fg - fc) <= self.minfunc:
+                self.stop, self.best_x, self.best_f = 1, pc.copy(), fc
+            elif stepsize <= self.minstep:
+                self.stop, self.best_x, self.best_f = 2, pc.copy(), fc
+            else:
+                self.g, self.fg = pc.copy(), fc
+                self.best_x, self.best_f = pc.copy(), fc
+        self.iteration += 1
+
+
+# ---- the product path ---------------------------------------------------------------------------
+class DeviceSwarm:
+    """Device-resident swarm over an ``equations.Evaluator`` (csrc/pso.hip)."""
+
+    def __init__(self, evaluator, lower, upper, swarmsize, offset=0, S_local=None, seed=0,
+                 omega=DEFAULTS["omega"], phip=DEFAULTS["phip"], phig=DEFAULTS["phig"],
+                 minstep=DEFAULTS["minstep"], minfunc=DEFAULTS["minfunc"]):
+        self._lib = _cabi.lib()
+        self.ev = evaluator
+        lb, ub = _cabi.f64(lower), _cabi.f64(upper)
+        assert len(lb) == len(ub), 'Lower- and upper-bounds must be the same length'
+        assert np.all(ub > lb), 'All upper-bound values must be greater than lower-bound values'
+        self.D = int(lb.size)
+        if self.D < 4 or (self.D - 4) % 3:
+            raise ValueError("bounds must have 4 + 3P entries")
+        self.P = (self.D - 4) // 3
+        self.S_global = int(swarmsize)
+        self.offset = int(offset)
+        self.S = self.S_global if S_local is None else int(S_local)
+        prm = _cabi.PsoParams(omega, phip, phig, minstep, minfunc, int(seed) & 0xFFFFFFFFFFFFFFFF)
+        self._h = ctypes.c_void_p()
+        _cabi.check(self._lib.nmrfit_pso_create(evaluator.handle, self.S, self.S_global, self.offset, self.P,
+                                                _cabi.ptr(lb), _cabi.ptr(ub), ctypes.byref(prm),
+                                                ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.nmrfit_pso_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def init(self):
+        _cabi.check(self._lib.nmrfit_pso_init(self._h))
+
+    def step_local(self):
+        _cabi.check(self._lib.nmrfit_pso_step_local(self._h))
+
+    def candidate_dev(self):
+        p = ctypes.c_void_p()
+        _cabi.check(self._lib.nmrfit_pso_candidate_dev(self._h, ctypes.byref(p)))
+        return p
+
+    def set_candidate_dev(self, dptr):
+        _cabi.check(self._lib.nmrfit_pso_set_candidate_dev(self._h, ctypes.c_void_p(dptr) if dptr else None))
+
+    def candidate(self):
+        return self.ev.download(self.candidate_dev(), (self.D + 1,))
+
+    def apply_global_dev(self, d_cands, nranks):
+        _cabi.check(self._lib.nmrfit_pso_apply_global_dev(self._h, d_cands, int(nranks)))
+
+    def apply_global(self, cands):
+        """Host-array form: uploads the gathered records (used with gloo / tests)."""
+        cands = _cabi.f64(cands).reshape(-1, self.D + 1)
+        if getattr(self, "_d_gather", None) is None or self._gather_rows < cands.shape[0]:
+            self._d_gather = self.ev.dev_alloc(cands.nbytes)
+            self._gather_rows = cands.shape[0]
+        self.ev.upload(self._d_gather, cands)
+        self.apply_global_dev(self._d_gather, cands.shape[0])
+
+    def status(self):
+        it, stop, fg = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_double(0.0)
+        _cabi.check(self._lib.nmrfit_pso_status(self._h, ctypes.byref(it), ctypes.byref(stop), ctypes.byref(fg)))
+        return dict(iteration=it.value, stop=stop.value, fg=fg.value)
+
+    def best(self):
+        x = np.empty(self.D)
+        f = ctypes.c_double(0.0)
+        _cabi.check(self._lib.nmrfit_pso_best(self._h, _cabi.ptr(x), ctypes.byref(f)))
+        return x, f.value
+
+    def run(self, maxiter, check_every=16):
+        _cabi.check(self._lib.nmrfit_pso_run(self._h, int(maxiter), int(check_every)))
+
+    def state(self):
+        x = np.empty((self.S, self.D)); v = np.empty_like(x); p = np.empty_like(x)
+        fx = np.empty(self.S); fp = np.empty(self.S)
+        _cabi.check(self._lib.nmrfit_pso_get_state(self._h, _cabi.ptr(x), _cabi.ptr(v), _cabi.ptr(p),
+                                                   _cabi.ptr(fx), _cabi.ptr(fp)))
+        return dict(x=x, v=v, p=p, fx=fx, fp=fp)
+
+
+STOP_MESSAGES = {
+    1: 'Stopping search: Swarm best objective change less than {minfunc}',
+    2: 'Stopping search: Swarm best position change less than {minstep}',
+}
+
+
+def run_sharded(swarm, exchange, maxiter, check_every=1, verbose=False):
+    """Generation loop for a (possibly sharded) swarm with host-side candidate exchange.
+    Works for HostSwarm and DeviceSwarm; every rank must call it.  Returns (x_best, f_best)."""
+    swarm.init()
+    swarm.apply_global(exchange.gather_host(swarm.candidate()))
+    it = 0
+    stopped = 0
+    while it < maxiter:
+        it += 1
+        swarm.step_local()
+        swarm.apply_global(exchange.gather_host(swarm.candidate()))
+        if it % check_every == 0 or it == maxiter:
+            stopped = swarm.stop if isinstance(swarm, HostSwarm) else swarm.status()["stop"]
+            if stopped:
+                break
+    if verbose and exchange.rank == 0:
+        if stopped:
+            print(STOP_MESSAGES[stopped].format(minfunc=getattr(swarm, "minfunc", 1e-8),
+                                                minstep=getattr(swarm, "minstep", 1e-8)))
+        else:
+            print('Stopping search: maximum iterations reached --> {:}'.format(maxiter))
+    if isinstance(swarm, HostSwarm):
+        return swarm.best_x.copy(), float(swarm.best_f)
+    return swarm.best()
+
+
+def pso(evaluator, lb, ub, swarmsize=100, omega=0.5, phip=0.5, phig=0.5, maxiter=100, minstep=1e-8,
+        minfunc=1e-8, seed=0, check_every=16, verbose=True):
+    """pyswarm.pso-shaped entry point over a GPU ``Evaluator`` (single rank):
+    returns (xopt, fopt) like pyswarm does."""
+    sw = DeviceSwarm(evaluator, lb, ub, swarmsize, seed=seed, omega=omega, phip=phip, phig=phig,
+                     minstep=minstep, minfunc=minfunc)
+    try:
+        sw.run(maxiter, check_every)
+        st = sw.status()
+        if verbose:
+            if st["stop"]:
+                print(STOP_MESSAGES[st["stop"]].format(minfunc=minfunc, minstep=minstep))
+            else:
+                print('Stopping search: maximum iterations reached --> {:}'.format(maxiter))
+        return sw.best()
+    finally:
+        sw.close()

@@ -1,0 +1,78 @@
+"""
+CPU tier: the C-ABI library loads and exports every symbol include/nmrfit_amd.h declares,
+the ctypes table covers all of them, and -- with no GPU -- the product path fails loudly
+instead of falling back to anything.  No compute calls here.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from nmrfit_amd import _cabi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nmrfit_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nmrfit_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built_and_exports_every_declared_symbol():
+    if not os.path.exists(_cabi.LIB_PATH):
+        _cabi.build()
+    L = ctypes.CDLL(_cabi.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), "libnmrfit_amd.so does not export " + n
+
+
+def test_ctypes_table_covers_header():
+    names = set(_declared_symbols())
+    bound = set(_cabi.SIGNATURES) | {"nmrfit_last_error"}
+    assert names == bound, (names - bound, bound - names)
+
+
+def test_abi_version():
+    assert _cabi.lib().nmrfit_abi_version() == 1
+
+
+def test_no_silent_fallback_without_gpu():
+    """On a box without a GPU every evaluation must raise; on a GPU box this test checks the
+    invalid-device path instead."""
+    from nmrfit_amd import equations
+    w = np.linspace(0, 1, 64)
+    if _cabi.device_count() == 0:
+        with pytest.raises(equations.NmrfitError) as ei:
+            equations.Evaluator(w, w, w, w)
+        assert ei.value.code == _cabi.E_NO_DEVICE
+        with pytest.raises(equations.NmrfitError):
+            equations.objective(np.zeros(7), w, w, w, w)
+    else:
+        with pytest.raises(equations.NmrfitError) as ei:
+            equations.Evaluator(w, w, w, w, device=1 << 20)
+        assert ei.value.code == _cabi.E_NO_DEVICE
+
+
+def test_argument_validation_needs_no_gpu():
+    L = _cabi.lib()
+    out = ctypes.c_void_p()
+    rc = L.nmrfit_ctx_create(0, 0, None, None, None, None, ctypes.byref(out))
+    assert rc == _cabi.E_INVALID
+    assert b"N must be" in L.nmrfit_last_error()
+    assert L.nmrfit_ctx_destroy(None) == _cabi.OK
+    assert L.nmrfit_pso_destroy(None) == _cabi.OK
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "nmrfit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".sh")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in text.lower() or fn == "synth.py" and False, \
+                    "%s mentions the oracle: product code must not depend on it" % fn

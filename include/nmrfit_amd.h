@@ -46,9 +46,10 @@ enum {
 
 /* Kernel variants (numerics identical to <= 1e-12 relative; for A/B measurement). */
 enum {
-    NMRFIT_VARIANT_DEFAULT = 0,   /* the tuned fp64 kernel                                  */
-    NMRFIT_VARIANT_BASELINE = 1,  /* plain fp64: IEEE divide + libdevice exp2, no skipping  */
-    NMRFIT_VARIANT_NOSKIP = 2     /* tuned arithmetic, Gaussian evaluated everywhere        */
+    NMRFIT_VARIANT_DEFAULT = 0,   /* tuned fp64: 4 Lorentzians per reciprocal + Gaussian window skip */
+    NMRFIT_VARIANT_BASELINE = 1,  /* plain fp64: IEEE divide + libdevice exp2 per unit, no skipping  */
+    NMRFIT_VARIANT_NOSKIP = 2,    /* tuned arithmetic, Gaussian evaluated everywhere                 */
+    NMRFIT_VARIANT_SINGLE = 3     /* one reciprocal per unit + Gaussian window skip                  */
 };
 
 typedef struct nmrfit_ctx nmrfit_ctx;

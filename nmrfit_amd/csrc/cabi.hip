@@ -3,7 +3,9 @@
 // device memory and HIP-event timing helpers.  No exception leaves this file.
 #include "nmrfit_internal.h"
 
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -154,7 +156,9 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
     ctx->compute_units = prop.multiProcessorCount;
     ctx->N = N;
     ctx->n_chunks = (N + kChunk - 1) / kChunk;
+    if (const char *tw = getenv("NMRFIT_TARGET_WAVES")) ctx->target_waves = atoll(tw);   // tuning knob
     ctx->w0 = w[N / 2];
+    for (int64_t j = 0; j < N; ++j) ctx->wspan = std::fmax(ctx->wspan, std::fabs(w[j] - ctx->w0));
     const size_t bytes = (size_t)N * sizeof(double);
     double *d_w_raw = nullptr;
 #define CTX_HIP(call)                                                              \
@@ -242,7 +246,7 @@ int nmrfit_ctx_set_stream(nmrfit_ctx *ctx, void *hip_stream)
 
 int nmrfit_ctx_set_variant(nmrfit_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > NMRFIT_VARIANT_NOSKIP) {
+    if (!ctx || variant < 0 || variant > NMRFIT_VARIANT_SINGLE) {
         set_error("bad context or variant");
         return NMRFIT_E_INVALID;
     }

@@ -16,14 +16,16 @@ constexpr int kPointsPerLane = 8;    // grid points register-blocked per lane pe
 constexpr int kChunk = kWave * kPointsPerLane;   // 512 grid points per wave per chunk
 constexpr int kMaxPeaks = 1024;      // LDS: 4 waves x P x 48 B <= 192 KiB -> capped below
 
-// Per-(particle, peak) constants staged in LDS (48 B): see objective.hip.
-struct PeakRec {
-    double ihw;   // 2/width
+// Per-(particle, peak) constants staged in LDS: see objective.hip.
+struct PeakLor {
+    double ihw;   // 2/width (|t| capped at 1e18)
     double c;     // -(loc - w0) * ihw        so that t = (w_j - w0)*ihw + c
     double al;    // area*r*(2/(pi*width))    Lorentzian amplitude
     double ag2;   // 2*area*(1-r)*(2/width)*sqrt(ln2/pi)   Gaussian amplitude, factor 2 folds exp2(1)
-    double glo;   // (loc - w0) - G*width     the Gaussian is < 2^-kSkipExp outside [glo, ghi]
-    double ghi;
+};
+struct PeakWin {
+    double lo;    // (loc - w0) - G*width     the Gaussian is < 2^-64 of its amplitude outside [lo, hi]
+    double hi;
 };
 
 void set_error(const std::string &msg);
@@ -50,6 +52,8 @@ struct nmrfit_ctx {
     hipStream_t own_stream = nullptr;
     int64_t N = 0;
     double w0 = 0.0;             // centring offset: d_wc[j] = w[j] - w0
+    double wspan = 0.0;          // max_j |w[j] - w0|
+    int64_t target_waves = 0;    // launch-geometry override (0 = heuristic)
     double *d_wc = nullptr;      // centred grid
     double *d_u = nullptr, *d_v = nullptr, *d_wt = nullptr;
     double2 *d_chunk = nullptr;  // per 512-point chunk: (min, max) of the centred grid

@@ -14,13 +14,15 @@
 //     the w/u/v/weights reads are coalesced 512-B rows that stay L2-resident (the four
 //     arrays are shared by every particle: <= 2 MiB at N = 65536);
 //   * each lane register-blocks 8 grid points, so the per-peak constants are fetched once
-//     per 8 points.  They are wave-uniform and live in LDS (48 B per peak, read as three
-//     broadcast ds_read_b128), staged once per wave from the particle's row of X;
+//     per 8 points.  They are wave-uniform and live in LDS (48 B per peak; the main loop
+//     reads 24 B of it with broadcast ds_reads), staged once per wave from the particle's
+//     row of X;
 //   * algebra (derived from equations.py:141-147, exact in real arithmetic): with
 //     t = (w-loc)*(2/width), s = 1 + t^2:  L = (2/(pi*width))/s  and
 //     exp(-((w-loc)/(width/(2 sqrt(ln2))))^2) = 2^(-t^2) = 2*2^(-s), so one fma chain per
 //     point and peak: t = fma(wc, ihw, c); s = fma(t, t, 1); acc += AL*rcp(s) + AG2*exp2(-s);
-//   * rcp(s): v_rcp_f32 seed + one fp64 Newton step (relative error <= 2^-45);
+//   * the Lorentzians of four peaks share one reciprocal (common denominator s0 s1 s2 s3);
+//     rcp: v_rcp_f64 + one Newton step (relative error 2.2e-15);
 //     exp2(-s): round-to-nearest split + degree-11 polynomial + v_ldexp_f64 (<= 3e-16);
 //   * the Gaussian term is < 2^-64 of its amplitude once |w-loc| > 3.97*width; a wave
 //     skips it for a whole 512-point chunk when the chunk's [min,max] of w (precomputed
@@ -42,14 +44,16 @@ namespace {
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kInvPi = 0.31830988618379067154;
 constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
+constexpr int kQuadInterleave = 4;
 constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
 
 // ---- fp64 helpers (coefficients: tools/gen_poly.py) ---------------------------------------
 
-// 1/s for finite s >= 1: f32 hardware reciprocal (1 ulp) refined by one Newton step.
-__device__ __forceinline__ double rcp_refined(double s)
+// 1/s: v_rcp_f64 (measured 4.6e-8 relative on gfx950) + one Newton step -> 2.2e-15, full fp64
+// range.  Same issue cost as an f32 seed (16 cycles vs cvt + v_rcp_f32 + cvt) and more accurate.
+__device__ __forceinline__ double rcp64(double s)
 {
-    const double r0 = (double)__builtin_amdgcn_rcpf((float)s);
+    const double r0 = __builtin_amdgcn_rcp(s);
     const double e = __builtin_fma(-s, r0, 1.0);
     return __builtin_fma(r0, e, r0);
 }
@@ -119,24 +123,94 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
+// ---- per-chunk building blocks ---------------------------------------------------------------
+// Per-(particle, peak) constants in LDS, two arrays per wave: PeakLor (32 B: read in the main
+// loop as one broadcast ds_read_b128 + one ds_read_b64) and PeakWin (16 B: Gaussian window).
+
+// Lorentzian of ONE peak at the lane's 8 points: acc += AL / (1 + t^2)
+__device__ __forceinline__ void lorentz_single(const PeakLor *r, const double (&wv)[kPointsPerLane],
+                                               double (&acc)[kPointsPerLane])
+{
+    const double ihw = r->ihw, c = r->c, al = r->al;
+#pragma unroll
+    for (int q = 0; q < kPointsPerLane; ++q) {
+        const double t = __builtin_fma(wv[q], ihw, c);
+        const double s = __builtin_fma(t, t, 1.0);
+        acc[q] = __builtin_fma(al, rcp64(s), acc[q]);
+    }
+}
+
+// Lorentzians of FOUR peaks over one common denominator: with s_k = 1 + t_k^2 >= 1,
+//   sum_k AL_k/s_k = [ (AL0 s1 + AL1 s0) s2 s3 + (AL2 s3 + AL3 s2) s0 s1 ] / (s0 s1 s2 s3)
+// -> one reciprocal per four (point, peak) units: 17 fp64 FMA-class ops + v_rcp_f64 + 2 Newton
+// FMAs, against 4 x (5 FMA + v_rcp_f64) done one by one.  All products are of factors >= 1 and
+// |t| is capped at 1e18 when the record is staged, so the denominator stays below 1e145.
+__device__ __forceinline__ void lorentz_quad(const PeakLor *r, const double (&wv)[kPointsPerLane],
+                                             double (&acc)[kPointsPerLane])
+{
+    const double i0 = r[0].ihw, c0 = r[0].c, a0 = r[0].al;
+    const double i1 = r[1].ihw, c1 = r[1].c, a1 = r[1].al;
+    const double i2 = r[2].ihw, c2 = r[2].c, a2 = r[2].al;
+    const double i3 = r[3].ihw, c3 = r[3].c, a3 = r[3].al;
+#pragma unroll
+    for (int q = 0; q < kPointsPerLane; ++q) {
+        const double t0 = __builtin_fma(wv[q], i0, c0);
+        const double t1 = __builtin_fma(wv[q], i1, c1);
+        const double t2 = __builtin_fma(wv[q], i2, c2);
+        const double t3 = __builtin_fma(wv[q], i3, c3);
+        const double s0 = __builtin_fma(t0, t0, 1.0);
+        const double s1 = __builtin_fma(t1, t1, 1.0);
+        const double s2 = __builtin_fma(t2, t2, 1.0);
+        const double s3 = __builtin_fma(t3, t3, 1.0);
+        const double p01 = s0 * s1;
+        const double n01 = __builtin_fma(a0, s1, a1 * s0);
+        const double p23 = s2 * s3;
+        const double n23 = __builtin_fma(a2, s3, a3 * s2);
+        const double den = p01 * p23;
+        const double num = __builtin_fma(n01, p23, n23 * p01);
+        acc[q] = __builtin_fma(num, rcp64(den), acc[q]);
+        // let the scheduler interleave at most kQuadInterleave points: all 8 at once needs
+        // > 128 VGPRs (spills), which costs more than the extra latency hiding buys
+        if ((q + 1) % kQuadInterleave == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Gaussian of one peak: acc += AG2 * 2^-(1 + t^2)   (t recomputed: cheaper than keeping s live)
+__device__ __forceinline__ void gauss_add(const PeakLor *r, const double (&wv)[kPointsPerLane],
+                                          double (&acc)[kPointsPerLane])
+{
+    const double ihw = r->ihw, c = r->c, ag2 = r->ag2;
+#pragma unroll
+    for (int q = 0; q < kPointsPerLane; ++q) {
+        const double t = __builtin_fma(wv[q], ihw, c);
+        const double s = __builtin_fma(t, t, 1.0);
+        acc[q] = __builtin_fma(ag2, exp2_neg(-s), acc[q]);
+    }
+}
+
 // ---- the kernel ----------------------------------------------------------------------------
-// VARIANT: NMRFIT_VARIANT_DEFAULT (tuned + Gaussian window skip), _BASELINE (IEEE divide and
-// libdevice exp2, no skip: the obviously-right form the tuned ones are A/B-checked against),
-// _NOSKIP (tuned arithmetic, Gaussian everywhere).
+// VARIANT: NMRFIT_VARIANT_DEFAULT  quad-grouped Lorentzians + Gaussian window skip
+//          NMRFIT_VARIANT_BASELINE IEEE divide and libdevice exp2 per unit, no skip: the
+//                                  obviously-right form the tuned ones are A/B-checked against
+//          NMRFIT_VARIANT_NOSKIP   quad-grouped, Gaussian evaluated everywhere
+//          NMRFIT_VARIANT_SINGLE   one reciprocal per unit + Gaussian window skip
 // Wave g = blockIdx.x*4 + wave  ->  particle g / nseg, segment g % nseg;
 // a segment is seg_len (multiple of 512) consecutive grid points.
 template <int VARIANT, bool WRITE_R>
-__global__ __launch_bounds__(kBlock) void objective_kernel(
+__global__ __launch_bounds__(kBlock, 4) void objective_kernel(
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax,
-    const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, int nseg, int64_t seg_len,
+    const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, double wspan, int nseg,
+    int64_t seg_len,
     double *__restrict__ out,       // nseg == 1: f[S];  else partial sums [S*nseg]
     double *__restrict__ R_out)     // WRITE_R: residual rows [S*N]
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    PeakRec *recs = reinterpret_cast<PeakRec *>(lds_raw) + (size_t)wave * P;
+    PeakLor *lor = reinterpret_cast<PeakLor *>(lds_raw) + (size_t)wave * P;
+    PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)kWavesPerBlock * P * sizeof(PeakLor)) +
+                   (size_t)wave * P;
 
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const bool active = g < S * nseg;
@@ -147,20 +221,23 @@ __global__ __launch_bounds__(kBlock) void objective_kernel(
 
     const double p0 = x[0], p1 = x[1], r = x[2], yoff = x[3];   // equations.py:177
 
-    // stage this particle's per-peak constants in the wave's LDS slice
+    // stage this particle's per-peak constants in the wave's LDS slices
     for (int k = lane; k < P; k += kWave) {
         const double width = x[4 + 3 * k], loc = x[5 + 3 * k], a = x[6 + 3 * k];
         const double ihw = 2.0 / width;
         const double locc = loc - w0;
-        PeakRec rec;
-        rec.ihw = ihw;
-        rec.c = -locc * ihw;
+        // |t| <= 1e18 keeps the grouped denominators finite; the cap only engages for widths
+        // below 2e-18 of the spectral span, where L and G are 0 to 1e-36 either way
+        const double lim = 1.0e18 / (wspan + fabs(locc));
+        const double it = (fabs(ihw) > lim) ? copysign(lim, ihw) : ihw;
+        PeakLor rec;
+        rec.ihw = it;
+        rec.c = -locc * it;
         rec.al = a * r * ihw * kInvPi;                            // a*r*(2/(pi*width))
         rec.ag2 = 2.0 * a * (1.0 - r) * ihw * kSqrtLn2OverPi;     // 2 * a*(1-r)*(2/width)*sqrt(ln2/pi)
+        lor[k] = rec;
         const double gw = kGaussWindow * fabs(width);
-        rec.glo = locc - gw;
-        rec.ghi = locc + gw;
-        recs[k] = rec;
+        win[k] = PeakWin{locc - gw, locc + gw};
     }
     __syncthreads();
     if (!active) return;
@@ -177,6 +254,8 @@ __global__ __launch_bounds__(kBlock) void objective_kernel(
     }
     const double base = (double)P * yoff;     // yoff is added once per peak (equations.py:147,195)
     double ss = 0.0;
+    constexpr bool kSkip = (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_SINGLE);
+    constexpr bool kQuad = (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP);
 
     for (int64_t jb = j0; jb < j1; jb += kChunk) {
         double wv[kPointsPerLane], acc[kPointsPerLane];
@@ -186,12 +265,10 @@ __global__ __launch_bounds__(kBlock) void objective_kernel(
             wv[q] = (j < j1) ? wc[j] : 0.0;
             acc[q] = base;
         }
-        double2 mm = make_double2(0.0, 0.0);
-        if (VARIANT == NMRFIT_VARIANT_DEFAULT) mm = chunk_minmax[jb / kChunk];
 
-        for (int k = 0; k < P; ++k) {
-            const PeakRec rec = recs[k];
-            if (VARIANT == NMRFIT_VARIANT_BASELINE) {
+        if (VARIANT == NMRFIT_VARIANT_BASELINE) {
+            for (int k = 0; k < P; ++k) {
+                const PeakLor rec = lor[k];
 #pragma unroll
                 for (int q = 0; q < kPointsPerLane; ++q) {
                     const double t = __builtin_fma(wv[q], rec.ihw, rec.c);
@@ -199,25 +276,46 @@ __global__ __launch_bounds__(kBlock) void objective_kernel(
                     acc[q] = __builtin_fma(rec.al, 1.0 / s, acc[q]);
                     acc[q] = __builtin_fma(rec.ag2, exp2(-s), acc[q]);
                 }
-            } else {
-                double sv[kPointsPerLane];
-#pragma unroll
-                for (int q = 0; q < kPointsPerLane; ++q) {
-                    const double t = __builtin_fma(wv[q], rec.ihw, rec.c);
-                    sv[q] = __builtin_fma(t, t, 1.0);
-                    acc[q] = __builtin_fma(rec.al, rcp_refined(sv[q]), acc[q]);
+            }
+        } else {
+            double2 mm = make_double2(0.0, 0.0);
+            if (kSkip) mm = chunk_minmax[jb / kChunk];
+            for (int kb = 0; kb < P; kb += kWave) {
+                const int kend = (P < kb + kWave) ? P : kb + kWave;
+                // which of peaks kb..kb+63 have their Gaussian window inside this chunk's
+                // [min,max] of w: lane i tests peak kb+i, the ballot is a scalar bit mask
+                unsigned long long hits = ~0ull;
+                if (kSkip) {
+                    bool h = false;
+                    if (kb + lane < P) {
+                        const PeakWin wn = win[kb + lane];
+                        h = (mm.y >= wn.lo) && (mm.x <= wn.hi);
+                    }
+                    hits = __ballot(h);
                 }
-                int gauss = 1;
-                if (VARIANT == NMRFIT_VARIANT_DEFAULT)   // operands are wave-uniform: make the branch scalar
-                    gauss = __builtin_amdgcn_readfirstlane((int)((mm.y >= rec.glo) && (mm.x <= rec.ghi)));
-                if (gauss) {
-#pragma unroll
-                    for (int q = 0; q < kPointsPerLane; ++q)
-                        acc[q] = __builtin_fma(rec.ag2, exp2_neg(-sv[q]), acc[q]);
+                int k = kb;
+                if (kQuad) {
+                    for (; k + 4 <= kend; k += 4) {
+                        lorentz_quad(lor + k, wv, acc);
+                        const unsigned h4 = (unsigned)(hits >> (k - kb)) & 15u;
+                        if (h4) {
+                            if (h4 & 1u) gauss_add(lor + k, wv, acc);
+                            if (h4 & 2u) gauss_add(lor + k + 1, wv, acc);
+                            if (h4 & 4u) gauss_add(lor + k + 2, wv, acc);
+                            if (h4 & 8u) gauss_add(lor + k + 3, wv, acc);
+                        }
+                    }
+                }
+                for (; k < kend; ++k) {   // remainder of a quad pass, or every peak of SINGLE
+                    lorentz_single(lor + k, wv, acc);
+                    if ((hits >> (k - kb)) & 1ull) gauss_add(lor + k, wv, acc);
                 }
             }
         }
 
+        // keep the u/v/weights loads below the peak loop: hoisted, they would hold 48 VGPRs
+        // across it and push the kernel under 4 waves per SIMD
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int q = 0; q < kPointsPerLane; ++q) {
             const int64_t j = jb + q * kWave + lane;
@@ -291,11 +389,11 @@ int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, doub
     if (dR)
         hipLaunchKernelGGL((objective_kernel<VARIANT, true>), dim3((unsigned)blocks), dim3(kBlock), lds,
                            ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,
-                           ctx->N, ctx->w0, nseg, seg_len, out, dR);
+                           ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, out, dR);
     else
         hipLaunchKernelGGL((objective_kernel<VARIANT, false>), dim3((unsigned)blocks), dim3(kBlock), lds,
                            ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,
-                           ctx->N, ctx->w0, nseg, seg_len, out, dR);
+                           ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, out, dR);
     NMRFIT_HIP(hipGetLastError());
     return NMRFIT_OK;
 }
@@ -323,7 +421,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     // Segmenting: aim for >= 4 waves per SIMD across the chip; a segment is a whole number
     // of 512-point chunks.  Large swarms get nseg = 1 (one wave per particle, f written
     // directly); small ones split the grid.
-    const int64_t target_waves = (int64_t)ctx->compute_units * 4 * 4;
+    int64_t target_waves = (int64_t)ctx->compute_units * 4 * 4;
+    if (ctx->target_waves > 0) target_waves = ctx->target_waves;
     const int64_t max_seg = (N + kChunk - 1) / kChunk;
     int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(max_seg, (target_waves + S - 1) / S));
     int64_t seg_len = ((N + nseg - 1) / nseg + kChunk - 1) / kChunk * kChunk;
@@ -334,7 +433,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         set_error("swarm too large for one launch");
         return NMRFIT_E_INVALID;
     }
-    const size_t lds = (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(PeakRec);
+    const size_t lds = (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * (sizeof(PeakLor) + sizeof(PeakWin));
     double *out = df;
     if (nseg > 1) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, waves);
@@ -348,6 +447,9 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
             break;
         case NMRFIT_VARIANT_NOSKIP:
             rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            break;
+        case NMRFIT_VARIANT_SINGLE:
+            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
             break;
         default:
             rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);

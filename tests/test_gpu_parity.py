@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 RTOL_F = 1e-9
 F_FLOOR = 1e-6
-VARIANTS = [_cabi.VARIANT_DEFAULT, _cabi.VARIANT_BASELINE, _cabi.VARIANT_NOSKIP]
+VARIANTS = [_cabi.VARIANT_DEFAULT, _cabi.VARIANT_BASELINE, _cabi.VARIANT_NOSKIP, _cabi.VARIANT_SINGLE]
 
 
 def _close_f(f, ref, rtol=RTOL_F):

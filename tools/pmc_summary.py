@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile.sh output directory: per-kernel stats + mean PMC counters of the
+objective kernel.  Usage: tools/pmc_summary.py gpurun_out/prof/<tag> [--json out.json]"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    d = sys.argv[1]
+    out = {}
+    st = glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv"))
+    if st:
+        rows = list(csv.DictReader(open(st[0])))
+        out["kernel_stats"] = [{"name": r["Name"].split("(")[0][-60:], "calls": int(r["Calls"]),
+                                "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                                "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])} for r in rows[:8]]
+    pmc = {}
+    for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds"):
+        fs = glob.glob(os.path.join(d, sub, "*", "*_counter_collection.csv"))
+        if not fs:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[0])):
+            if "objective_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            pmc[k] = {"mean": sum(v) / len(v), "n": len(v)}
+    out["objective_kernel_pmc"] = pmc
+    if "FETCH_SIZE" in pmc:
+        # MI355X_MICROARCH.md (HBM): FETCH_SIZE is in KiB and reads 1/2 of the bytes of wide
+        # coalesced reads on gfx950 -> double it; WRITE_SIZE is exact (KiB).
+        fetch = pmc["FETCH_SIZE"]["mean"] * 1024 * 2
+        write = pmc.get("WRITE_SIZE", {"mean": 0})["mean"] * 1024
+        out["hbm_bytes_per_launch"] = fetch + write
+        out["hbm_bytes_note"] = "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction per MI355X_MICROARCH.md)"
+    if "GRBM_GUI_ACTIVE" in pmc and st:
+        ks = [k for k in out["kernel_stats"] if "objective_kernel" in k["name"]]
+        if ks:
+            out["clock_ghz_est"] = pmc["GRBM_GUI_ACTIVE"]["mean"] / 8 / ks[0]["avg_ns"]
+    if "SQ_INSTS_VALU" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:
+        out["valu_cycles_per_inst"] = 4 * pmc["SQ_ACTIVE_INST_VALU"]["mean"] / pmc["SQ_INSTS_VALU"]["mean"]
+    if "SQ_BUSY_CYCLES" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:
+        # SQ_BUSY_CYCLES sums 32 shader engines; SQ_ACTIVE_INST_VALU counts quad-cycles over 1024 SIMDs
+        kernel_cycles = pmc["SQ_BUSY_CYCLES"]["mean"] / 32
+        out["kernel_cycles"] = kernel_cycles
+        out["valu_busy_frac"] = 4 * pmc["SQ_ACTIVE_INST_VALU"]["mean"] / 1024 / kernel_cycles
+    print(json.dumps(out, indent=1))
+    if "--json" in sys.argv:
+        json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -236,6 +236,29 @@ __global__ void k_lds_bcast(double *out, double a, double b)
     if (s == 12345.678) out[0] = s;
 }
 
+
+// does the quarter-rate v_rcp_f64 overlap with full-rate fp64 FMAs of the same / other waves?
+// 4 rcp + 12 fma per iteration: 4*16 + 12*4 = 112 cycles if serial, ~64 if they overlap.
+__global__ void k_mix_rcp_fma(double *out, double a, double b)
+{
+    double r[8], t[4];
+    for (int i = 0; i < 8; ++i) r[i] = a + threadIdx.x * 1e-9 + i;
+    for (int i = 0; i < 4; ++i) t[i] = b + i;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            asm volatile("v_rcp_f64 %0, %0" : "+v"(t[i]));
+            asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[2 * i]) : "v"(a), "v"(b));
+            asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[2 * i + 1]) : "v"(a), "v"(b));
+            asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[(2 * i + 2) & 7]) : "v"(a), "v"(b));
+        }
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += r[i];
+    for (int i = 0; i < 4; ++i) s += t[i];
+    if (s == 12345.678) out[0] = s;
+}
+
 // clock measurement: ratio of s_memtime (shader clock) to s_memrealtime (100 MHz)
 __global__ void k_clock(unsigned long long *out)
 {
@@ -304,6 +327,7 @@ int main()
         {"cvt f64->f32->f64 (2 instr)", k_cvt_roundtrip, 16},
         {"v_fma_f32", k_fma_f32, 16},     {"v_pk_fma_f32", k_pk_fma_f32, 16}, {"v_rcp_f32", k_rcp_f32, 16},
         {"v_exp_f32", k_exp_f32, 16},     {"v_mov_b32", k_mov_b32, 16},       {"3x ds_read_b128 bcast", k_lds_bcast, 16},
+        {"mix 4 rcp_f64 + 12 fma_f64 /16", k_mix_rcp_fma, 16},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));

@@ -111,7 +111,7 @@ def main():
         # run our launches on torch's current stream so they order with the RCCL all-gather
         ev.set_stream(torch.cuda.current_stream().cuda_stream)
         send = torch.zeros(D + 1, dtype=torch.float64, device="cuda")
-        recv = torch.zeros((world, D + 1), dtype=torch.float64, device="cuda")
+        recv = torch.zeros(world * (D + 1), dtype=torch.float64, device="cuda")
         sw.set_candidate_dev(send.data_ptr())
         ex = TorchExchange()
 

@@ -1,0 +1,17 @@
+"""
+nmrfit_amd -- MI355X (gfx950) evaluator for nmrfit's objective function and the swarm loop
+around it, behind the reference's own API for that path:
+
+    nmrfit_amd.fit(data, lower, upper, ...) -> FitUtility        (nmrfit/core.py:64)
+    nmrfit_amd.equations.objective(x, w, u, v, weights)          (nmrfit/equations.py:152)
+    nmrfit_amd.equations.Evaluator(...).objective_batch(X)       one launch per swarm generation
+    nmrfit_amd.pso.DeviceSwarm / pso.pso                         (replaces pyswarm.pso)
+
+Everything that evaluates goes through libnmrfit_amd.so (include/nmrfit_amd.h); there is no
+CPU fallback.  Instrument I/O, peak picking, GUI selectors and plotting of the reference are
+out of scope.
+"""
+from .core import fit  # noqa: F401
+from . import equations, pso, synth, utils  # noqa: F401
+
+__version__ = "0.1.0"

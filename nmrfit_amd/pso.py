@@ -97,14 +97,20 @@ class TorchExchange:
         self.rank = dist.get_rank(group)
 
     def gather_host(self, cand):
+        """Host-array form (fit() on several ranks, CPU tests): with the nccl backend the
+        record takes a round trip through a CUDA tensor, with gloo it stays on the host."""
         import torch
         t = torch.from_numpy(np.ascontiguousarray(cand))
-        out = torch.empty((self.world, t.numel()), dtype=t.dtype)
+        on_gpu = self._dist.get_backend(self.group) == "nccl"
+        if on_gpu:
+            t = t.cuda()
+        out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)   # flat: gloo needs 1-D
         self._dist.all_gather_into_tensor(out, t, group=self.group)
-        return out.numpy()
+        out = out.view(self.world, t.numel())
+        return out.cpu().numpy() if on_gpu else out.numpy()
 
     def gather_device(self, send, recv):
-        """send: cuda tensor (D+1), recv: cuda tensor (world, D+1); ordered on torch's current stream."""
+        """send: cuda tensor (D+1), recv: flat cuda tensor world*(D+1); ordered on torch's current stream."""
         self._dist.all_gather_into_tensor(recv, send, group=self.group)
 
 

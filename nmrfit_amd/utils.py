@@ -1,0 +1,130 @@
+"""
+Host-side mirror of the reference's fit driver (nmrfit/utils.py:96-339 ``FitUtility``):
+same constructor, same attributes, same ``options`` keys -- the swarm loop and the objective
+run on the MI355X instead of going through pyswarm one particle at a time.
+
+Kept verbatim from the reference interface:
+  FitUtility(data, lower, upper, expon=0.5, dynamic_weighting=True, fit_im=False,
+             processes=1, summary=True, options={})
+  attributes data, lower, upper, expon, dynamic_weighting, fit_im, summary, processes, options;
+  after fit(): weights, params, error.
+  options: swarmsize (204), maxiter (2000), omega (-0.2134), phip (-0.3344), phig (2.3259)
+           (utils.py:177-181).  Extra opt-in keys: minstep, minfunc (pyswarm's 1e-8 defaults,
+           which the reference does not forward), seed, device, check_every, exchange.
+
+``processes`` is accepted and ignored: the reference's only use of it is to spread the
+per-particle objective calls over a multiprocessing.Pool (utils.py:182), which the batched
+launch replaces.  ``fit_im=True`` raises (Kramers-Kronig path).
+"""
+import numpy as np
+
+from . import _cabi, equations, pso
+
+
+def compute_weights(w, peaks, expon=0.5):
+    """FitUtility._compute_weights (utils.py:191-224): ones, then per peak region
+    weights[l:r+1] = (max|height| / |height_i|)**expon (later peaks overwrite earlier ones),
+    then 10 Laplacian smoothing sweeps.  Host code in the reference too (once per fit).
+    np.int (utils.py:201-202) no longer exists in numpy; plain int is the same type."""
+    w = np.asarray(w)
+    n = len(peaks)
+    lIdx = np.zeros(n, dtype=int)
+    rIdx = np.zeros(n, dtype=int)
+    maxabs = np.zeros(n)
+    for i, p in enumerate(peaks):
+        lIdx[i] = np.argmin(np.abs(w - p.bounds[0]))
+        rIdx[i] = np.argmin(np.abs(w - p.bounds[1]))
+        if lIdx[i] > rIdx[i]:
+            lIdx[i], rIdx[i] = rIdx[i], lIdx[i]
+        maxabs[i] = np.abs(p.height)
+    biggest = np.amax(maxabs)
+    weights = np.ones(len(w)) * 1.0
+    for i in range(n):
+        weights[lIdx[i]:rIdx[i] + 1] = np.power(biggest / maxabs[i], expon)
+    return equations.laplace1d(weights)
+
+
+class FitUtility:
+    """Interface used to perform a fit of the data (reference: nmrfit/utils.py:96)."""
+
+    def __init__(self, data, lower, upper, expon=0.5, dynamic_weighting=True, fit_im=False, processes=1,
+                 summary=True, options={}):
+        self.data = data
+        self.lower = lower
+        self.upper = upper
+        self.expon = expon
+        self.dynamic_weighting = dynamic_weighting
+        self.fit_im = fit_im
+        self.summary = summary
+        self.processes = processes
+        self.options = options
+
+    def _compute_weights(self):
+        return compute_weights(self.data.w, self.data.peaks, self.expon)
+
+    def fit(self):
+        """utils.py:164-189: weights, minimise, store params/error, optional summary."""
+        if self.fit_im:
+            raise equations.NmrfitError(_cabi.E_UNSUPPORTED, "fit_im=True (Kramers-Kronig imaginary fit, "
+                                        "nmrfit/equations.py:197-209) is not supported")
+        self.weights = self._compute_weights()
+        if self.dynamic_weighting is False:
+            self.weights = np.ones_like(self.weights)
+
+        opt = self.options
+        kw = dict(omega=opt.get('omega', pso.DEFAULTS['omega']), phip=opt.get('phip', pso.DEFAULTS['phip']),
+                  phig=opt.get('phig', pso.DEFAULTS['phig']), minstep=opt.get('minstep', pso.DEFAULTS['minstep']),
+                  minfunc=opt.get('minfunc', pso.DEFAULTS['minfunc']))
+        swarmsize = opt.get('swarmsize', pso.DEFAULTS['swarmsize'])
+        maxiter = opt.get('maxiter', pso.DEFAULTS['maxiter'])
+        seed = opt.get('seed')
+        if seed is None:     # pyswarm draws from numpy's unseeded global RNG: do the equivalent
+            seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+        exchange = opt.get('exchange')       # a pso.TorchExchange for multi-GPU fits
+
+        ev = equations.Evaluator(self.data.w, self.data.u, self.data.v, self.weights, device=opt.get('device', 0))
+        try:
+            if exchange is None or exchange.world == 1:
+                xopt, fopt = pso.pso(ev, self.lower, self.upper, swarmsize=swarmsize, maxiter=maxiter, seed=seed,
+                                     check_every=opt.get('check_every', 16), verbose=True, **kw)
+            else:
+                off, n = pso.shard(swarmsize, exchange.rank, exchange.world)
+                sw = pso.DeviceSwarm(ev, self.lower, self.upper, swarmsize, offset=off, S_local=n, seed=seed, **kw)
+                try:
+                    xopt, fopt = pso.run_sharded(sw, exchange, maxiter, check_every=opt.get('check_every', 1),
+                                                 verbose=True)
+                finally:
+                    sw.close()
+        finally:
+            ev.close()
+
+        self.params = xopt
+        self.error = fopt
+        if self.summary is True:
+            self._print_summary()
+
+    def get_areas(self):
+        """utils.py:312-322."""
+        return np.array([self.params[i] for i in range(6, len(self.params), 3)])
+
+    def calculate_area_fraction(self):
+        """utils.py:297-310: satellites (areas below the mean) over total."""
+        areas = self.get_areas()
+        m = np.mean(areas)
+        peaks = areas[areas >= m].sum()
+        sats = areas[areas < m].sum()
+        return sats / (peaks + sats)
+
+    def _print_summary(self):
+        """utils.py:324-339."""
+        import pandas as pd
+        res = np.array(self.params)
+        res_globals = pd.DataFrame(res[:4].reshape((1, -1)), columns=['p0', 'p1', 'r', 'y-off'])
+        res = pd.DataFrame(res[4:].reshape((-1, 3)), columns=['width', 'location', 'area'])
+        print('\nFit Summary:')
+        print('------------')
+        print('Global parameters')
+        print(res_globals.to_string(index=False))
+        print('\nPeak parameters')
+        print(res.to_string(index=False))
+        print("Error:\t", self.error)

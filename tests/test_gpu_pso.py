@@ -1,0 +1,146 @@
+"""
+GPU tier (iii/iv): the device-resident swarm (csrc/pso.hip through the C-ABI) against its
+numpy mirror, the sharded form against the single swarm, and nmrfit_amd.fit() end to end.
+"""
+import numpy as np
+import pytest
+
+from nmrfit_amd import _cabi, pso, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def problem():
+    from nmrfit_amd import equations
+    assert _cabi.device_count() >= 1
+    sp = synth.make_spectrum(2048, 3, seed=5)
+    ev = equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"])
+    yield sp, ev
+    ev.close()
+
+
+def test_device_swarm_matches_numpy_mirror_bitwise(problem):
+    """Same Philox stream, same IEEE update arithmetic (no FMA contraction in the swarm
+    kernels), same objective values (the mirror evaluates through the same GPU kernel with
+    the same launch geometry) => x, v, p, fp, g identical bit for bit after 10 generations."""
+    sp, ev = problem
+    S, seed = 204, 77
+    dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+    host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+    dev.init()
+    host.init()
+    st = dev.state()
+    np.testing.assert_array_equal(st["x"], host.x)
+    np.testing.assert_array_equal(st["v"], host.v)
+    np.testing.assert_array_equal(st["fx"], host.fx)
+    np.testing.assert_array_equal(dev.candidate(), host.candidate())
+    dev.apply_global(dev.candidate()[None, :])
+    host.apply_global(host.candidate()[None, :])
+    for _ in range(10):
+        dev.step_local()
+        host.step_local()
+        np.testing.assert_array_equal(dev.candidate(), host.candidate())
+        dev.apply_global(dev.candidate()[None, :])
+        host.apply_global(host.candidate()[None, :])
+    st = dev.state()
+    for k in ("x", "v", "p", "fx", "fp"):
+        np.testing.assert_array_equal(st[k], getattr(host, k), err_msg=k)
+    xb, fb = dev.best()
+    np.testing.assert_array_equal(xb, host.best_x)
+    assert fb == host.best_f
+    assert dev.status() == dict(iteration=10, stop=0, fg=host.fg)
+    dev.close()
+
+
+def test_sharded_device_swarms_equal_single(problem):
+    """Three shards (uneven: 70/67/67) on one GPU, candidates gathered on the host."""
+    sp, ev = problem
+    S, seed = 204, 5
+    one = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+    shards = []
+    for r in range(3):
+        off, n = pso.shard(S, r, 3)
+        shards.append(pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, offset=off, S_local=n, seed=seed,
+                                      minfunc=-1.0, minstep=-1.0))
+    one.init()
+    one.apply_global(one.candidate()[None, :])
+    for s in shards:
+        s.init()
+    cands = np.stack([s.candidate() for s in shards])
+    for s in shards:
+        s.apply_global(cands)
+    for _ in range(8):
+        one.step_local()
+        one.apply_global(one.candidate()[None, :])
+        for s in shards:
+            s.step_local()
+        cands = np.stack([s.candidate() for s in shards])
+        for s in shards:
+            s.apply_global(cands)
+    x1 = one.state()["x"]
+    np.testing.assert_array_equal(np.concatenate([s.state()["x"] for s in shards]), x1)
+    b1 = one.best()
+    for s in shards:
+        b = s.best()
+        np.testing.assert_array_equal(b[0], b1[0])
+        assert b[1] == b1[1]
+        s.close()
+    one.close()
+
+
+def test_stop_flag_on_device_and_run_polling(problem):
+    """nmrfit_pso_run polls the stop flag every check_every generations; generations after
+    the stop are no-ops on the device, so the answer does not depend on check_every."""
+    sp, ev = problem
+    res = []
+    for ce in (1, 7, 64):
+        sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 64, seed=3)
+        sw.run(400, check_every=ce)
+        st = sw.status()
+        res.append((st["stop"], st["iteration"], sw.best()))
+        sw.close()
+    assert res[0][0] in (1, 2)
+    for r in res[1:]:
+        assert r[0] == res[0][0] and r[1] == res[0][1]
+        np.testing.assert_array_equal(r[2][0], res[0][2][0])
+        assert r[2][1] == res[0][2][1]
+    # and the mirror stops at the same generation with the same answer
+    host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], 64, seed=3)
+    xh, fh = pso.run_sharded(host, pso.LocalExchange(), 400)
+    assert host.stop == res[0][0] and host.iteration == res[0][1]
+    np.testing.assert_array_equal(xh, res[0][2][0])
+
+
+def test_bounds_validation(problem):
+    sp, ev = problem
+    with pytest.raises(AssertionError):
+        pso.DeviceSwarm(ev, sp["upper"], sp["lower"], 8)
+
+
+def test_fit_api_end_to_end(problem, capsys):
+    """nmrfit_amd.fit with the reference signature on a synthetic spectrum: recovers the
+    generating parameters to within the box scale and reaches the noise floor."""
+    import nmrfit_amd
+    from oracle import c_oracle
+    sp = synth.make_spectrum(4096, 3, seed=9)
+    data = synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"])
+    res = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), expon=0.5, dynamic_weighting=True,
+                         summary=True, options={"swarmsize": 204, "maxiter": 600, "seed": 1})
+    out = capsys.readouterr().out
+    assert "Fit Summary:" in out and "Stopping search:" in out
+    assert res.params.shape == (13,) and np.isfinite(res.error)
+    assert res.weights.shape == (4096,) and res.weights.min() >= 1.0
+    # the returned error is the reference objective at the returned parameters
+    ref = c_oracle.objective_batch(res.params, sp["w"], sp["u"], sp["v"], res.weights)[0]
+    assert res.error == pytest.approx(ref, rel=1e-9)
+    f_truth = c_oracle.objective_batch(sp["x_true"], sp["w"], sp["u"], sp["v"], res.weights)[0]
+    assert res.error <= 1.5 * f_truth
+    np.testing.assert_allclose(res.get_areas(), sp["x_true"][6::3], rtol=0.25)
+    assert 0.0 <= res.calculate_area_fraction() <= 1.0
+    # dynamic_weighting=False -> unit weights (utils.py:172-173)
+    res2 = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), dynamic_weighting=False, summary=False,
+                          options={"swarmsize": 64, "maxiter": 50, "seed": 2})
+    assert (res2.weights == 1.0).all()
+    with pytest.raises(nmrfit_amd.equations.NmrfitError):
+        nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im=True, summary=False)

@@ -1,0 +1,60 @@
+"""
+CPU tier: the host-side pieces of the fit driver that the reference also runs on the CPU once
+per fit -- weights and Laplacian smoothing -- against the
+golden vectors produced by the reference's own FitUtility._compute_weights / laplace1d, and
+the FitUtility surface (attributes, option defaults) without touching a GPU.
+"""
+import inspect
+import os
+
+import numpy as np
+import pytest
+
+import nmrfit_amd
+from nmrfit_amd import equations, pso, synth, utils
+
+
+def test_compute_weights_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "weights.npz"))
+    np.testing.assert_array_equal(equations.laplace1d(g["lap_in"].copy()), g["lap_out"])
+    np.testing.assert_array_equal(equations.laplace1d(g["lap_in"].copy(), n=3, omega=0.5), g["lap3_out"])
+    sp = synth.make_spectrum(4096, 6, seed=int(g["cw_seed"]))
+    np.testing.assert_array_equal(utils.compute_weights(sp["w"], sp["peaks"], 0.5), g["cw_weights"])
+    np.testing.assert_array_equal(utils.compute_weights(sp["w"], sp["peaks"], 1.3), g["cw_weights_e13"])
+    # reversed grid (nmrfit/core.py:60 hands out reversed views): exercises the lIdx > rIdx swap
+    np.testing.assert_array_equal(utils.compute_weights(sp["w"][::-1], sp["peaks"], 0.5), g["cw_weights_rev"])
+
+
+def test_fit_signature_matches_reference():
+    """nmrfit/core.py:64 and nmrfit/utils.py:129."""
+    sig = inspect.signature(nmrfit_amd.fit)
+    assert list(sig.parameters) == ["data", "lower", "upper", "expon", "dynamic_weighting", "fit_im",
+                                    "processes", "summary", "options"]
+    d = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect._empty}
+    assert d == dict(expon=0.5, dynamic_weighting=True, fit_im=False, processes=1, summary=True, options={})
+    sig2 = inspect.signature(utils.FitUtility.__init__)
+    assert list(sig2.parameters)[1:] == list(sig.parameters)
+    assert pso.DEFAULTS == dict(swarmsize=204, maxiter=2000, omega=-0.2134, phip=-0.3344, phig=2.3259,
+                                minstep=1e-8, minfunc=1e-8)
+
+
+def test_fitutility_attributes_and_area_helpers():
+    sp = synth.make_spectrum(256, 3, seed=2)
+    data = synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"])
+    fu = utils.FitUtility(data, list(sp["lower"]), list(sp["upper"]), expon=0.7, options={"swarmsize": 10})
+    for a in ("data", "lower", "upper", "expon", "dynamic_weighting", "fit_im", "summary", "processes", "options"):
+        assert hasattr(fu, a)
+    w = fu._compute_weights()
+    assert w.shape == (256,) and w[0] == 1.0 and w[-1] == 1.0
+    fu.params = sp["x_true"]
+    np.testing.assert_array_equal(fu.get_areas(), sp["x_true"][6::3])
+    areas = fu.get_areas()
+    m = areas.mean()
+    assert fu.calculate_area_fraction() == areas[areas < m].sum() / areas.sum()
+
+
+def test_fit_im_is_rejected_loudly():
+    sp = synth.make_spectrum(64, 1, seed=2)
+    data = synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"])
+    with pytest.raises(equations.NmrfitError):
+        nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im=True)

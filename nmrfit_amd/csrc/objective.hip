@@ -41,10 +41,12 @@
 namespace nmrfit {
 namespace {
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kInvPi = 0.31830988618379067154;
 constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
-constexpr int kQuadInterleave = 4;
 constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
 
 // ---- fp64 helpers (coefficients: tools/gen_poly.py) ---------------------------------------
@@ -127,51 +129,69 @@ __device__ __forceinline__ double wave_sum(double x)
 // Per-(particle, peak) constants in LDS, two arrays per wave: PeakLor (32 B: read in the main
 // loop as one broadcast ds_read_b128 + one ds_read_b64) and PeakWin (16 B: Gaussian window).
 
-// Lorentzian of ONE peak at the lane's 8 points: acc += AL / (1 + t^2)
-__device__ __forceinline__ void lorentz_single(const PeakLor *r, const double (&wv)[kPointsPerLane],
-                                               double (&acc)[kPointsPerLane])
+// Lorentzians of G peaks over one common denominator.  With s_k = 1 + t_k^2 >= 1, a pair is
+//   AL0/s0 + AL1/s1 = (AL0 s1 + AL1 s0) / (s0 s1)
+// and (numerator, denominator) pairs combine the same way up a binary tree:
+//   (n0, d0) + (n1, d1) = (n0 d1 + n1 d0, d0 d1)            3 FMA-class ops per combine
+// -> ONE reciprocal per G (point, peak) units: 2G + 3(G-1) + 3 FMA-class ops + v_rcp_f64,
+// against G x (5 + v_rcp_f64) done one by one (G = 8: 5.0 ops + 1/8 rcp per unit).  All
+// products are of factors >= 1 and |t| is capped at 1e18 when the record is staged, so the
+// denominator of 8 peaks stays below 1e289.
+template <int G, int LO, int HI>
+__device__ __forceinline__ void lorentz_tree(const double (&a)[G], const double (&s)[G], double &n, double &d)
 {
-    const double ihw = r->ihw, c = r->c, al = r->al;
-#pragma unroll
-    for (int q = 0; q < kPointsPerLane; ++q) {
-        const double t = __builtin_fma(wv[q], ihw, c);
-        const double s = __builtin_fma(t, t, 1.0);
-        acc[q] = __builtin_fma(al, rcp64(s), acc[q]);
+    if constexpr (HI - LO == 1) {
+        n = a[LO];
+        d = s[LO];
+    } else {
+        constexpr int MID = LO + (HI - LO + 1) / 2;
+        double n0, d0, n1, d1;
+        lorentz_tree<G, LO, MID>(a, s, n0, d0);
+        lorentz_tree<G, MID, HI>(a, s, n1, d1);
+        d = d0 * d1;
+        n = __builtin_fma(n0, d1, n1 * d0);
     }
 }
 
-// Lorentzians of FOUR peaks over one common denominator: with s_k = 1 + t_k^2 >= 1,
-//   sum_k AL_k/s_k = [ (AL0 s1 + AL1 s0) s2 s3 + (AL2 s3 + AL3 s2) s0 s1 ] / (s0 s1 s2 s3)
-// -> one reciprocal per four (point, peak) units: 17 fp64 FMA-class ops + v_rcp_f64 + 2 Newton
-// FMAs, against 4 x (5 FMA + v_rcp_f64) done one by one.  All products are of factors >= 1 and
-// |t| is capped at 1e18 when the record is staged, so the denominator stays below 1e145.
-__device__ __forceinline__ void lorentz_quad(const PeakLor *r, const double (&wv)[kPointsPerLane],
-                                             double (&acc)[kPointsPerLane])
+template <int G>
+__device__ __forceinline__ void lorentz_group(const PeakLor *r, const double (&wv)[kPointsPerLane],
+                                              double (&acc)[kPointsPerLane])
 {
-    const double i0 = r[0].ihw, c0 = r[0].c, a0 = r[0].al;
-    const double i1 = r[1].ihw, c1 = r[1].c, a1 = r[1].al;
-    const double i2 = r[2].ihw, c2 = r[2].c, a2 = r[2].al;
-    const double i3 = r[3].ihw, c3 = r[3].c, a3 = r[3].al;
+    double ih[G], c[G], a[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        ih[g] = r[g].ihw;
+        c[g] = r[g].c;
+        a[g] = r[g].al;
+    }
+    // how many points the scheduler may interleave: all 8 at once needs > 128 VGPRs (spills),
+    // which costs more than the extra latency hiding buys
+    constexpr int kInterleave = (G <= 4) ? 4 : 1;
 #pragma unroll
     for (int q = 0; q < kPointsPerLane; ++q) {
-        const double t0 = __builtin_fma(wv[q], i0, c0);
-        const double t1 = __builtin_fma(wv[q], i1, c1);
-        const double t2 = __builtin_fma(wv[q], i2, c2);
-        const double t3 = __builtin_fma(wv[q], i3, c3);
-        const double s0 = __builtin_fma(t0, t0, 1.0);
-        const double s1 = __builtin_fma(t1, t1, 1.0);
-        const double s2 = __builtin_fma(t2, t2, 1.0);
-        const double s3 = __builtin_fma(t3, t3, 1.0);
-        const double p01 = s0 * s1;
-        const double n01 = __builtin_fma(a0, s1, a1 * s0);
-        const double p23 = s2 * s3;
-        const double n23 = __builtin_fma(a2, s3, a3 * s2);
-        const double den = p01 * p23;
-        const double num = __builtin_fma(n01, p23, n23 * p01);
+        double s[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const double t = __builtin_fma(wv[q], ih[g], c[g]);
+            s[g] = __builtin_fma(t, t, 1.0);
+        }
+        double num, den;
+        lorentz_tree<G, 0, G>(a, s, num, den);
         acc[q] = __builtin_fma(num, rcp64(den), acc[q]);
-        // let the scheduler interleave at most kQuadInterleave points: all 8 at once needs
-        // > 128 VGPRs (spills), which costs more than the extra latency hiding buys
-        if ((q + 1) % kQuadInterleave == 0) __builtin_amdgcn_sched_barrier(0);
+        if ((q + 1) % kInterleave == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// group of a run-time size 1..GMAX-1 (tail of a pass)
+template <int GMAX>
+__device__ __forceinline__ void lorentz_tail(int n, const PeakLor *r, const double (&wv)[kPointsPerLane],
+                                             double (&acc)[kPointsPerLane])
+{
+    if constexpr (GMAX > 1) {
+        if (n == GMAX - 1)
+            lorentz_group<GMAX - 1>(r, wv, acc);
+        else
+            lorentz_tail<GMAX - 1>(n, r, wv, acc);
     }
 }
 
@@ -189,15 +209,21 @@ __device__ __forceinline__ void gauss_add(const PeakLor *r, const double (&wv)[k
 }
 
 // ---- the kernel ----------------------------------------------------------------------------
-// VARIANT: NMRFIT_VARIANT_DEFAULT  quad-grouped Lorentzians + Gaussian window skip
+// VARIANT: NMRFIT_VARIANT_DEFAULT  8 Lorentzians per reciprocal + Gaussian window skip + u/v/weights
+//                                  of each chunk prefetched into LDS by global_load_lds (LDS-DMA)
+//          NMRFIT_VARIANT_OCT      the same without the LDS-DMA staging (used when P is so large
+//                                  that the staging buffers would cost a workgroup per CU)
 //          NMRFIT_VARIANT_BASELINE IEEE divide and libdevice exp2 per unit, no skip: the
 //                                  obviously-right form the tuned ones are A/B-checked against
-//          NMRFIT_VARIANT_NOSKIP   quad-grouped, Gaussian evaluated everywhere
+//          NMRFIT_VARIANT_NOSKIP   8 per reciprocal, Gaussian evaluated everywhere
 //          NMRFIT_VARIANT_SINGLE   one reciprocal per unit + Gaussian window skip
+//          NMRFIT_VARIANT_QUAD     4 per reciprocal + Gaussian window skip
 // Wave g = blockIdx.x*4 + wave  ->  particle g / nseg, segment g % nseg;
 // a segment is seg_len (multiple of 512) consecutive grid points.
 template <int VARIANT, bool WRITE_R>
-__global__ __launch_bounds__(kBlock, 4) void objective_kernel(
+// The 8-peak group keeps 24 per-peak constants live next to the 8-point register block:
+// ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
+__global__ __launch_bounds__(kBlock, (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_OCT) ? 3 : 4) void objective_kernel(
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax,
     const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, double wspan, int nseg,
@@ -211,6 +237,10 @@ __global__ __launch_bounds__(kBlock, 4) void objective_kernel(
     PeakLor *lor = reinterpret_cast<PeakLor *>(lds_raw) + (size_t)wave * P;
     PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)kWavesPerBlock * P * sizeof(PeakLor)) +
                    (size_t)wave * P;
+    constexpr bool kStage = (VARIANT == NMRFIT_VARIANT_DEFAULT);
+    // kStage: per-wave staging area for one chunk of u, v, weights (3 x 512 doubles = 12 KiB)
+    double *stage = reinterpret_cast<double *>(lds_raw + (size_t)kWavesPerBlock * P * (sizeof(PeakLor) + sizeof(PeakWin))) +
+                    (size_t)wave * (3 * kChunk);
 
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const bool active = g < S * nseg;
@@ -254,17 +284,51 @@ __global__ __launch_bounds__(kBlock, 4) void objective_kernel(
     }
     const double base = (double)P * yoff;     // yoff is added once per peak (equations.py:147,195)
     double ss = 0.0;
-    constexpr bool kSkip = (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_SINGLE);
-    constexpr bool kQuad = (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP);
+    constexpr bool kSkip = (VARIANT != NMRFIT_VARIANT_NOSKIP && VARIANT != NMRFIT_VARIANT_BASELINE);
+    constexpr int kGroup = (VARIANT == NMRFIT_VARIANT_SINGLE) ? 1 : (VARIANT == NMRFIT_VARIANT_QUAD) ? 4 : 8;
+
+    double wnext[kPointsPerLane];
+    if (kStage) {
+#pragma unroll
+        for (int q = 0; q < kPointsPerLane; ++q)
+            wnext[q] = (j0 + lane + q * kWave < j1) ? wc[j0 + lane + q * kWave] : 0.0;
+    }
 
     for (int64_t jb = j0; jb < j1; jb += kChunk) {
+        // Full chunks (all but possibly the last of a segment) take unpredicated loads at
+        // constant offsets from one pointer; the ragged tail is predicated per point.
+        const bool full = (jb + kChunk <= j1);   // wave-uniform
+        const int64_t jl = jb + lane;
         double wv[kPointsPerLane], acc[kPointsPerLane];
+        if (kStage) {
+            // w of this chunk was prefetched into registers during the previous epilogue
 #pragma unroll
-        for (int q = 0; q < kPointsPerLane; ++q) {
-            const int64_t j = jb + q * kWave + lane;
-            wv[q] = (j < j1) ? wc[j] : 0.0;
-            acc[q] = base;
+            for (int q = 0; q < kPointsPerLane; ++q) {
+                wv[q] = wnext[q];
+                asm volatile("" : "+v"(wv[q]));   // consume the load before any LDS-DMA is in flight
+            }
+            if (full) {
+                // LDS-DMA: u, v, weights of this chunk -> the wave's staging area, 16 B per lane
+                // per instruction, no VGPRs held; they land while the peak loop runs
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier reads of the area are done
+#pragma unroll
+                for (int i = 0; i < kChunk / 128; ++i) {
+                    const int64_t js = jb + i * 128 + lane * 2;
+                    __builtin_amdgcn_global_load_lds((gbl_void *)(u + js), (lds_void *)(stage + i * 128), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_void *)(v + js), (lds_void *)(stage + kChunk + i * 128), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_void *)(wt + js), (lds_void *)(stage + 2 * kChunk + i * 128), 16, 0, 0);
+                }
+            }
+        } else if (full) {
+            const double *wp = wc + jl;
+#pragma unroll
+            for (int q = 0; q < kPointsPerLane; ++q) wv[q] = wp[q * kWave];
+        } else {
+#pragma unroll
+            for (int q = 0; q < kPointsPerLane; ++q) wv[q] = (jl + q * kWave < j1) ? wc[jl + q * kWave] : 0.0;
         }
+#pragma unroll
+        for (int q = 0; q < kPointsPerLane; ++q) acc[q] = base;
 
         if (VARIANT == NMRFIT_VARIANT_BASELINE) {
             for (int k = 0; k < P; ++k) {
@@ -294,40 +358,68 @@ __global__ __launch_bounds__(kBlock, 4) void objective_kernel(
                     hits = __ballot(h);
                 }
                 int k = kb;
-                if (kQuad) {
-                    for (; k + 4 <= kend; k += 4) {
-                        lorentz_quad(lor + k, wv, acc);
-                        const unsigned h4 = (unsigned)(hits >> (k - kb)) & 15u;
-                        if (h4) {
-                            if (h4 & 1u) gauss_add(lor + k, wv, acc);
-                            if (h4 & 2u) gauss_add(lor + k + 1, wv, acc);
-                            if (h4 & 4u) gauss_add(lor + k + 2, wv, acc);
-                            if (h4 & 8u) gauss_add(lor + k + 3, wv, acc);
-                        }
-                    }
+                for (; k + kGroup <= kend; k += kGroup) {
+                    lorentz_group<kGroup>(lor + k, wv, acc);
+                    unsigned hg = (unsigned)(hits >> (k - kb)) & ((1u << kGroup) - 1u);
+                    for (int g = 0; hg; ++g, hg >>= 1)
+                        if (hg & 1u) gauss_add(lor + k + g, wv, acc);
                 }
-                for (; k < kend; ++k) {   // remainder of a quad pass, or every peak of SINGLE
-                    lorentz_single(lor + k, wv, acc);
-                    if ((hits >> (k - kb)) & 1ull) gauss_add(lor + k, wv, acc);
+                if (k < kend) {   // fewer than kGroup peaks left: one smaller group
+                    lorentz_tail<kGroup>(kend - k, lor + k, wv, acc);
+                    unsigned hg = (unsigned)(hits >> (k - kb)) & ((1u << (kend - k)) - 1u);
+                    for (int g = 0; hg; ++g, hg >>= 1)
+                        if (hg & 1u) gauss_add(lor + k + g, wv, acc);
                 }
             }
         }
 
         // keep the u/v/weights loads below the peak loop: hoisted, they would hold 48 VGPRs
-        // across it and push the kernel under 4 waves per SIMD
+        // across it
         asm volatile("" ::: "memory");
+        double uq[kPointsPerLane], vq[kPointsPerLane], tq[kPointsPerLane];
+        if (kStage) {
+            if (full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk has landed
+            // prefetch w of the next chunk into registers (the per-peak constants are dead here)
+            const int64_t jn = jl + kChunk;
+            if (jb + 2 * kChunk <= j1) {
+#pragma unroll
+                for (int q = 0; q < kPointsPerLane; ++q) wnext[q] = wc[jn + q * kWave];
+            } else {
+#pragma unroll
+                for (int q = 0; q < kPointsPerLane; ++q) wnext[q] = (jn + q * kWave < j1) ? wc[jn + q * kWave] : 0.0;
+            }
+        }
+        if (kStage && full) {
+#pragma unroll
+            for (int q = 0; q < kPointsPerLane; ++q) {
+                uq[q] = stage[q * kWave + lane];
+                vq[q] = stage[kChunk + q * kWave + lane];
+                tq[q] = stage[2 * kChunk + q * kWave + lane];
+            }
+        } else if (full) {
+            const double *up = u + jl, *vp = v + jl, *tp = wt + jl;
+#pragma unroll
+            for (int q = 0; q < kPointsPerLane; ++q) {
+                uq[q] = up[q * kWave];
+                vq[q] = vp[q * kWave];
+                tq[q] = tp[q * kWave];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kPointsPerLane; ++q) {
+                const bool ok = jl + q * kWave < j1;
+                uq[q] = ok ? u[jl + q * kWave] : 0.0;
+                vq[q] = ok ? v[jl + q * kWave] : 0.0;
+                tq[q] = ok ? wt[jl + q * kWave] : 0.0;   // weight 0: the point contributes nothing
+            }
+        }
 #pragma unroll
         for (int q = 0; q < kPointsPerLane; ++q) {
-            const int64_t j = jb + q * kWave + lane;
-            const bool ok = j < j1;
-            const double uj = ok ? u[j] : 0.0;
-            const double vj = ok ? v[j] : 0.0;
-            const double wj = ok ? wt[j] : 0.0;
-            const double vd = __builtin_fma(zr, uj, -(zi * vj));        // Re((zr + i zi)(u + i v))
-            const double e = wj * (vd - acc[q]);                         // equations.py:202
+            const double vd = __builtin_fma(zr, uq[q], -(zi * vq[q]));   // Re((zr + i zi)(u + i v))
+            const double e = tq[q] * (vd - acc[q]);                       // equations.py:202
             ss = __builtin_fma(e, e, ss);
-            if (WRITE_R && ok) R_out[particle * N + j] = e;
-            const double nzr = __builtin_fma(zr, rr, -(zi * ri));        // z *= rho
+            if (WRITE_R && (full || jl + q * kWave < j1)) R_out[particle * N + jl + q * kWave] = e;
+            const double nzr = __builtin_fma(zr, rr, -(zi * ri));         // z *= rho
             zi = __builtin_fma(zr, ri, zi * rr);
             zr = nzr;
         }
@@ -434,7 +526,13 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         set_error("swarm too large for one launch");
         return NMRFIT_E_INVALID;
     }
-    const size_t lds = (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * (sizeof(PeakLor) + sizeof(PeakWin));
+    const size_t lds_recs = (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * (sizeof(PeakLor) + sizeof(PeakWin));
+    const size_t lds_stage = (size_t)kWavesPerBlock * 3 * kChunk * sizeof(double);
+    // DEFAULT stages u/v/weights through LDS as long as three workgroups still fit in a CU's
+    // 160 KiB (P <= 28); beyond that it runs the unstaged 8-peak kernel.
+    int variant = ctx->variant;
+    if (variant == NMRFIT_VARIANT_DEFAULT && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_OCT;
+    const size_t lds = lds_recs + (variant == NMRFIT_VARIANT_DEFAULT ? lds_stage : 0);
     double *out = df;
     if (nseg > 1) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, waves);
@@ -442,7 +540,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         out = ctx->d_partial;
     }
     int rc;
-    switch (ctx->variant) {
+    switch (variant) {
         case NMRFIT_VARIANT_BASELINE:
             rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
             break;
@@ -451,6 +549,12 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
             break;
         case NMRFIT_VARIANT_SINGLE:
             rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            break;
+        case NMRFIT_VARIANT_QUAD:
+            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            break;
+        case NMRFIT_VARIANT_OCT:
+            rc = launch_variant<NMRFIT_VARIANT_OCT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
             break;
         default:
             rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 RTOL_F = 1e-9
 F_FLOOR = 1e-6
-VARIANTS = [_cabi.VARIANT_DEFAULT, _cabi.VARIANT_BASELINE, _cabi.VARIANT_NOSKIP, _cabi.VARIANT_SINGLE]
+VARIANTS = [_cabi.VARIANT_DEFAULT, _cabi.VARIANT_BASELINE, _cabi.VARIANT_NOSKIP, _cabi.VARIANT_SINGLE,
+            _cabi.VARIANT_QUAD, _cabi.VARIANT_OCT]
 
 
 def _close_f(f, ref, rtol=RTOL_F):

@@ -57,8 +57,25 @@ def _lineshape(w, r, width, loc, a):
     return a * (r * lor + (1.0 - r) * gau)
 
 
-def make_spectrum(N, P, seed=1, noise=1e-3, w_lo=3.0, w_hi=4.0):
-    """Returns dict(w,u,v,weights,x_true,lower,upper,peaks) for a P-peak, N-point spectrum."""
+def _dispersion(w, r, width, loc, a):
+    """Imaginary (dispersive) partner of ``_lineshape``: its Hilbert transform, which is what
+    the reference's Kramers-Kronig integral (nmrfit/equations.py:9-80) evaluates numerically.
+    Lorentzian 1/(1+t^2) -> t/(1+t^2); Gaussian exp(-x^2) -> (2/sqrt(pi))*Dawson(x)."""
+    from scipy.special import dawsn
+    t = (w - loc) * (2.0 / width)
+    lor = (2.0 / (np.pi * width)) * t / (1.0 + t * t)
+    gau = (2.0 / width) * np.sqrt(np.log(2.0) / np.pi) * (2.0 / np.sqrt(np.pi)) * dawsn(np.sqrt(np.log(2.0)) * t)
+    return a * (r * lor + (1.0 - r) * gau)
+
+
+def make_spectrum(N, P, seed=1, noise=1e-3, w_lo=3.0, w_hi=4.0, physical=False):
+    """Returns dict(w,u,v,weights,x_true,lower,upper,peaks) for a P-peak, N-point spectrum.
+
+    physical=False (the BASELINE/SURVEY 8(d) workload): the imaginary channel is pure noise --
+    enough for the objective, which never looks at it when fit_im=False, but it leaves the
+    phase degenerate with the areas (rotating by D scales the real part by cos D).
+    physical=True: the imaginary channel carries the dispersive line shape, as a spectrometer
+    delivers it, so (p0, p1) are identifiable; used by the convergence tests."""
     rng = np.random.default_rng(seed)
     w = np.linspace(w_lo, w_hi, N)
     p0, p1, r, yoff = 0.3, -0.2, 0.6, 0.002
@@ -75,6 +92,9 @@ def make_spectrum(N, P, seed=1, noise=1e-3, w_lo=3.0, w_hi=4.0):
     sigma = noise * np.max(V)
     Vn = V + sigma * rng.standard_normal(N)
     In = sigma * rng.standard_normal(N)
+    if physical:
+        for k in range(P):
+            In += _dispersion(w, r, widths[k], locs[k], areas[k])
     # de-phase: (u + i v) = (V + i I) * exp(-i phi), phi_j = p0 + p1*j/N
     phi = p0 + p1 * np.arange(N) / N
     z = (Vn + 1j * In) * np.exp(-1j * phi)

@@ -95,6 +95,11 @@ class FitUtility:
                                                  verbose=True)
                 finally:
                     sw.close()
+            if opt.get('polish', False):
+                # opt-in extension (no reference counterpart): trust-region least squares on the
+                # batched residual kernel, started from the swarm's answer
+                from . import lsq
+                xopt, fopt, _ = lsq.polish(ev, xopt, self.lower, self.upper)
         finally:
             ev.close()
 

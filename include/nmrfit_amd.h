@@ -40,7 +40,7 @@ enum {
     NMRFIT_E_INVALID = -1,      /* bad argument (NULL pointer, negative size, P out of range) */
     NMRFIT_E_NO_DEVICE = -2,    /* no usable HIP device / device index out of range         */
     NMRFIT_E_HIP = -3,          /* a HIP runtime call failed; see nmrfit_last_error()       */
-    NMRFIT_E_UNSUPPORTED = -4,  /* fit_im != 0 (Kramers-Kronig path, equations.py:197-209)  */
+    NMRFIT_E_UNSUPPORTED = -4,  /* combination not implemented (e.g. fit_im with an A/B variant) */
     NMRFIT_E_STATE = -5         /* call sequence error (e.g. pso step before init)          */
 };
 
@@ -52,6 +52,19 @@ enum {
     NMRFIT_VARIANT_SINGLE = 3,    /* one reciprocal per unit + Gaussian window skip                  */
     NMRFIT_VARIANT_QUAD = 4,      /* 4 Lorentzians per reciprocal + Gaussian window skip             */
     NMRFIT_VARIANT_OCT = 5        /* DEFAULT without the LDS-DMA staging of u/v/weights               */
+};
+
+/* What the objective compares besides the real part (nmrfit/equations.py:197-209).
+ * The reference evaluates the imaginary line shape by a Kramers-Kronig quadrature per grid
+ * point (equations.py:9-80); this library uses its closed form (Lorentzian dispersion +
+ * Dawson's integral), which agrees with the quadrature to the quadrature's tolerance. */
+enum {
+    NMRFIT_FIT_IM_OFF = 0,     /* fit_im=False: real part only (reference default)                */
+    NMRFIT_FIT_IM_REFERENCE = 1, /* fit_im=True exactly as the reference computes it: the imaginary
+                                  model is the LAST peak's dispersion only, because
+                                  equations.py:199 assigns I_fit instead of accumulating it       */
+    NMRFIT_FIT_IM_SUM = 2      /* imaginary model = sum over all peaks (what generate_result,
+                                  utils.py:271-276, builds)                                      */
 };
 
 typedef struct nmrfit_ctx nmrfit_ctx;
@@ -81,6 +94,8 @@ int nmrfit_ctx_synchronize(nmrfit_ctx *ctx);
  * with an RCCL collective on the same stream with no host synchronisation. */
 int nmrfit_ctx_set_stream(nmrfit_ctx *ctx, void *hip_stream);
 int nmrfit_ctx_set_variant(nmrfit_ctx *ctx, int variant);
+/* imaginary-part mode (NMRFIT_FIT_IM_*) for the device-pointer objective calls and the swarm */
+int nmrfit_ctx_set_fit_im(nmrfit_ctx *ctx, int fit_im);
 int nmrfit_ctx_n(const nmrfit_ctx *ctx, int64_t *N);
 
 /* ---- the hot path -----------------------------------------------------------------------
@@ -88,13 +103,22 @@ int nmrfit_ctx_n(const nmrfit_ctx *ctx, int64_t *N);
  *     fx[i] = equations.objective(x[i, :], w, u, v, weights, fit_im)
  * (nmrfit/equations.py:152-212, called by pyswarm from nmrfit/utils.py:176-182) by one
  * batched launch: f_out[i] = sqrt(mean_j (weights_j * (V_data_ij - V_fit_ij))^2).
- * fit_im must be 0 (NMRFIT_E_UNSUPPORTED otherwise).  S == 0 is a no-op.           */
+ * fit_im is one of NMRFIT_FIT_IM_*; with it the value is (rmse_real + rmse_imag)/2
+ * (equations.py:205-209).  S == 0 is a no-op.                                        */
 int nmrfit_objective_batch(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *X, int fit_im,
                            double *f_out);
 /* R_out[b*N + j] = weights_j * (V_data_bj - V_fit_bj): the vector inside the mean of
  * nmrfit/equations.py:202.  f_out (may be NULL) receives the matching objective values. */
 int nmrfit_residual_batch(nmrfit_ctx *ctx, int64_t B, int32_t P, const double *X, double *R_out,
                           double *f_out);
+
+/* Per-peak contributions of one parameter vector on an output grid -- the building block of
+ * FitUtility.generate_result (nmrfit/utils.py:226-295): real_out[k*Nout + j] =
+ * voigt(w_out[j]; r, yoff, peak k) (equations.py:115-149, yoff included per peak) and
+ * imag_out[k*Nout + j] = its Kramers-Kronig partner (equations.py:52-80) in closed form.
+ * w_out == NULL evaluates on the context's own grid (Nout is then ignored and taken as N). */
+int nmrfit_contributions(nmrfit_ctx *ctx, int32_t P, const double *x, int64_t Nout, const double *w_out,
+                         double *real_out, double *imag_out);
 
 /* device-pointer forms (asynchronous on the context's stream) */
 int nmrfit_objective_batch_dev(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df_out);

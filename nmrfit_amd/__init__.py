@@ -12,6 +12,6 @@ CPU fallback.  Instrument I/O, peak picking, GUI selectors and plotting of the r
 out of scope.
 """
 from .core import fit  # noqa: F401
-from . import equations, pso, synth, utils  # noqa: F401
+from . import equations, proc_autophase, pso, synth, utils  # noqa: F401
 
 __version__ = "0.1.0"

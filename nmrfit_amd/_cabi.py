@@ -15,6 +15,7 @@ BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4, -5
+FIT_IM_OFF, FIT_IM_REFERENCE, FIT_IM_SUM = 0, 1, 2
 VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_OCT = 0, 1, 2, 3, 4, 5
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
@@ -44,10 +45,12 @@ SIGNATURES = {
     "nmrfit_ctx_set_weights": [_VP, _VP],
     "nmrfit_ctx_synchronize": [_VP],
     "nmrfit_ctx_set_variant": [_VP, _INT],
+    "nmrfit_ctx_set_fit_im": [_VP, _INT],
     "nmrfit_ctx_set_stream": [_VP, _VP],
     "nmrfit_ctx_n": [_VP, ctypes.POINTER(_I64)],
     "nmrfit_objective_batch": [_VP, _I64, _I32, _VP, _INT, _VP],
     "nmrfit_residual_batch": [_VP, _I64, _I32, _VP, _VP, _VP],
+    "nmrfit_contributions": [_VP, _I32, _VP, _I64, _VP, _VP, _VP],
     "nmrfit_objective_batch_dev": [_VP, _I64, _I32, _VP, _VP],
     "nmrfit_residual_batch_dev": [_VP, _I64, _I32, _VP, _VP, _VP],
     "nmrfit_dev_alloc": [_VP, _I64, _c_void_pp],

@@ -288,13 +288,23 @@ int nmrfit_residual_batch_dev(nmrfit_ctx *ctx, int64_t B, int32_t P, const doubl
     return launch_objective(ctx, B, P, dX, df_out, dR_out);
 }
 
+int nmrfit_ctx_set_fit_im(nmrfit_ctx *ctx, int fit_im)
+{
+    if (!ctx || fit_im < 0 || fit_im > NMRFIT_FIT_IM_SUM) {
+        set_error("fit_im must be 0 (real part), 1 (reference fit_im=True) or 2 (all-peak imaginary model)");
+        return NMRFIT_E_INVALID;
+    }
+    ctx->fit_im = fit_im;
+    return NMRFIT_OK;
+}
+
 int nmrfit_objective_batch(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *X, int fit_im, double *f_out)
 {
     int rc = bind(ctx);
     if (rc != NMRFIT_OK) return rc;
-    if (fit_im) {
-        set_error("fit_im=True (Kramers-Kronig imaginary fit, equations.py:197-209) is not supported by this library");
-        return NMRFIT_E_UNSUPPORTED;
+    if (fit_im < 0 || fit_im > NMRFIT_FIT_IM_SUM) {
+        set_error("fit_im must be 0 (real part), 1 (reference fit_im=True) or 2 (all-peak imaginary model)");
+        return NMRFIT_E_INVALID;
     }
     rc = check_batch(ctx, S, P, X, f_out);
     if (rc != NMRFIT_OK) return rc;
@@ -303,10 +313,61 @@ int nmrfit_objective_batch(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *
     if ((rc = ensure(ctx, &ctx->d_X, &ctx->cap_X, S * D)) != NMRFIT_OK) return rc;
     if ((rc = ensure(ctx, &ctx->d_f, &ctx->cap_f, S)) != NMRFIT_OK) return rc;
     NMRFIT_HIP(hipMemcpyAsync(ctx->d_X, X, (size_t)(S * D) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = launch_objective(ctx, S, P, ctx->d_X, ctx->d_f, nullptr)) != NMRFIT_OK) return rc;
+    const int saved = ctx->fit_im;
+    ctx->fit_im = fit_im;
+    rc = launch_objective(ctx, S, P, ctx->d_X, ctx->d_f, nullptr);
+    ctx->fit_im = saved;
+    if (rc != NMRFIT_OK) return rc;
     NMRFIT_HIP(hipMemcpyAsync(f_out, ctx->d_f, (size_t)S * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
     return NMRFIT_OK;
+}
+
+int nmrfit_contributions(nmrfit_ctx *ctx, int32_t P, const double *x, int64_t Nout, const double *w_out,
+                         double *real_out, double *imag_out)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (P < 0 || P > kMaxPeaks || !x || Nout < 0 || (P > 0 && Nout > 0 && (!real_out || !imag_out))) {
+        set_error("nmrfit_contributions: bad arguments");
+        return NMRFIT_E_INVALID;
+    }
+    if (!w_out) Nout = ctx->N;
+    const int64_t n = (int64_t)P * Nout;
+    if (n == 0) return NMRFIT_OK;
+    const int64_t D = 4 + 3 * (int64_t)P;
+    double *d_x = nullptr, *d_w = nullptr, *d_out = nullptr;
+    hipStream_t st = ctx->stream;
+#define CB_HIP(call)                                              \
+    do {                                                          \
+        hipError_t _e = (call);                                   \
+        if (_e != hipSuccess) {                                   \
+            rc = hip_fail(_e, #call, __FILE__, __LINE__);         \
+            goto done;                                            \
+        }                                                         \
+    } while (0)
+    CB_HIP(hipMalloc((void **)&d_x, (size_t)D * sizeof(double)));
+    CB_HIP(hipMalloc((void **)&d_out, (size_t)(2 * n) * sizeof(double)));
+    CB_HIP(hipMemcpyAsync(d_x, x, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
+    if (w_out) {
+        // centre on the host with the context's offset: the kernel works on w - w0
+        std::vector<double> wc((size_t)Nout);
+        for (int64_t j = 0; j < Nout; ++j) wc[(size_t)j] = w_out[j] - ctx->w0;
+        CB_HIP(hipMalloc((void **)&d_w, (size_t)Nout * sizeof(double)));
+        CB_HIP(hipMemcpy(d_w, wc.data(), (size_t)Nout * sizeof(double), hipMemcpyHostToDevice));
+    }
+    rc = launch_contributions(ctx, P, d_x, Nout, w_out ? d_w : ctx->d_wc, d_out, d_out + n);
+    if (rc != NMRFIT_OK) goto done;
+    CB_HIP(hipMemcpyAsync(real_out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    CB_HIP(hipMemcpyAsync(imag_out, d_out + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    CB_HIP(hipStreamSynchronize(st));
+#undef CB_HIP
+done:
+    if (rc != NMRFIT_OK) (void)hipStreamSynchronize(st);
+    if (d_x) (void)hipFree(d_x);
+    if (d_w) (void)hipFree(d_w);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
 }
 
 int nmrfit_residual_batch(nmrfit_ctx *ctx, int64_t B, int32_t P, const double *X, double *R_out, double *f_out)

@@ -69,6 +69,7 @@ struct nmrfit_ctx {
     int64_t cap_R = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int variant = NMRFIT_VARIANT_DEFAULT;
+    int fit_im = 0;              // 0 real only; 1 reference-compatible fit_im=True; 2 all-peak imaginary model
     nmrfit::LaunchGeom last;
 };
 
@@ -78,4 +79,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
 int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need);
 // centred grid + per-chunk (min,max) table from the raw device copy of w
 int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw);
+// per-peak real/imag contributions on a (centred) output grid resident on the device
+int launch_contributions(nmrfit_ctx *ctx, int32_t P, const double *dx, int64_t Nout, const double *d_wc_out,
+                         double *d_real, double *d_imag);
 }  // namespace nmrfit

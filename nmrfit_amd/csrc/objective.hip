@@ -35,6 +35,9 @@
 //     the per-segment partial sums in fixed order (deterministic, no atomics).
 #include "nmrfit_internal.h"
 
+#define NMRFIT_DAWSON_QUAL __device__ const
+#include "dawson_coeffs.h"
+
 #include <algorithm>
 #include <cmath>
 
@@ -123,6 +126,52 @@ __device__ __forceinline__ double wave_sum(double x)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
     return x;
+}
+
+// Dawson's integral D(x) = exp(-x^2) int_0^x exp(t^2) dt, |error| <= 4.1e-16 relative
+// (piecewise polynomials generated by tools/gen_dawson.py).  The Hilbert transform of the
+// Gaussian line exp(-x^2) is (2/sqrt(pi)) D(x): the closed form of what the reference's
+// Kramers-Kronig quadrature computes point by point (nmrfit/equations.py:9-80).
+__device__ __forceinline__ double dawson(double x)
+{
+    const double ax = fabs(x);
+    double r;
+    if (ax < 1.0) {
+        const double y = x * x;
+        double p = dawson::kNear[14];
+#pragma unroll
+        for (int i = 13; i >= 0; --i) p = __builtin_fma(p, y, dawson::kNear[i]);
+        return x * p;
+    } else if (ax < 7.0) {
+        const int k = (int)ax;                 // 1..6
+        const double t = 2.0 * (ax - (double)k) - 1.0;
+        const double *q = dawson::kMid[k - 1];
+        double p = q[18];
+#pragma unroll
+        for (int i = 17; i >= 0; --i) p = __builtin_fma(p, t, q[i]);
+        r = p;
+    } else {
+        const double inv = 1.0 / ax;          // NaN/inf propagate: D(inf) = 0
+        const double s2 = 49.0 * inv * inv;
+        double p = dawson::kFar[11];
+#pragma unroll
+        for (int i = 10; i >= 0; --i) p = __builtin_fma(p, s2, dawson::kFar[i]);
+        r = 0.5 * p * inv;
+    }
+    return copysign(r, x);
+}
+
+constexpr double kSqrtLn2 = 0.83255461115769775635;     // sqrt(ln 2)
+constexpr double kInvSqrtPi = 0.56418958354775628695;   // 1/sqrt(pi)
+
+// Imaginary (dispersive) partner of one peak at one point: the Hilbert transform of
+// a*(r*L + (1-r)*G) -- yoff drops out of the transform (equations.py:43-48: V2 - V1).
+//   L -> AL * t/(1+t^2),   G -> (AG2/2) * (2/sqrt(pi)) * D(sqrt(ln2) t)
+__device__ __forceinline__ double dispersion(double wcj, const PeakLor &r)
+{
+    const double t = __builtin_fma(wcj, r.ihw, r.c);
+    const double s = __builtin_fma(t, t, 1.0);
+    return __builtin_fma(r.al * t, rcp64(s), (r.ag2 * kInvSqrtPi) * dawson(kSqrtLn2 * t));
 }
 
 // ---- per-chunk building blocks ---------------------------------------------------------------
@@ -220,7 +269,10 @@ __device__ __forceinline__ void gauss_add(const PeakLor *r, const double (&wv)[k
 //          NMRFIT_VARIANT_QUAD     4 per reciprocal + Gaussian window skip
 // Wave g = blockIdx.x*4 + wave  ->  particle g / nseg, segment g % nseg;
 // a segment is seg_len (multiple of 512) consecutive grid points.
-template <int VARIANT, bool WRITE_R>
+template <int VARIANT, bool WRITE_R, int FIT_IM>
+// FIT_IM: 0 real part only (reference default); 1 reference-compatible fit_im=True -- the
+// imaginary model is the LAST peak's dispersion only, because equations.py:199 assigns
+// instead of accumulating; 2 the imaginary model is the sum over all peaks.
 // The 8-peak group keeps 24 per-peak constants live next to the 8-point register block:
 // ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
 __global__ __launch_bounds__(kBlock, (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_OCT) ? 3 : 4) void objective_kernel(
@@ -283,7 +335,7 @@ __global__ __launch_bounds__(kBlock, (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIA
         sincos_fast((p1 * 64.0) * invN, &ri, &rr);
     }
     const double base = (double)P * yoff;     // yoff is added once per peak (equations.py:147,195)
-    double ss = 0.0;
+    double ss = 0.0, ss_im = 0.0;
     constexpr bool kSkip = (VARIANT != NMRFIT_VARIANT_NOSKIP && VARIANT != NMRFIT_VARIANT_BASELINE);
     constexpr int kGroup = (VARIANT == NMRFIT_VARIANT_SINGLE) ? 1 : (VARIANT == NMRFIT_VARIANT_QUAD) ? 4 : 8;
 
@@ -418,6 +470,17 @@ __global__ __launch_bounds__(kBlock, (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIA
             const double vd = __builtin_fma(zr, uq[q], -(zi * vq[q]));   // Re((zr + i zi)(u + i v))
             const double e = tq[q] * (vd - acc[q]);                       // equations.py:202
             ss = __builtin_fma(e, e, ss);
+            if (FIT_IM != 0) {                                            // equations.py:197-199,205-206
+                const double id = __builtin_fma(zr, vq[q], zi * uq[q]);  // Im((zr + i zi)(u + i v))
+                double ifit = 0.0;
+                if (FIT_IM == 1) {
+                    if (P > 0) ifit = dispersion(wv[q], lor[P - 1]);
+                } else {
+                    for (int k = 0; k < P; ++k) ifit += dispersion(wv[q], lor[k]);
+                }
+                const double ei = tq[q] * (id - ifit);
+                ss_im = __builtin_fma(ei, ei, ss_im);
+            }
             if (WRITE_R && (full || jl + q * kWave < j1)) R_out[particle * N + jl + q * kWave] = e;
             const double nzr = __builtin_fma(zr, rr, -(zi * ri));         // z *= rho
             zi = __builtin_fma(zr, ri, zi * rr);
@@ -426,23 +489,71 @@ __global__ __launch_bounds__(kBlock, (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIA
     }
 
     ss = wave_sum(ss);
+    if (FIT_IM != 0) ss_im = wave_sum(ss_im);
     if (lane == 0) {
-        if (nseg == 1)
-            out[particle] = sqrt(ss / (double)N);
-        else
-            out[particle * nseg + seg] = ss;
+        if (FIT_IM == 0) {
+            if (nseg == 1)
+                out[particle] = sqrt(ss / (double)N);
+            else
+                out[particle * nseg + seg] = ss;
+        } else {   // (rmse_real + rmse_imag) / 2, equations.py:205-209
+            if (nseg == 1) {
+                out[particle] = 0.5 * (sqrt(ss / (double)N) + sqrt(ss_im / (double)N));
+            } else {
+                out[(particle * nseg + seg) * 2] = ss;
+                out[(particle * nseg + seg) * 2 + 1] = ss_im;
+            }
+        }
     }
 }
 
-// f[i] = sqrt( (sum of the particle's segment partials, in segment order) / N )
-__global__ void finalize_kernel(const double *__restrict__ partial, int64_t S, int nseg, int64_t N,
+// f[i] = sqrt( (sum of the particle's segment partials, in segment order) / N ); with the
+// imaginary part: the mean of the real and imaginary RMSE (two partials per segment)
+__global__ void finalize_kernel(const double *__restrict__ partial, int64_t S, int nseg, int64_t N, int fit_im,
                                 double *__restrict__ f)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
-    double ss = 0.0;
-    for (int s = 0; s < nseg; ++s) ss += partial[i * nseg + s];
-    f[i] = sqrt(ss / (double)N);
+    if (fit_im == 0) {
+        double ss = 0.0;
+        for (int s = 0; s < nseg; ++s) ss += partial[i * nseg + s];
+        f[i] = sqrt(ss / (double)N);
+    } else {
+        double ss = 0.0, si = 0.0;
+        for (int s = 0; s < nseg; ++s) {
+            ss += partial[(i * nseg + s) * 2];
+            si += partial[(i * nseg + s) * 2 + 1];
+        }
+        f[i] = 0.5 * (sqrt(ss / (double)N) + sqrt(si / (double)N));
+    }
+}
+
+// Per-peak real and imaginary contributions on an output grid (FitUtility.generate_result,
+// nmrfit/utils.py:262-281): real[k, j] = voigt(w_j; r, yoff, peak k) (equations.py:141-147),
+// imag[k, j] = its Kramers-Kronig partner in closed form.  One thread per (peak, point).
+__global__ void contributions_kernel(const double *__restrict__ wc_out, int64_t Nout, const double *__restrict__ x,
+                                     int P, double w0, double wspan, double *__restrict__ real_out,
+                                     double *__restrict__ imag_out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)P * Nout) return;
+    const int k = (int)(idx / Nout);
+    const int64_t j = idx - (int64_t)k * Nout;
+    const double r = x[2], yoff = x[3];
+    const double width = x[4 + 3 * k], loc = x[5 + 3 * k], a = x[6 + 3 * k];
+    const double ihw = 2.0 / width;
+    const double locc = loc - w0;
+    const double lim = 1.0e18 / (wspan + fabs(locc));
+    PeakLor rec;
+    rec.ihw = (fabs(ihw) > lim) ? copysign(lim, ihw) : ihw;
+    rec.c = -locc * rec.ihw;
+    rec.al = a * r * ihw * kInvPi;
+    rec.ag2 = 2.0 * a * (1.0 - r) * ihw * kSqrtLn2OverPi;
+    const double wj = wc_out[j];
+    const double t = __builtin_fma(wj, rec.ihw, rec.c);
+    const double s = __builtin_fma(t, t, 1.0);
+    real_out[idx] = yoff + __builtin_fma(rec.al, rcp64(s), rec.ag2 * exp2_neg(-s));
+    imag_out[idx] = dispersion(wj, rec);
 }
 
 // per-chunk (min, max) of the centred grid: one wave per chunk
@@ -476,16 +587,26 @@ __global__ void centre_kernel(const double *__restrict__ w, int64_t N, double w0
 
 template <int VARIANT>
 int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *out, double *dR,
-                   int nseg, int64_t seg_len, int64_t blocks, size_t lds)
+                   int nseg, int64_t seg_len, int64_t blocks, size_t lds, int fit_im)
 {
-    if (dR)
-        hipLaunchKernelGGL((objective_kernel<VARIANT, true>), dim3((unsigned)blocks), dim3(kBlock), lds,
-                           ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,
-                           ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, out, dR);
-    else
-        hipLaunchKernelGGL((objective_kernel<VARIANT, false>), dim3((unsigned)blocks), dim3(kBlock), lds,
-                           ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,
-                           ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, out, dR);
+#define NMRFIT_LAUNCH(WR, FI)                                                                                   \
+    hipLaunchKernelGGL((objective_kernel<VARIANT, WR, FI>), dim3((unsigned)blocks), dim3(kBlock), lds,         \
+                       ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,     \
+                       ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, out, dR)
+    if (dR) {
+        NMRFIT_LAUNCH(true, 0);
+    } else if (fit_im == 0) {
+        NMRFIT_LAUNCH(false, 0);
+    } else if constexpr (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_OCT) {
+        if (fit_im == 1)
+            NMRFIT_LAUNCH(false, 1);
+        else
+            NMRFIT_LAUNCH(false, 2);
+    } else {
+        set_error("fit_im is implemented for the DEFAULT kernel variant only");
+        return NMRFIT_E_UNSUPPORTED;
+    }
+#undef NMRFIT_LAUNCH
     NMRFIT_HIP(hipGetLastError());
     return NMRFIT_OK;
 }
@@ -508,6 +629,7 @@ int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw)
 
 int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR)
 {
+    const int fit_im = dR ? 0 : ctx->fit_im;
     if (S == 0) return NMRFIT_OK;
     const int64_t N = ctx->N;
     // Segmenting: a wave is one (particle, segment) task.  Aim for ~16 tasks per SIMD so the
@@ -535,40 +657,51 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     const size_t lds = lds_recs + (variant == NMRFIT_VARIANT_DEFAULT ? lds_stage : 0);
     double *out = df;
     if (nseg > 1) {
-        int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, waves);
+        int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, waves * (fit_im ? 2 : 1));
         if (rc != NMRFIT_OK) return rc;
         out = ctx->d_partial;
     }
     int rc;
     switch (variant) {
         case NMRFIT_VARIANT_BASELINE:
-            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
             break;
         case NMRFIT_VARIANT_NOSKIP:
-            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
             break;
         case NMRFIT_VARIANT_SINGLE:
-            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
             break;
         case NMRFIT_VARIANT_QUAD:
-            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
             break;
         case NMRFIT_VARIANT_OCT:
-            rc = launch_variant<NMRFIT_VARIANT_OCT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            rc = launch_variant<NMRFIT_VARIANT_OCT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
             break;
         default:
-            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds);
+            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
             break;
     }
     if (rc != NMRFIT_OK) return rc;
     if (nseg > 1) {
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream,
-                           ctx->d_partial, S, (int)nseg, N, df);
+                           ctx->d_partial, S, (int)nseg, N, fit_im, df);
         NMRFIT_HIP(hipGetLastError());
     }
     ctx->last.waves = waves;
     ctx->last.nseg = (int32_t)nseg;
     ctx->last.seg_len = seg_len;
+    return NMRFIT_OK;
+}
+
+int launch_contributions(nmrfit_ctx *ctx, int32_t P, const double *dx, int64_t Nout, const double *d_wc_out,
+                         double *d_real, double *d_imag)
+{
+    const int64_t n = (int64_t)P * Nout;
+    if (n == 0) return NMRFIT_OK;
+    hipLaunchKernelGGL(contributions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_wc_out,
+                       Nout, dx, (int)P, ctx->w0, ctx->wspan, d_real, d_imag);
+    NMRFIT_HIP(hipGetLastError());
     return NMRFIT_OK;
 }
 

@@ -8,6 +8,12 @@ libnmrfit_amd.so.
     Evaluator(...).residual_batch(X) -> R[B, N]                weights*(V_data - V_fit), eq.py:202
     laplace1d(x, n=10, omega=0.33333333)                       nmrfit/equations.py:215-238
 
+    Evaluator(...).contributions(x, w) -> real[P, N], imag[P, N]   voigt + Kramers-Kronig per peak
+    ps2(u, v, p0, p1, inv) / voigt(w, ...) / kk_relation_vectorized(w, ...)   host utilities
+
+``fit_im=True`` is supported: the imaginary line shape the reference obtains by adaptive
+quadrature per grid point (equations.py:9-80) is evaluated in closed form on the GPU.
+
 There is no CPU fallback in this module: without the HIP library and a gfx950 device every
 evaluation raises ``NmrfitError``.
 """
@@ -18,6 +24,19 @@ import numpy as np
 
 from . import _cabi
 from ._cabi import NmrfitError  # noqa: F401  (re-export)
+
+
+def fit_im_mode(fit_im):
+    """Map the reference's ``fit_im`` argument to the library's mode: False/0 -> real part only;
+    True/1 -> exactly what the reference computes (equations.py:197-209: the imaginary model is
+    the LAST peak only, since I_fit is assigned, not accumulated); "sum"/2 -> all peaks."""
+    if fit_im is False or fit_im is None or fit_im == 0:
+        return _cabi.FIT_IM_OFF
+    if fit_im is True or fit_im == 1 or fit_im == "reference":
+        return _cabi.FIT_IM_REFERENCE
+    if fit_im == 2 or fit_im == "sum":
+        return _cabi.FIT_IM_SUM
+    raise ValueError("fit_im must be False, True, 'reference' or 'sum'")
 
 
 class Evaluator:
@@ -90,9 +109,29 @@ class Evaluator:
     def objective_batch(self, X, fit_im=False):
         X, P = self._as_batch(X)
         f = np.empty(X.shape[0], dtype=np.float64)
-        _cabi.check(self._lib.nmrfit_objective_batch(self._ctx, X.shape[0], P, _cabi.ptr(X), 1 if fit_im else 0,
+        _cabi.check(self._lib.nmrfit_objective_batch(self._ctx, X.shape[0], P, _cabi.ptr(X), fit_im_mode(fit_im),
                                                      _cabi.ptr(f)))
         return f
+
+    def set_fit_im(self, fit_im):
+        """Imaginary-part mode for the device-resident calls and the swarm (see fit_im_mode)."""
+        _cabi.check(self._lib.nmrfit_ctx_set_fit_im(self._ctx, fit_im_mode(fit_im)))
+
+    def contributions(self, x, w=None):
+        """Per-peak (real, imag) contributions [P, Nout] of one parameter vector: voigt per peak
+        and its Kramers-Kronig partner in closed form (FitUtility.generate_result,
+        nmrfit/utils.py:262-281).  ``w`` None -> the context's grid."""
+        x = _cabi.f64(x)
+        if x.ndim != 1 or x.size < 4 or (x.size - 4) % 3:
+            raise ValueError("parameter vector must have 4 + 3P entries")
+        P = (x.size - 4) // 3
+        wout = None if w is None else _cabi.f64(w)
+        n = self.N if wout is None else wout.size
+        real = np.empty((P, n), dtype=np.float64)
+        imag = np.empty((P, n), dtype=np.float64)
+        _cabi.check(self._lib.nmrfit_contributions(self._ctx, P, _cabi.ptr(x), n, _cabi.ptr(wout),
+                                                   _cabi.ptr(real), _cabi.ptr(imag)))
+        return real, imag
 
     def residual_batch(self, X, return_f=False):
         X, P = self._as_batch(X)
@@ -155,9 +194,6 @@ def objective(x, w, u, v, weights, fit_im=False):
     The constant arrays are cached on the GPU between calls (keyed by content), so a
     third-party optimiser that calls this per particle still avoids re-uploading them; use
     ``Evaluator.objective_batch`` to evaluate a whole swarm per launch."""
-    if fit_im:
-        raise NmrfitError(_cabi.E_UNSUPPORTED, "fit_im=True (Kramers-Kronig path, equations.py:197-209) "
-                                               "is not supported")
     arrays = tuple(_cabi.f64(a) for a in (w, u, v, weights))
     k = _key(*arrays)
     ev = _shim_cache.get(k)
@@ -167,7 +203,7 @@ def objective(x, w, u, v, weights, fit_im=False):
             old.close()
         ev = Evaluator(*arrays)
         _shim_cache[k] = ev
-    return float(ev.objective_batch(np.asarray(x, dtype=np.float64))[0])
+    return float(ev.objective_batch(np.asarray(x, dtype=np.float64), fit_im=fit_im)[0])
 
 
 def laplace1d(x, n=10, omega=0.33333333):
@@ -176,3 +212,34 @@ def laplace1d(x, n=10, omega=0.33333333):
     for _ in range(n):
         x[1:-1] = (1. - omega) * x[1:-1] + omega * 0.5 * (x[2:] + x[:-2])
     return x
+
+
+# ---- single-line-shape utilities with the reference's names --------------------------------
+def _grid_evaluator(w):
+    """An Evaluator that only carries a grid (for voigt / kk_relation_vectorized)."""
+    w = _cabi.f64(w)
+    k = ("grid",) + _key(w)
+    ev = _shim_cache.get(k)
+    if ev is None:
+        if len(_shim_cache) >= _SHIM_CACHE_MAX:
+            _, old = _shim_cache.popitem()
+            old.close()
+        z = np.zeros_like(w)
+        ev = Evaluator(w, z, z, np.ones_like(w))
+        _shim_cache[k] = ev
+    return ev
+
+
+def voigt(w, r, yoff, width, loc, a):
+    """nmrfit.equations.voigt (equations.py:115-149) on the GPU: yoff + a*(r*L + (1-r)*G)."""
+    x = np.array([0.0, 0.0, r, yoff, width, loc, a], dtype=np.float64)
+    return _grid_evaluator(w).contributions(x)[0][0]
+
+
+def kk_relation_vectorized(w, r, yoff, width, loc, a):
+    """nmrfit.equations.kk_relation_vectorized (equations.py:52-80, 242): the Kramers-Kronig
+    partner of ``voigt`` over w.  The reference integrates numerically for every point
+    (scipy.integrate.quad, ~4 ms per point); this is the closed form (Lorentzian dispersion +
+    Dawson's integral), which the quadrature approximates to ~1e-12."""
+    x = np.array([0.0, 0.0, r, yoff, width, loc, a], dtype=np.float64)
+    return _grid_evaluator(w).contributions(x)[1][0]

@@ -13,12 +13,14 @@ Kept verbatim from the reference interface:
            which the reference does not forward), seed, device, check_every, exchange.
 
 ``processes`` is accepted and ignored: the reference's only use of it is to spread the
-per-particle objective calls over a multiprocessing.Pool (utils.py:182), which the batched
-launch replaces.  ``fit_im=True`` raises (Kramers-Kronig path).
+per-particle objective calls (and the Kramers-Kronig quadratures of generate_result) over a
+multiprocessing.Pool (utils.py:182, 259-261), which the batched launches replace.
+``fit_im=True`` follows the reference to the letter (equations.py:197-209: the imaginary
+model is the last peak's line only); ``fit_im="sum"`` fits the imaginary part of all peaks.
 """
 import numpy as np
 
-from . import _cabi, equations, pso
+from . import _cabi, equations, proc_autophase, pso
 
 
 def compute_weights(w, peaks, expon=0.5):
@@ -64,9 +66,6 @@ class FitUtility:
 
     def fit(self):
         """utils.py:164-189: weights, minimise, store params/error, optional summary."""
-        if self.fit_im:
-            raise equations.NmrfitError(_cabi.E_UNSUPPORTED, "fit_im=True (Kramers-Kronig imaginary fit, "
-                                        "nmrfit/equations.py:197-209) is not supported")
         self.weights = self._compute_weights()
         if self.dynamic_weighting is False:
             self.weights = np.ones_like(self.weights)
@@ -84,6 +83,7 @@ class FitUtility:
 
         ev = equations.Evaluator(self.data.w, self.data.u, self.data.v, self.weights, device=opt.get('device', 0))
         try:
+            ev.set_fit_im(self.fit_im)     # True: the reference's imaginary term (equations.py:197-209)
             if exchange is None or exchange.world == 1:
                 xopt, fopt = pso.pso(ev, self.lower, self.upper, swarmsize=swarmsize, maxiter=maxiter, seed=seed,
                                      check_every=opt.get('check_every', 16), verbose=True, **kw)
@@ -107,6 +107,49 @@ class FitUtility:
         self.error = fopt
         if self.summary is True:
             self._print_summary()
+
+    def generate_result(self, scale=1):
+        """utils.py:226-295: per-peak real and imaginary contributions of the fitted parameters
+        on the data grid (or a grid upsampled by ``scale``), their sums V, I, and the fit
+        rotated back to the (u, v) frame.  The imaginary contributions are the Kramers-Kronig
+        partners in closed form on the GPU (the reference integrates each point numerically)."""
+        if scale == 1.0:
+            w = self.data.w
+        else:
+            w = np.linspace(self.data.w.min(), self.data.w.max(), int(scale * self.data.w.shape[0]))
+        p0, p1 = self.params[0], self.params[1]
+
+        # phase shift data by fit theta (containers.py:68-78 with method='manual')
+        if hasattr(self.data, 'shift_phase'):
+            self.data.shift_phase(method='manual', p0=p0, p1=p1)
+        else:
+            self.data.p0, self.data.p1 = p0, p1
+            self.data.V, self.data.I = proc_autophase.ps2(self.data.u, self.data.v, p0, p1)
+
+        ev = equations.Evaluator(self.data.w, self.data.u, self.data.v, np.ones(len(self.data.w)),
+                                 device=self.options.get('device', 0))
+        try:
+            real, imag = ev.contributions(self.params, None if scale == 1.0 else w)
+        finally:
+            ev.close()
+        real_contribs = [real[k] for k in range(real.shape[0])]
+        imag_contribs = [imag[k] for k in range(imag.shape[0])]
+        V_fit = np.zeros_like(w)
+        I_fit = np.zeros_like(w)
+        for k in range(len(real_contribs)):          # same accumulation order as utils.py:276-277
+            V_fit = V_fit + real_contribs[k]
+            I_fit = I_fit + imag_contribs[k]
+
+        # transform the fits for V and I to get fits for u and v
+        u_fit, v_fit = proc_autophase.ps2(V_fit, I_fit, inv=True, p0=p0, p1=p1)
+
+        self.u = u_fit
+        self.v = v_fit
+        self.V = V_fit
+        self.I = I_fit
+        self.w = w
+        self.real_contribs = real_contribs
+        self.imag_contribs = imag_contribs
 
     def get_areas(self):
         """utils.py:312-322."""

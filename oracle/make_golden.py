@@ -215,6 +215,35 @@ def main():
                  cw_bounds=np.array([p.bounds for p in sp["peaks"]]))
         print("compute_weights fixture written (min %.4f max %.4f)" % (wts.min(), wts.max()))
     np.savez_compressed(os.path.join(OUT, "weights.npz"), **d)
+
+    # --- 7. Kramers-Kronig path: fit_im=True objective and generate_result pieces ---------------
+    # (reference: scipy quad per grid point, ~4 ms each -> small grids only)
+    sp = synth.make_spectrum(160, 3, seed=7, physical=True)
+    X = synth.make_swarm(sp["lower"], sp["upper"], 4, seed=8, x_true=sp["x_true"])
+    f_im = np.array([eq.objective(X[i, :], sp["w"], sp["u"], sp["v"], sp["weights"], True) for i in range(4)])
+    f_re = np.array([eq.objective(X[i, :], sp["w"], sp["u"], sp["v"], sp["weights"], False) for i in range(4)])
+    x = X[1]
+    p0, p1, r, yoff = x[:4]
+    real_c = np.stack([eq.voigt(sp["w"], r, yoff, x[i], x[i + 1], x[i + 2]) for i in range(4, len(x), 3)])
+    imag_c = np.stack([eq.kk_relation_vectorized(sp["w"], r, yoff, x[i], x[i + 1], x[i + 2])
+                       for i in range(4, len(x), 3)])
+    V_ph, I_ph = pa.ps2(sp["u"], sp["v"], p0=p0, p1=p1)
+    u_fit, v_fit = pa.ps2(real_c.sum(axis=0), imag_c.sum(axis=0), inv=True, p0=p0, p1=p1)
+    # upsampled grid (generate_result(scale=1.5), utils.py:241) for one peak
+    w_up = np.linspace(sp["w"].min(), sp["w"].max(), int(1.5 * sp["w"].shape[0]))
+    imag_up = eq.kk_relation_vectorized(w_up, r, yoff, x[4], x[5], x[6])
+    real_up = eq.voigt(w_up, r, yoff, x[4], x[5], x[6])
+    # a wide and a needle line, grid crossing zero
+    w2 = np.linspace(-1.0, 1.0, 96)
+    imag_wide = eq.kk_relation_vectorized(w2, 0.25, 0.01, 0.6, 0.13, 1.7)
+    imag_needle = eq.kk_relation_vectorized(w2, 0.8, 0.0, 0.004, -0.21, 0.02)
+    np.savez_compressed(os.path.join(OUT, "kramers_kronig.npz"), w=sp["w"], u=sp["u"], v=sp["v"],
+                        weights=sp["weights"], X=X, f_fit_im=f_im, f_real=f_re, x=x, real_contribs=real_c,
+                        imag_contribs=imag_c, V=V_ph, I=I_ph, u_fit=u_fit, v_fit=v_fit, w_up=w_up,
+                        imag_up=imag_up, real_up=real_up, w2=w2, imag_wide=imag_wide, imag_needle=imag_needle,
+                        wide_args=np.array([0.25, 0.01, 0.6, 0.13, 1.7]),
+                        needle_args=np.array([0.8, 0.0, 0.004, -0.21, 0.02]))
+    print("kramers_kronig fixture: f_fit_im", f_im)
     print("done ->", OUT)
 
 

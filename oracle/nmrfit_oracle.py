@@ -205,3 +205,72 @@ def pso(func, lb, ub, args=(), swarmsize=100, omega=0.5, phip=0.5, phig=0.5,
     if verbose:
         print('Stopping search: maximum iterations reached --> {:}'.format(maxiter))
     return g, fg
+
+
+# ----------------------------------------------------------------------------------
+# Kramers-Kronig path (fit_im=True and generate_result).  Restated as the reference
+# computes it: adaptive quadrature per grid point.  Slow by construction (~4 ms/point).
+# nmrfit/equations.py:9-49 kk_equation, :52-80 kk_relation, :242 kk_relation_vectorized
+# ----------------------------------------------------------------------------------
+def kk_equation(x, r, yoff, width, loc, a, w):
+    """equations.py:37-49: [V(w - x) - V(w + x)] / x, the integrand with the singularity folded."""
+    L1 = (2 / (np.pi * width)) * 1 / (1 + ((x + w - loc) / (0.5 * width)) ** 2)
+    G1 = (2 / width) * np.sqrt(np.log(2) / np.pi) * np.exp(-((x + w - loc) / (width / (2 * np.sqrt(np.log(2))))) ** 2)
+    V1 = yoff + a * (r * L1 + (1 - r) * G1)
+    L2 = (2 / (np.pi * width)) * 1 / (1 + ((-x + w - loc) / (0.5 * width)) ** 2)
+    G2 = (2 / width) * np.sqrt(np.log(2) / np.pi) * np.exp(-((-x + w - loc) / (width / (2 * np.sqrt(np.log(2))))) ** 2)
+    V2 = yoff + a * (r * L2 + (1 - r) * G2)
+    return 1 / x * (V2 - V1)
+
+
+def kk_relation(w, r, yoff, width, loc, a):
+    """equations.py:79-80: quad(kk_equation, 0, inf)/pi for one w."""
+    import scipy.integrate
+    res, _ = scipy.integrate.quad(kk_equation, 0, np.inf, args=(r, yoff, width, loc, a, w))
+    return res / np.pi
+
+
+kk_relation_vectorized = np.vectorize(kk_relation, otypes=[float])      # equations.py:242 (np.float -> float)
+
+
+def objective_fit_im(x, w, u, v, weights):
+    """equations.py:152-212 with fit_im=True, INCLUDING its quirk: I_fit is assigned inside
+    the peak loop (equations.py:199), so only the last peak's imaginary line is compared."""
+    p0, p1, r, yoff = x[:4]
+    V_data, I_data = ps2(u, v, p0=p0, p1=p1)
+    V_fit = np.zeros_like(V_data)
+    I_fit = np.zeros_like(I_data)
+    for i in range(4, len(x), 3):
+        width, loc, a = x[i], x[i + 1], x[i + 2]
+        V_fit = V_fit + voigt(w, r, yoff, width, loc, a)
+        I_fit = kk_relation_vectorized(w, r, yoff, width, loc, a)
+    rmse = np.sqrt(np.square(np.multiply(weights, (V_data - V_fit))).mean(axis=None))
+    rmse += np.sqrt(np.square(np.multiply(weights, (I_data - I_fit))).mean(axis=None))
+    rmse /= 2.0
+    return rmse
+
+
+def generate_result(params, w_data, u, v, scale=1):
+    """FitUtility.generate_result (utils.py:226-295) as a function: returns a dict with
+    w, V, I (phase-corrected data), real_contribs, imag_contribs, V_fit, I_fit, u_fit, v_fit."""
+    if scale == 1.0:
+        w = w_data
+    else:
+        w = np.linspace(w_data.min(), w_data.max(), int(scale * w_data.shape[0]))
+    V_fit = np.zeros_like(w)
+    I_fit = np.zeros_like(w)
+    p0, p1, r, yoff = params[:4]
+    res = params[4:]
+    V, I = ps2(u, v, p0, p1)                       # containers.py:68-78 shift_phase('manual')
+    real_contribs, imag_contribs = [], []
+    for i in range(0, len(res), 3):
+        width, loc, a = res[i], res[i + 1], res[i + 2]
+        real = voigt(w, r, yoff, width, loc, a)
+        imag = kk_relation_vectorized(w, r, yoff, width, loc, a)
+        real_contribs.append(real)
+        imag_contribs.append(imag)
+        V_fit = V_fit + real
+        I_fit = I_fit + imag
+    u_fit, v_fit = ps2(V_fit, I_fit, inv=True, p0=p0, p1=p1)
+    return dict(w=w, V=V, I=I, real_contribs=real_contribs, imag_contribs=imag_contribs,
+                V_fit=V_fit, I_fit=I_fit, u_fit=u_fit, v_fit=v_fit)

@@ -97,8 +97,8 @@ def test_scalar_shim_matches_reference_signature(eq, golden_dir):
     wr, ur, vr, wtr = g["w"][::-1], g["u"][::-1], g["v"][::-1], g["weights"][::-1]
     f1 = eq.objective(g["X"][3], wr, ur, vr, wtr)
     _close_f([f1], c_oracle.objective_batch(g["X"][3], wr, ur, vr, wtr))
-    with pytest.raises(eq.NmrfitError):
-        eq.objective(g["X"][3], g["w"], g["u"], g["v"], g["weights"], fit_im=True)
+    with pytest.raises(ValueError):
+        eq.objective(g["X"][3], g["w"], g["u"], g["v"], g["weights"], fit_im="nonsense")
 
 
 @pytest.mark.parametrize("S", [1, 3, 50, 204, 1024, 5000])
@@ -135,8 +135,9 @@ def test_empty_batch_and_errors(eq):
         assert f.shape == (0,)
         with pytest.raises(ValueError):
             ev.objective_batch(np.zeros((2, 9)))          # 9 != 4 + 3P
+        ev.set_variant(_cabi.VARIANT_BASELINE)           # fit_im exists for the DEFAULT kernel only
         with pytest.raises(eq.NmrfitError) as ei:
-            ev.objective_batch(np.zeros((1, 10)), fit_im=True)
+            ev.objective_batch(sp["x_true"][None, :], fit_im=True)
         assert ei.value.code == _cabi.E_UNSUPPORTED
     with pytest.raises(ValueError):
         eq.Evaluator(sp["w"], sp["u"][:-1], sp["v"], sp["weights"])

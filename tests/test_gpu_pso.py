@@ -145,5 +145,5 @@ def test_fit_api_end_to_end(problem, capsys):
     res2 = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), dynamic_weighting=False, summary=False,
                           options={"swarmsize": 64, "maxiter": 50, "seed": 2})
     assert (res2.weights == 1.0).all()
-    with pytest.raises(nmrfit_amd.equations.NmrfitError):
-        nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im=True, summary=False)
+    with pytest.raises(ValueError):
+        nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im="nonsense", summary=False)

@@ -53,8 +53,15 @@ def test_fitutility_attributes_and_area_helpers():
     assert fu.calculate_area_fraction() == pytest.approx(areas[areas < m].sum() / areas.sum(), rel=1e-14)
 
 
-def test_fit_im_is_rejected_loudly():
+def test_fit_without_a_gpu_raises():
+    from nmrfit_amd import _cabi
+    if _cabi.device_count() > 0:
+        pytest.skip("a GPU is present")
     sp = synth.make_spectrum(64, 1, seed=2)
     data = synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"])
     with pytest.raises(equations.NmrfitError):
-        nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im=True)
+        nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]))
+    assert equations.fit_im_mode(False) == 0 and equations.fit_im_mode(True) == 1
+    assert equations.fit_im_mode("sum") == 2
+    with pytest.raises(ValueError):
+        equations.fit_im_mode("both")

@@ -69,7 +69,8 @@ def test_dawson_over_the_whole_range(eq):
     w = loc + t * width / 2
     im = eq.kk_relation_vectorized(w, 0.0, 0.0, width, loc, a)
     ref = a * (2 / width) * np.sqrt(np.log(2) / np.pi) * (2 / np.sqrt(np.pi)) * dawsn(np.sqrt(np.log(2)) * t)
-    np.testing.assert_allclose(im, ref, rtol=2e-14, atol=0)
+    # atol: the grid is centred on w[N/2], so w - loc carries ~1e-16 absolute error
+    np.testing.assert_allclose(im, ref, rtol=2e-14, atol=1e-15 * np.abs(ref).max())
 
 
 def test_fit_im_objective_matches_reference(eq, g):
@@ -119,9 +120,10 @@ def test_generate_result_matches_reference(eq, g):
     fu.params = g["x"]
     fu.generate_result()
     si = np.abs(g["imag_contribs"]).max()
-    np.testing.assert_allclose(np.stack(fu.real_contribs), g["real_contribs"], rtol=1e-13)
+    sr = np.abs(g["real_contribs"]).max()
+    np.testing.assert_allclose(np.stack(fu.real_contribs), g["real_contribs"], rtol=0, atol=1e-13 * sr)
     np.testing.assert_allclose(np.stack(fu.imag_contribs), g["imag_contribs"], rtol=0, atol=1e-8 * si)
-    np.testing.assert_allclose(fu.V, g["real_contribs"].sum(axis=0), rtol=1e-13)
+    np.testing.assert_allclose(fu.V, g["real_contribs"].sum(axis=0), rtol=0, atol=1e-13 * sr)
     np.testing.assert_allclose(fu.u, g["u_fit"], rtol=0, atol=1e-8 * si)
     np.testing.assert_allclose(fu.v, g["v_fit"], rtol=0, atol=1e-8 * si)
     np.testing.assert_allclose(data.V, g["V"], rtol=0, atol=1e-15)
@@ -140,5 +142,8 @@ def test_fit_with_imaginary_part(eq):
     data = synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"])
     res = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im=True, summary=False,
                          options={"swarmsize": 204, "maxiter": 400, "seed": 6})
-    assert abs(res.params[0] - sp["x_true"][0]) < 0.05
+    # one line: only the phase AT the line, p0 + p1*j_line/N, is identifiable
+    frac = (sp["x_true"][5] - sp["w"][0]) / (sp["w"][-1] - sp["w"][0])
+    ph = res.params[0] + frac * res.params[1]
+    assert abs(ph - (sp["x_true"][0] + frac * sp["x_true"][1])) < 0.02
     assert res.params[6] == pytest.approx(sp["x_true"][6], rel=0.1)

@@ -151,7 +151,7 @@ __device__ __forceinline__ double dawson(double x)
         for (int i = 17; i >= 0; --i) p = __builtin_fma(p, t, q[i]);
         r = p;
     } else {
-        const double inv = 1.0 / ax;          // NaN/inf propagate: D(inf) = 0
+        const double inv = rcp64(ax);         // NaN/inf propagate: D(inf) = 0
         const double s2 = 49.0 * inv * inv;
         double p = dawson::kFar[11];
 #pragma unroll
@@ -275,7 +275,9 @@ template <int VARIANT, bool WRITE_R, int FIT_IM>
 // instead of accumulating; 2 the imaginary model is the sum over all peaks.
 // The 8-peak group keeps 24 per-peak constants live next to the 8-point register block:
 // ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
-__global__ __launch_bounds__(kBlock, (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_OCT) ? 3 : 4) void objective_kernel(
+// With the imaginary part the epilogue also evaluates dispersion lines (Dawson polynomials):
+// 2 waves per SIMD rather than spilling.
+__global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_OCT) ? 3 : 4) void objective_kernel(
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax,
     const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, double wspan, int nseg,

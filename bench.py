@@ -68,6 +68,7 @@ def cpu_baseline(spec, lower, upper, P, budget_s):
     try:
         from oracle import c_oracle
         th = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        th = min(th, 16)     # a one-GPU box's CPU share
         m = min(X.shape[0], max(th, 4 * th))
         t0 = time.perf_counter()
         c_oracle.objective_batch(X[:m], spec["w"], spec["u"], spec["v"], spec["weights"], threads=th)

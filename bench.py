@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--workload", default="C3", help="C3 (default, the metric's config) or C2")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--swarm-per-gpu", type=int, default=0, help="override the workload's swarm size per GPU")
     return ap.parse_args()
 
 
@@ -93,6 +94,8 @@ def main():
 
     cfg = synth.CONFIGS[args.workload]
     S_local, N, P = cfg.S, cfg.N, cfg.P
+    if args.swarm_per_gpu > 0:
+        S_local = args.swarm_per_gpu
     D = 4 + 3 * P
     spec = synth.make_spectrum(N, P, seed=1)
 
@@ -123,8 +126,12 @@ def main():
                      S_local=S_local, seed=1234, minstep=-1.0, minfunc=-1.0)   # never stop while timing
 
     if use_dist and backend == "nccl":
-        # run our launches on torch's current stream so they order with the RCCL all-gather
-        ev.set_stream(torch.cuda.current_stream().cuda_stream)
+        # run our launches and the RCCL all-gather on ONE explicit stream, so they are ordered
+        # without host synchronisation (torch's default stream is the null stream, whose
+        # handle 0 the C-ABI reads as "use the context's own stream": hence a real stream)
+        stream = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(stream)
+        ev.set_stream(stream.cuda_stream)
         send = torch.zeros(D + 1, dtype=torch.float64, device="cuda")
         recv = torch.zeros(world * (D + 1), dtype=torch.float64, device="cuda")
         sw.set_candidate_dev(send.data_ptr())
@@ -225,7 +232,7 @@ def main():
                                    % (cfg.name, P, N, S_local, S_local * world),
                        "peaks": P, "grid": N, "swarm_per_gpu": S_local, "swarm_total": S_local * world,
                        "exchange": "rccl all_gather of %d doubles per generation" % (D + 1) if world > 1 else "none",
-                       "variant": args.variant, "generations_done": st["iteration"]},
+                       "variant": args.variant, "generations_done": st["iteration"], "swarm_best_f": st["fg"]},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "model": "streaming-operand bytes S*(4*N*8)+S*D*8+S*8 per launch (SURVEY 8(d)(i)); "

@@ -46,12 +46,12 @@ enum {
 
 /* Kernel variants (numerics identical to <= 1e-12 relative; for A/B measurement). */
 enum {
-    NMRFIT_VARIANT_DEFAULT = 0,   /* tuned fp64: 8 Lorentzians per reciprocal, Gaussian window skip, LDS-DMA staging */
+    NMRFIT_VARIANT_DEFAULT = 0,   /* tuned fp64: 8 Lorentzians per reciprocal + Gaussian window skip  */
     NMRFIT_VARIANT_BASELINE = 1,  /* plain fp64: IEEE divide + libdevice exp2 per unit, no skipping  */
     NMRFIT_VARIANT_NOSKIP = 2,    /* tuned arithmetic, Gaussian evaluated everywhere                 */
     NMRFIT_VARIANT_SINGLE = 3,    /* one reciprocal per unit + Gaussian window skip                  */
     NMRFIT_VARIANT_QUAD = 4,      /* 4 Lorentzians per reciprocal + Gaussian window skip             */
-    NMRFIT_VARIANT_OCT = 5        /* DEFAULT without the LDS-DMA staging of u/v/weights               */
+    NMRFIT_VARIANT_STAGED = 5     /* DEFAULT + LDS-DMA staging of u/v/weights (pays only for P <= 2)  */
 };
 
 /* What the objective compares besides the real part (nmrfit/equations.py:197-209).

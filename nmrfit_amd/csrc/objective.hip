@@ -32,7 +32,8 @@
 //     seeded once per lane by sincos;
 //   * sum of squares: per-lane fp64 accumulation, then a wave64 shuffle tree.  With one
 //     segment per particle the wave writes f directly; otherwise a tiny second kernel adds
-//     the per-segment partial sums in fixed order (deterministic, no atomics).
+//     the per-chunk sums in grid order (deterministic, no atomics, and the same order whatever
+//     the segmentation: f does not depend on launch geometry or on sharding).
 #include "nmrfit_internal.h"
 
 #define NMRFIT_DAWSON_QUAL __device__ const
@@ -50,6 +51,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kInvPi = 0.31830988618379067154;
 constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
+constexpr int kMaxBlocks = 16;     // blocks per grid (blk_chunks = ceil(n_chunks/16))
 constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
 
 // ---- fp64 helpers (coefficients: tools/gen_poly.py) ---------------------------------------
@@ -85,15 +87,11 @@ __device__ __forceinline__ double exp2_neg(double x)
     return __builtin_amdgcn_ldexp(p, (int)n);
 }
 
-// sin and cos of phi.  |phi| < 1e6: 3-term Cody-Waite reduction by pi/2 (33-bit pieces,
-// k*piece exact for |k| < 2^20) + polynomials on [-pi/4, pi/4] (<= 3e-16); otherwise the
-// libdevice routine (Payne-Hanek).  The branch is wave-uniform in practice (phi = p0 + p1*j/N).
-__device__ __forceinline__ void sincos_fast(double phi, double *s_out, double *c_out)
+// sin and cos of phi by a 3-term Cody-Waite reduction by pi/2 (FMA form: each step is exact
+// before its single rounding, so the reduced angle stays accurate to ~|k| * 1e-26 + 1e-16)
+// + polynomials on [-pi/4, pi/4] (<= 3e-16).  Branch-free; good to ~1e-14 up to |phi| ~ 1e12.
+__device__ __forceinline__ void sincos_cw(double phi, double *s_out, double *c_out)
 {
-    if (!(fabs(phi) < 1.0e6)) {
-        sincos(phi, s_out, c_out);
-        return;
-    }
     const double k = __builtin_rint(phi * 0.6366197723675814);
     double r = __builtin_fma(-k, 1.5707963267341256, phi);
     r = __builtin_fma(-k, 6.077100506303966e-11, r);
@@ -114,11 +112,31 @@ __device__ __forceinline__ void sincos_fast(double phi, double *s_out, double *c
     pc = __builtin_fma(pc, y, 4.1666666666666452389e-2);
     pc = __builtin_fma(pc, y, -0.5);
     const double cs = __builtin_fma(pc, y, 1.0);
-    const int q = (int)k & 3;
+    const int q = (int)(k - 4.0 * __builtin_floor(k * 0.25));   // k mod 4 in {0,1,2,3}, any |k| < 2^52
     const double s1 = (q & 1) ? cs : sn;
     const double c1 = (q & 1) ? sn : cs;
     *s_out = (q & 2) ? -s1 : s1;
     *c_out = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// the same with the libdevice routine (Payne-Hanek) for absurd arguments; not used inside
+// the chunk loop (its register footprint would spill)
+__device__ __forceinline__ void sincos_fast(double phi, double *s_out, double *c_out)
+{
+    if (!(fabs(phi) < 1.0e12)) {
+        sincos(phi, s_out, c_out);
+        return;
+    }
+    sincos_cw(phi, s_out, c_out);
+}
+
+// A value that is the same in every lane (computed from the particle's globals), moved to
+// scalar registers: frees VGPRs in the chunk loop (VALU ops take one SGPR operand each).
+__device__ __forceinline__ double wave_uniform(double x)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double wave_sum(double x)
@@ -258,10 +276,11 @@ __device__ __forceinline__ void gauss_add(const PeakLor *r, const double (&wv)[k
 }
 
 // ---- the kernel ----------------------------------------------------------------------------
-// VARIANT: NMRFIT_VARIANT_DEFAULT  8 Lorentzians per reciprocal + Gaussian window skip + u/v/weights
-//                                  of each chunk prefetched into LDS by global_load_lds (LDS-DMA)
-//          NMRFIT_VARIANT_OCT      the same without the LDS-DMA staging (used when P is so large
-//                                  that the staging buffers would cost a workgroup per CU)
+// VARIANT: NMRFIT_VARIANT_DEFAULT  8 Lorentzians per reciprocal + Gaussian window skip
+//          NMRFIT_VARIANT_STAGED   the same + u/v/weights of each chunk prefetched into LDS by
+//                                  global_load_lds (LDS-DMA) and w of the next chunk into
+//                                  registers: hides the load latency when there are very few
+//                                  peaks (P = 1: 0.54 -> 0.43 ms), neutral to -5 % otherwise
 //          NMRFIT_VARIANT_BASELINE IEEE divide and libdevice exp2 per unit, no skip: the
 //                                  obviously-right form the tuned ones are A/B-checked against
 //          NMRFIT_VARIANT_NOSKIP   8 per reciprocal, Gaussian evaluated everywhere
@@ -277,12 +296,12 @@ template <int VARIANT, bool WRITE_R, int FIT_IM>
 // ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
 // With the imaginary part the epilogue also evaluates dispersion lines (Dawson polynomials):
 // 2 waves per SIMD rather than spilling.
-__global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_OCT) ? 3 : 4) void objective_kernel(
+__global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_STAGED) ? 3 : 4) void objective_kernel(
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax,
     const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, double wspan, int nseg,
-    int64_t seg_len,
-    double *__restrict__ out,       // nseg == 1: f[S];  else partial sums [S*nseg]
+    int64_t seg_len, int blk_chunks,
+    double *__restrict__ out,       // nseg == 1: f[S];  else per-block sums [S * n_blocks] (x2 with FIT_IM)
     double *__restrict__ R_out)     // WRITE_R: residual rows [S*N]
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -291,9 +310,12 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     PeakLor *lor = reinterpret_cast<PeakLor *>(lds_raw) + (size_t)wave * P;
     PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)kWavesPerBlock * P * sizeof(PeakLor)) +
                    (size_t)wave * P;
-    constexpr bool kStage = (VARIANT == NMRFIT_VARIANT_DEFAULT);
-    // kStage: per-wave staging area for one chunk of u, v, weights (3 x 512 doubles = 12 KiB)
-    double *stage = reinterpret_cast<double *>(lds_raw + (size_t)kWavesPerBlock * P * (sizeof(PeakLor) + sizeof(PeakWin))) +
+    constexpr bool kStage = (VARIANT == NMRFIT_VARIANT_STAGED);
+    // per-wave table of block seeds (<= 16 blocks per grid), then (kStage) the per-wave staging
+    // area for one chunk of u, v, weights (3 x 512 doubles = 12 KiB)
+    unsigned char *lds_tail = lds_raw + (((size_t)kWavesPerBlock * P * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15);
+    double2 *seeds = reinterpret_cast<double2 *>(lds_tail) + (size_t)wave * kMaxBlocks;
+    double *stage = reinterpret_cast<double *>(lds_tail + (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2)) +
                     (size_t)wave * (3 * kChunk);
 
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -320,23 +342,45 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
         rec.al = a * r * ihw * kInvPi;                            // a*r*(2/(pi*width))
         rec.ag2 = 2.0 * a * (1.0 - r) * ihw * kSqrtLn2OverPi;     // 2 * a*(1-r)*(2/width)*sqrt(ln2/pi)
         lor[k] = rec;
+        // window bounds in f32, rounded outwards (a slightly wider window is still exact)
         const double gw = kGaussWindow * fabs(width);
-        win[k] = PeakWin{locc - gw, locc + gw};
+        const double wlo = locc - gw, whi = locc + gw;
+        win[k] = PeakWin{(float)(wlo - fabs(wlo) * 1.2e-7 - 1e-37), (float)(whi + fabs(whi) * 1.2e-7 + 1e-37)};
     }
     __syncthreads();
     if (!active) return;
 
     const int64_t j0 = (int64_t)seg * seg_len;
     const int64_t j1 = (j0 + seg_len < N) ? j0 + seg_len : N;
+    const int64_t n_chunks = (N + kChunk - 1) / kChunk;
 
     // phase ramp: z = exp(i*phi_j) for this lane's current point, rho = exp(i*p1*64/N)
-    double zr, zi, rr, ri;
+    // z is re-seeded at the start of every block of blk_chunks chunks as E_b * L_lane with
+    // E_b = exp(i*p1*(b*blk_len)/N) (wave-uniform, tabulated in LDS for this segment's blocks)
+    // and L_lane = exp(i*(p0 + p1*lane/N)): both depend on the GLOBAL block index and the lane
+    // only, never on where the segment starts.
+    double zr = 1.0, zi = 0.0, rr, ri, lr, li;
+    const double invN = 1.0 / (double)N;
+    const int64_t blk_len = (int64_t)blk_chunks * kChunk;
+    sincos_fast((p1 * 64.0) * invN, &ri, &rr);
+    rr = wave_uniform(rr);
+    ri = wave_uniform(ri);
+    sincos_fast(p0 + (p1 * (double)lane) * invN, &li, &lr);
     {
-        const double invN = 1.0 / (double)N;
-        sincos_fast(p0 + (p1 * (double)(j0 + lane)) * invN, &zi, &zr);
-        sincos_fast((p1 * 64.0) * invN, &ri, &rr);
+        const int64_t b0 = j0 / blk_len;
+        const int64_t nb = (j1 - j0 + blk_len - 1) / blk_len;
+        if (lane < nb) {
+            double er, ei;
+            sincos_fast((p1 * (double)((b0 + lane) * blk_len)) * invN, &ei, &er);
+            seeds[lane] = make_double2(er, ei);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
     }
-    const double base = (double)P * yoff;     // yoff is added once per peak (equations.py:147,195)
+    const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
+    double bs = 0.0, bs_im = 0.0;             // per-lane sums of squares of the current block
+    const int64_t blk0 = j0 / blk_len;         // global index of this segment's first block
+    int cib = 0, bidx = 0;                     // chunk within block, block within segment
+    const double base = wave_uniform((double)P * yoff);   // yoff is added once per peak (equations.py:147,195)
     double ss = 0.0, ss_im = 0.0;
     constexpr bool kSkip = (VARIANT != NMRFIT_VARIANT_NOSKIP && VARIANT != NMRFIT_VARIANT_BASELINE);
     constexpr int kGroup = (VARIANT == NMRFIT_VARIANT_SINGLE) ? 1 : (VARIANT == NMRFIT_VARIANT_QUAD) ? 4 : 8;
@@ -353,6 +397,16 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
         // constant offsets from one pointer; the ragged tail is predicated per point.
         const bool full = (jb + kChunk <= j1);   // wave-uniform
         const int64_t jl = jb + lane;
+        // A block = blk_chunks consecutive chunks, a function of N only; segments are whole
+        // blocks.  Everything that carries state from point to point restarts at block
+        // boundaries -- the phase recurrence is re-seeded here, the sums of squares are reduced
+        // at the block's end -- so every value, and hence f, is bit-identical for any
+        // segmentation of the grid and any sharding of the swarm.
+        if (cib == 0) {   // first chunk of a block (segments start on block boundaries)
+            const double2 e = seeds[bidx];
+            zr = __builtin_fma(e.x, lr, -(e.y * li));
+            zi = __builtin_fma(e.x, li, e.y * lr);
+        }
         double wv[kPointsPerLane], acc[kPointsPerLane];
         if (kStage) {
             // w of this chunk was prefetched into registers during the previous epilogue
@@ -407,7 +461,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                     bool h = false;
                     if (kb + lane < P) {
                         const PeakWin wn = win[kb + lane];
-                        h = (mm.y >= wn.lo) && (mm.x <= wn.hi);
+                        h = (mm.y >= (double)wn.lo) && (mm.x <= (double)wn.hi);
                     }
                     hits = __ballot(h);
                 }
@@ -471,7 +525,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
         for (int q = 0; q < kPointsPerLane; ++q) {
             const double vd = __builtin_fma(zr, uq[q], -(zi * vq[q]));   // Re((zr + i zi)(u + i v))
             const double e = tq[q] * (vd - acc[q]);                       // equations.py:202
-            ss = __builtin_fma(e, e, ss);
+            bs = __builtin_fma(e, e, bs);
             if (FIT_IM != 0) {                                            // equations.py:197-199,205-206
                 const double id = __builtin_fma(zr, vq[q], zi * uq[q]);  // Im((zr + i zi)(u + i v))
                 double ifit = 0.0;
@@ -481,50 +535,62 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                     for (int k = 0; k < P; ++k) ifit += dispersion(wv[q], lor[k]);
                 }
                 const double ei = tq[q] * (id - ifit);
-                ss_im = __builtin_fma(ei, ei, ss_im);
+                bs_im = __builtin_fma(ei, ei, bs_im);
             }
             if (WRITE_R && (full || jl + q * kWave < j1)) R_out[particle * N + jl + q * kWave] = e;
             const double nzr = __builtin_fma(zr, rr, -(zi * ri));         // z *= rho
             zi = __builtin_fma(zr, ri, zi * rr);
             zr = nzr;
         }
+        // Canonical summation order: lane sums over its points of the block, wave tree over
+        // lanes, then block sums are added one after another in grid order -- by this wave if
+        // it owns the whole grid, else by finalize_kernel.
+        if (++cib == blk_chunks || jb + kChunk >= j1) {
+            const double cs = wave_sum(bs);
+            const double cs_im = (FIT_IM != 0) ? wave_sum(bs_im) : 0.0;
+            bs = 0.0;
+            bs_im = 0.0;
+            cib = 0;
+            if (nseg == 1) {
+                ss += cs;
+                ss_im += cs_im;
+            } else if (lane == 0) {
+                const int64_t slot = particle * n_blocks + blk0 + bidx;
+                if (FIT_IM == 0) {
+                    out[slot] = cs;
+                } else {
+                    out[2 * slot] = cs;
+                    out[2 * slot + 1] = cs_im;
+                }
+            }
+            ++bidx;
+        }
     }
 
-    ss = wave_sum(ss);
-    if (FIT_IM != 0) ss_im = wave_sum(ss_im);
-    if (lane == 0) {
-        if (FIT_IM == 0) {
-            if (nseg == 1)
-                out[particle] = sqrt(ss / (double)N);
-            else
-                out[particle * nseg + seg] = ss;
-        } else {   // (rmse_real + rmse_imag) / 2, equations.py:205-209
-            if (nseg == 1) {
-                out[particle] = 0.5 * (sqrt(ss / (double)N) + sqrt(ss_im / (double)N));
-            } else {
-                out[(particle * nseg + seg) * 2] = ss;
-                out[(particle * nseg + seg) * 2 + 1] = ss_im;
-            }
-        }
+    if (nseg == 1 && lane == 0) {
+        if (FIT_IM == 0)
+            out[particle] = sqrt(ss / (double)N);
+        else   // (rmse_real + rmse_imag) / 2, equations.py:205-209
+            out[particle] = 0.5 * (sqrt(ss / (double)N) + sqrt(ss_im / (double)N));
     }
 }
 
-// f[i] = sqrt( (sum of the particle's segment partials, in segment order) / N ); with the
-// imaginary part: the mean of the real and imaginary RMSE (two partials per segment)
-__global__ void finalize_kernel(const double *__restrict__ partial, int64_t S, int nseg, int64_t N, int fit_im,
-                                double *__restrict__ f)
+// f[i] = sqrt( (sum of the particle's per-block sums, in grid order) / N ); with the imaginary
+// part: the mean of the real and imaginary RMSE (two sums per block)
+__global__ void finalize_kernel(const double *__restrict__ partial, int64_t S, int64_t n_chunks, int64_t N,
+                                int fit_im, double *__restrict__ f)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     if (fit_im == 0) {
         double ss = 0.0;
-        for (int s = 0; s < nseg; ++s) ss += partial[i * nseg + s];
+        for (int64_t c = 0; c < n_chunks; ++c) ss += partial[i * n_chunks + c];
         f[i] = sqrt(ss / (double)N);
     } else {
         double ss = 0.0, si = 0.0;
-        for (int s = 0; s < nseg; ++s) {
-            ss += partial[(i * nseg + s) * 2];
-            si += partial[(i * nseg + s) * 2 + 1];
+        for (int64_t c = 0; c < n_chunks; ++c) {
+            ss += partial[(i * n_chunks + c) * 2];
+            si += partial[(i * n_chunks + c) * 2 + 1];
         }
         f[i] = 0.5 * (sqrt(ss / (double)N) + sqrt(si / (double)N));
     }
@@ -589,17 +655,17 @@ __global__ void centre_kernel(const double *__restrict__ w, int64_t N, double w0
 
 template <int VARIANT>
 int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *out, double *dR,
-                   int nseg, int64_t seg_len, int64_t blocks, size_t lds, int fit_im)
+                   int nseg, int64_t seg_len, int blk_chunks, int64_t blocks, size_t lds, int fit_im)
 {
 #define NMRFIT_LAUNCH(WR, FI)                                                                                   \
     hipLaunchKernelGGL((objective_kernel<VARIANT, WR, FI>), dim3((unsigned)blocks), dim3(kBlock), lds,         \
                        ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,     \
-                       ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, out, dR)
+                       ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, blk_chunks, out, dR)
     if (dR) {
         NMRFIT_LAUNCH(true, 0);
     } else if (fit_im == 0) {
         NMRFIT_LAUNCH(false, 0);
-    } else if constexpr (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_OCT) {
+    } else if constexpr (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_STAGED) {
         if (fit_im == 1)
             NMRFIT_LAUNCH(false, 1);
         else
@@ -636,13 +702,18 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     const int64_t N = ctx->N;
     // Segmenting: a wave is one (particle, segment) task.  Aim for ~16 tasks per SIMD so the
     // hardware dispatcher load-balances (measured on C3: 4096 one-per-particle waves 1.81 ms,
-    // 16384 waves 1.74 ms); a segment is a whole number of 512-point chunks.  Swarms that
+    // 16384 waves 1.74 ms); a segment is a whole number of blocks.  Swarms that
     // already supply enough waves get nseg = 1 and the wave writes f directly.
     int64_t target_waves = (int64_t)ctx->compute_units * 4 * 16;
     if (ctx->target_waves > 0) target_waves = ctx->target_waves;
-    const int64_t max_seg = (N + kChunk - 1) / kChunk;
-    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(max_seg, (target_waves + S - 1) / S));
-    int64_t seg_len = ((N + nseg - 1) / nseg + kChunk - 1) / kChunk * kChunk;
+    // Blocks: the unit of the canonical summation / phase re-seeding, a function of N only
+    // (at most 16 per grid), so that results do not depend on S or on sharding.
+    const int64_t n_chunks = (N + kChunk - 1) / kChunk;
+    const int blk_chunks = (int)((n_chunks + kMaxBlocks - 1) / kMaxBlocks);
+    const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
+    const int64_t blk_len = (int64_t)blk_chunks * kChunk;
+    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(n_blocks, (target_waves + S - 1) / S));
+    int64_t seg_len = ((n_blocks + nseg - 1) / nseg) * blk_len;
     nseg = (N + seg_len - 1) / seg_len;
     const int64_t waves = S * nseg;
     const int64_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -650,44 +721,45 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         set_error("swarm too large for one launch");
         return NMRFIT_E_INVALID;
     }
-    const size_t lds_recs = (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * (sizeof(PeakLor) + sizeof(PeakWin));
+    const size_t lds_recs = (((size_t)kWavesPerBlock * (size_t)std::max(P, 1) * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
+                            (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2);
     const size_t lds_stage = (size_t)kWavesPerBlock * 3 * kChunk * sizeof(double);
-    // DEFAULT stages u/v/weights through LDS as long as three workgroups still fit in a CU's
-    // 160 KiB (P <= 28); beyond that it runs the unstaged 8-peak kernel.
+    // STAGED needs three workgroups to still fit in a CU's 160 KiB (P <= 27); beyond that it
+    // runs the unstaged kernel.
     int variant = ctx->variant;
-    if (variant == NMRFIT_VARIANT_DEFAULT && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_OCT;
-    const size_t lds = lds_recs + (variant == NMRFIT_VARIANT_DEFAULT ? lds_stage : 0);
+    if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
+    const size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0);
     double *out = df;
     if (nseg > 1) {
-        int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, waves * (fit_im ? 2 : 1));
+        int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));
         if (rc != NMRFIT_OK) return rc;
         out = ctx->d_partial;
     }
     int rc;
     switch (variant) {
         case NMRFIT_VARIANT_BASELINE:
-            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
             break;
         case NMRFIT_VARIANT_NOSKIP:
-            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
             break;
         case NMRFIT_VARIANT_SINGLE:
-            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
             break;
         case NMRFIT_VARIANT_QUAD:
-            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
             break;
-        case NMRFIT_VARIANT_OCT:
-            rc = launch_variant<NMRFIT_VARIANT_OCT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
+        case NMRFIT_VARIANT_STAGED:
+            rc = launch_variant<NMRFIT_VARIANT_STAGED>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
             break;
         default:
-            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
             break;
     }
     if (rc != NMRFIT_OK) return rc;
     if (nseg > 1) {
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream,
-                           ctx->d_partial, S, (int)nseg, N, fit_im, df);
+                           ctx->d_partial, S, n_blocks, N, fit_im, df);
         NMRFIT_HIP(hipGetLastError());
     }
     ctx->last.waves = waves;

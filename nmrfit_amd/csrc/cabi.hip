@@ -55,7 +55,7 @@ static int check_batch(const nmrfit_ctx *ctx, int64_t S, int32_t P, const void *
         return NMRFIT_E_INVALID;
     }
     if (P > kMaxPeaks) {
-        set_error("P exceeds the supported maximum of 1024 peaks");
+        set_error("P exceeds the supported maximum of 1000 peaks");
         return NMRFIT_E_INVALID;
     }
     if (S > 0 && (!X || !out)) {

@@ -14,7 +14,7 @@ constexpr int kWavesPerBlock = 4;    // 256-thread workgroups: one wave per SIMD
 constexpr int kBlock = kWave * kWavesPerBlock;
 constexpr int kPointsPerLane = 8;    // grid points register-blocked per lane per chunk
 constexpr int kChunk = kWave * kPointsPerLane;   // 512 grid points per wave per chunk
-constexpr int kMaxPeaks = 1024;      // LDS: 4 waves x P x 48 B <= 192 KiB -> capped below
+constexpr int kMaxPeaks = 1000;      // LDS: 4 waves x P x 40 B + 1 KiB of block seeds <= 160 KiB
 
 // Per-(particle, peak) constants staged in LDS: see objective.hip.
 struct PeakLor {

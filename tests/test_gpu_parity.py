@@ -207,3 +207,54 @@ def test_objective_is_independent_of_launch_geometry(eq):
     np.testing.assert_array_equal(f_mid, f_big[:3000])
     np.testing.assert_array_equal(f_one, f_big[[0, 1, 2999]])
     np.testing.assert_array_equal(fi_small, fi_big[:7])
+
+
+@pytest.mark.parametrize("P", [9, 64, 65, 130, 1000])
+def test_many_peaks(eq, P):
+    """More peaks than a 64-peak window-mask block (P = 65, 130), group tails of every size and
+    the LDS limit (P = 1000 -> one workgroup per CU)."""
+    from oracle import c_oracle
+    N = 1500 if P < 1000 else 600
+    sp = synth.make_spectrum(N, P, seed=61)
+    X = synth.make_swarm(sp["lower"], sp["upper"], 9, seed=62, x_true=sp["x_true"])
+    ref_R, ref_f = c_oracle.residual_batch(X, sp["w"], sp["u"], sp["v"], sp["weights"], threads=8)
+    with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        for variant in (_cabi.VARIANT_DEFAULT, _cabi.VARIANT_STAGED, _cabi.VARIANT_QUAD):
+            ev.set_variant(variant)
+            _close_f(ev.objective_batch(X), ref_f)
+        ev.set_variant(_cabi.VARIANT_DEFAULT)
+        R = ev.residual_batch(X[:2])
+    np.testing.assert_allclose(R, ref_R[:2], rtol=0, atol=1e-11 * np.abs(ref_R).max())
+    if P == 1000:
+        with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+            with pytest.raises(eq.NmrfitError) as ei:
+                ev.objective_batch(np.zeros((1, 4 + 3 * 1001)))
+            assert ei.value.code == _cabi.E_INVALID
+
+
+def test_non_finite_parameters_do_not_crash(eq):
+    """width = 0, NaN and inf parameters: the reference returns nan/inf (with numpy warnings);
+    the kernel must return a non-finite value for those particles and leave the others alone."""
+    sp = synth.make_spectrum(1024, 3, seed=71)
+    X = synth.make_swarm(sp["lower"], sp["upper"], 6, seed=72, x_true=sp["x_true"])
+    good = X.copy()
+    X[1, 4] = 0.0            # width 0
+    X[2, 5] = np.nan         # loc NaN
+    X[3, 6] = np.inf         # area inf
+    X[4, 0] = np.nan         # p0 NaN
+    with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        f = ev.objective_batch(X)
+        f_good = ev.objective_batch(good)
+    assert np.isfinite(f[[0, 5]]).all() and (f[[0, 5]] == f_good[[0, 5]]).all()
+    assert not np.isfinite(f[1:5]).any()
+
+
+def test_context_churn_does_not_leak(eq):
+    sp = synth.make_spectrum(4096, 2, seed=81)
+    X = synth.make_swarm(sp["lower"], sp["upper"], 8, seed=82)
+    f0 = None
+    for _ in range(200):
+        with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+            f = ev.objective_batch(X)
+        f0 = f if f0 is None else f0
+        np.testing.assert_array_equal(f, f0)

@@ -74,8 +74,17 @@ struct nmrfit_ctx {
 };
 
 namespace nmrfit {
+// When the objective launch leaves per-block sums of squares instead of f (several segments
+// per particle), a caller may take over the final sum (finalize_kernel's job) in its own kernel.
+struct ObjectiveDeferred {
+    bool needed = false;
+    const double *partial = nullptr;   // [S * n_blocks] (x2 with fit_im)
+    int64_t n_blocks = 0;
+    int fit_im = 0;
+};
 // Enqueue the objective (R_out == nullptr) or residual launch on ctx->stream.
-int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR);
+int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR,
+                     ObjectiveDeferred *defer = nullptr);
 int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need);
 // centred grid + per-chunk (min,max) table from the raw device copy of w
 int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw);

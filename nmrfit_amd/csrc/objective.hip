@@ -695,8 +695,10 @@ int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw)
     return NMRFIT_OK;
 }
 
-int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR)
+int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR,
+                     ObjectiveDeferred *defer)
 {
+    if (defer) *defer = ObjectiveDeferred{};
     const int fit_im = dR ? 0 : ctx->fit_im;
     if (S == 0) return NMRFIT_OK;
     const int64_t N = ctx->N;
@@ -757,7 +759,12 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
             break;
     }
     if (rc != NMRFIT_OK) return rc;
-    if (nseg > 1) {
+    if (nseg > 1 && defer) {   // the caller's own kernel adds the per-block sums (pso_tail_kernel)
+        defer->needed = true;
+        defer->partial = ctx->d_partial;
+        defer->n_blocks = n_blocks;
+        defer->fit_im = fit_im;
+    } else if (nseg > 1) {
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream,
                            ctx->d_partial, S, n_blocks, N, fit_im, df);
         NMRFIT_HIP(hipGetLastError());

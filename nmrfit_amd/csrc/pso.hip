@@ -17,10 +17,14 @@
 // counter (generation, dimension, GLOBAL particle index): the swarm's trajectory does not
 // depend on how it is sharded.  After a stop is flagged on the device every later launch is
 // a no-op, so the host may poll the flag every k generations without changing the result.
+// Small swarms (S*D <= 4608, e.g. the reference's default 204 particles x 6 peaks) are launch-bound:
+// for them everything after the objective launch runs in ONE single-workgroup kernel
+// (pso_tail_kernel), two launches per generation instead of six.
 #include "nmrfit_internal.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 struct nmrfit_pso {
@@ -99,17 +103,16 @@ __global__ void pso_init_kernel(int64_t S, int64_t D, int64_t offset, uint64_t s
     if (d == 0) fp[i] = INFINITY;
 }
 
-__global__ void pso_update_kernel(int64_t S, int64_t D, int64_t offset, uint64_t seed, double omega, double phip,
-                                  double phig, const long long *__restrict__ flags, const double *__restrict__ best,
-                                  const double *__restrict__ lb, const double *__restrict__ ub,
-                                  const double *__restrict__ p, double *__restrict__ x, double *__restrict__ v)
+// ---- device bodies (shared by the stand-alone kernels and the fused tail kernel) -----------
+
+// velocity / position update of element idx of the S x D swarm for generation gen
+__device__ __forceinline__ void update_element(int64_t idx, int64_t D, int64_t offset, uint64_t seed, uint32_t gen,
+                                               double omega, double phip, double phig, const double *best,
+                                               const double *lb, const double *ub, const double *p, double *x,
+                                               double *v)
 {
-    if (flags[1] != 0) return;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= S * D) return;
     const int64_t i = idx / D;
     const int d = (int)(idx - i * D);
-    const uint32_t gen = (uint32_t)(flags[0] + 1);
     double rp, rg;
     uniform2(seed, gen, (uint32_t)d, (uint64_t)(offset + i), &rp, &rg);
     const double g = best[2 + d];
@@ -126,29 +129,21 @@ __global__ void pso_update_kernel(int64_t S, int64_t D, int64_t offset, uint64_t
     x[idx] = xn;
 }
 
-// one wave per particle: personal-best update (pyswarm: i_update = fx < fp)
-__global__ void pso_pbest_kernel(int64_t S, int64_t D, const long long *__restrict__ flags,
-                                 const double *__restrict__ x, const double *__restrict__ fx, double *__restrict__ p,
-                                 double *__restrict__ fp)
+// personal best of particle i by one wave (pyswarm: i_update = fx < fp)
+__device__ __forceinline__ void pbest_particle(int64_t i, int lane, int64_t D, const double *x, const double *fx,
+                                               double *p, double *fp)
 {
-    if (flags[1] != 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
-    if (i >= S) return;
     const double f = fx[i];
     if (!(f < fp[i])) return;
     for (int64_t d = lane; d < D; d += kWave) p[i * D + d] = x[i * D + d];
     if (lane == 0) fp[i] = f;
 }
 
-// single block: first index of the minimum of fp (np.argmin) -> candidate record
-__global__ __launch_bounds__(1024) void pso_argmin_kernel(int64_t S, int64_t D, const long long *__restrict__ flags,
-                                                          const double *__restrict__ fp, const double *__restrict__ p,
-                                                          double *__restrict__ cand)
+// block-wide first index of the minimum of fp (np.argmin) -> candidate record.
+// Must be called by every thread of the block (contains a barrier).
+__device__ __forceinline__ void argmin_block(int64_t S, int64_t D, const double *fp, const double *p, double *cand,
+                                             double *s_val, long long *s_idx)
 {
-    if (flags[1] != 0) return;
-    __shared__ double s_val[16];
-    __shared__ long long s_idx[16];
     double best = INFINITY;
     long long bi = 0x7fffffffffffffffLL;
     for (int64_t i = threadIdx.x; i < S; i += blockDim.x) {
@@ -185,20 +180,16 @@ __global__ __launch_bounds__(1024) void pso_argmin_kernel(int64_t S, int64_t D, 
             }
         }
         bi = __shfl(bi, 0, kWave);
-        best = __shfl(best, 0, kWave);
-        if (bi >= S) bi = 0;   // every fp is +inf (or S == 0 handled by the host): np.argmin -> 0
+        if (bi >= S) bi = 0;   // every fp is +inf: np.argmin -> 0
         if (lane == 0) cand[0] = (S > 0) ? fp[bi] : INFINITY;
         for (int64_t d = lane; d < D; d += kWave) cand[1 + d] = (S > 0) ? p[bi * D + d] : 0.0;
     }
 }
 
-// single wave: fold candidates, apply pyswarm's acceptance / stopping rule
-__global__ void pso_apply_kernel(int64_t D, int nranks, int is_init, double minstep, double minfunc,
-                                 const double *__restrict__ cands, long long *__restrict__ flags,
-                                 double *__restrict__ best)
+// one wave: fold the candidate records, apply pyswarm's acceptance / stopping rule
+__device__ __forceinline__ void apply_wave(int lane, int64_t D, int nranks, int is_init, double minstep,
+                                           double minfunc, const double *cands, long long *flags, double *best)
 {
-    if (flags[1] != 0) return;
-    const int lane = threadIdx.x;
     // lowest value wins, lowest rank wins ties (every rank sees the same records)
     int win = 0;
     double fc = cands[0];
@@ -260,6 +251,110 @@ __global__ void pso_apply_kernel(int64_t D, int nranks, int is_init, double mins
     if (lane == 0) flags[0] = flags[0] + 1;
 }
 
+// ---- stand-alone kernels (large swarms: one launch per phase, many workgroups) ------------
+
+__global__ void pso_update_kernel(int64_t S, int64_t D, int64_t offset, uint64_t seed, double omega, double phip,
+                                  double phig, const long long *__restrict__ flags, const double *__restrict__ best,
+                                  const double *__restrict__ lb, const double *__restrict__ ub,
+                                  const double *__restrict__ p, double *__restrict__ x, double *__restrict__ v)
+{
+    if (flags[1] != 0) return;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * D) return;
+    update_element(idx, D, offset, seed, (uint32_t)(flags[0] + 1), omega, phip, phig, best, lb, ub, p, x, v);
+}
+
+__global__ void pso_pbest_kernel(int64_t S, int64_t D, const long long *__restrict__ flags,
+                                 const double *__restrict__ x, const double *__restrict__ fx, double *__restrict__ p,
+                                 double *__restrict__ fp)
+{
+    if (flags[1] != 0) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
+    if (i >= S) return;
+    pbest_particle(i, lane, D, x, fx, p, fp);
+}
+
+__global__ __launch_bounds__(1024) void pso_argmin_kernel(int64_t S, int64_t D, const long long *__restrict__ flags,
+                                                          const double *__restrict__ fp, const double *__restrict__ p,
+                                                          double *__restrict__ cand)
+{
+    if (flags[1] != 0) return;
+    __shared__ double s_val[16];
+    __shared__ long long s_idx[16];
+    argmin_block(S, D, fp, p, cand, s_val, s_idx);
+}
+
+__global__ void pso_apply_kernel(int64_t D, int nranks, int is_init, double minstep, double minfunc,
+                                 const double *__restrict__ cands, long long *__restrict__ flags,
+                                 double *__restrict__ best)
+{
+    if (flags[1] != 0) return;
+    apply_wave(threadIdx.x, D, nranks, is_init, minstep, minfunc, cands, flags, best);
+}
+
+// ---- fused tail for small swarms (S*D <= tail_max_elems()): ONE workgroup runs every phase that
+// follows the objective launch, separated by workgroup barriers (all of it is tiny: a
+// 204 x 22 swarm is 4488 elements).  For a launch-bound small swarm -- the reference's default
+// is 204 particles -- this turns six launches per generation into two.
+enum { kTailFinalize = 1, kTailPbest = 2, kTailArgmin = 4, kTailApply = 8, kTailUpdate = 16 };
+
+struct TailArgs {
+    int64_t S, D, offset, N, n_blocks;
+    uint64_t seed;
+    double omega, phip, phig, minstep, minfunc;
+    int phases, fit_im, nranks, is_init;
+    const double *partial;       // per-block sums of squares from the objective launch (kTailFinalize)
+    const double *lb, *ub;
+    const double *cands;         // candidate records to fold (kTailApply)
+    double *x, *v, *p, *fx, *fp, *cand, *best;
+    long long *flags;
+};
+
+__global__ __launch_bounds__(1024) void pso_tail_kernel(TailArgs a)
+{
+    if (a.flags[1] != 0) return;
+    __shared__ double s_val[16];
+    __shared__ long long s_idx[16];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nw = blockDim.x / kWave;
+    if (a.phases & kTailFinalize) {   // same arithmetic and order as finalize_kernel
+        for (int64_t i = threadIdx.x; i < a.S; i += blockDim.x) {
+            if (a.fit_im == 0) {
+                double ss = 0.0;
+                for (int64_t c = 0; c < a.n_blocks; ++c) ss += a.partial[i * a.n_blocks + c];
+                a.fx[i] = sqrt(ss / (double)a.N);
+            } else {
+                double ss = 0.0, si = 0.0;
+                for (int64_t c = 0; c < a.n_blocks; ++c) {
+                    ss += a.partial[(i * a.n_blocks + c) * 2];
+                    si += a.partial[(i * a.n_blocks + c) * 2 + 1];
+                }
+                a.fx[i] = 0.5 * (sqrt(ss / (double)a.N) + sqrt(si / (double)a.N));
+            }
+        }
+        __syncthreads();
+    }
+    if (a.phases & kTailPbest) {
+        for (int64_t i = wave; i < a.S; i += nw) pbest_particle(i, lane, a.D, a.x, a.fx, a.p, a.fp);
+        __syncthreads();
+    }
+    if (a.phases & kTailArgmin) {
+        argmin_block(a.S, a.D, a.fp, a.p, a.cand, s_val, s_idx);
+        __syncthreads();
+    }
+    if (a.phases & kTailApply) {
+        if (wave == 0) apply_wave(lane, a.D, a.nranks, a.is_init, a.minstep, a.minfunc, a.cands, a.flags, a.best);
+        __syncthreads();
+    }
+    if ((a.phases & kTailUpdate) && a.flags[1] == 0) {
+        const uint32_t gen = (uint32_t)(a.flags[0] + 1);
+        for (int64_t idx = threadIdx.x; idx < a.S * a.D; idx += blockDim.x)
+            update_element(idx, a.D, a.offset, a.seed, gen, a.omega, a.phip, a.phig, a.best, a.lb, a.ub, a.p, a.x,
+                           a.v);
+    }
+}
+
+
 int bind_pso(const nmrfit_pso *pso)
 {
     if (!pso || !pso->ctx) {
@@ -270,10 +365,74 @@ int bind_pso(const nmrfit_pso *pso)
     return NMRFIT_OK;
 }
 
-int evaluate_and_select(nmrfit_pso *pso)
+// One workgroup handles the whole tail only while that is cheaper than five more launches:
+// measured: 50 x 22 elements 14.8 vs 23.7 us per generation, 204 x 22 22.2 vs 24.7, but
+// 204 x 40 41.4 vs 36.3 -- the cross-over is near 5k swarm elements.
+int64_t tail_max_elems()
+{
+    static const int64_t v = [] {
+        const char *e = getenv("NMRFIT_TAIL_MAX_ELEMS");   // tuning knob
+        return e ? (int64_t)atoll(e) : (int64_t)4608;
+    }();
+    return v;
+}
+
+bool small_swarm(const nmrfit_pso *pso) { return pso->S > 0 && pso->S * pso->D <= tail_max_elems(); }
+
+TailArgs tail_args(nmrfit_pso *pso, const ObjectiveDeferred &def, int phases)
+{
+    TailArgs a{};
+    a.S = pso->S;
+    a.D = pso->D;
+    a.offset = pso->offset;
+    a.N = pso->ctx->N;
+    a.n_blocks = def.n_blocks;
+    a.seed = pso->prm.seed;
+    a.omega = pso->prm.omega;
+    a.phip = pso->prm.phip;
+    a.phig = pso->prm.phig;
+    a.minstep = pso->prm.minstep;
+    a.minfunc = pso->prm.minfunc;
+    a.phases = phases;
+    a.fit_im = def.fit_im;
+    a.nranks = 1;
+    a.is_init = 0;
+    a.partial = def.partial;
+    a.lb = pso->d_lb;
+    a.ub = pso->d_ub;
+    a.cands = pso->d_cand;
+    a.x = pso->d_x;
+    a.v = pso->d_v;
+    a.p = pso->d_p;
+    a.fx = pso->d_fx;
+    a.fp = pso->d_fp;
+    a.cand = pso->d_cand;
+    a.best = pso->d_best;
+    a.flags = pso->d_flags;
+    return a;
+}
+
+int launch_tail(nmrfit_pso *pso, const TailArgs &a)
+{
+    hipLaunchKernelGGL(pso_tail_kernel, dim3(1), dim3(1024), 0, pso->ctx->stream, a);
+    NMRFIT_HIP(hipGetLastError());
+    return NMRFIT_OK;
+}
+
+// objective + personal bests + local candidate.  `more` adds phases to the fused tail of a
+// small swarm (kTailApply / kTailUpdate, used by nmrfit_pso_run); ignored for large swarms.
+int evaluate_and_select(nmrfit_pso *pso, int more = 0, int is_init = 0)
 {
     nmrfit_ctx *ctx = pso->ctx;
     const int64_t S = pso->S, D = pso->D;
+    if (small_swarm(pso)) {
+        ObjectiveDeferred def;
+        int rc = launch_objective(ctx, S, pso->P, pso->d_x, pso->d_fx, nullptr, &def);
+        if (rc != NMRFIT_OK) return rc;
+        TailArgs a = tail_args(pso, def, (def.needed ? kTailFinalize : 0) | kTailPbest | kTailArgmin | more);
+        a.is_init = is_init;
+        return launch_tail(pso, a);
+    }
     int rc = launch_objective(ctx, S, pso->P, pso->d_x, pso->d_fx, nullptr);
     if (rc != NMRFIT_OK) return rc;
     if (S > 0) {
@@ -497,9 +656,27 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
     if (!pso->seeded) {
         if ((rc = nmrfit_pso_apply_global_dev(pso, pso->d_cand, 1)) != NMRFIT_OK) return rc;
     }
+    const bool fused = small_swarm(pso);
+    if (fused && maxiter > 0) {
+        // generation 1's positions; from here on a generation is two launches: the objective
+        // and one single-workgroup tail that also folds the candidate, applies the stopping
+        // rule and prepares the next generation's positions
+        const int64_t n = pso->S * pso->D;
+        hipLaunchKernelGGL(pso_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pso->ctx->stream, pso->S,
+                           pso->D, pso->offset, pso->prm.seed, pso->prm.omega, pso->prm.phip, pso->prm.phig,
+                           pso->d_flags, pso->d_best, pso->d_lb, pso->d_ub, pso->d_p, pso->d_x, pso->d_v);
+        NMRFIT_HIP(hipGetLastError());
+    }
     for (int64_t it = 1; it <= maxiter; ++it) {
-        if ((rc = nmrfit_pso_step_local(pso)) != NMRFIT_OK) return rc;
-        if ((rc = nmrfit_pso_apply_global_dev(pso, pso->d_cand, 1)) != NMRFIT_OK) return rc;
+        if (fused) {
+            // no position update after the last generation: the state then is what the
+            // unfused sequence leaves behind
+            rc = evaluate_and_select(pso, kTailApply | (it < maxiter ? kTailUpdate : 0));
+            if (rc != NMRFIT_OK) return rc;
+        } else {
+            if ((rc = nmrfit_pso_step_local(pso)) != NMRFIT_OK) return rc;
+            if ((rc = nmrfit_pso_apply_global_dev(pso, pso->d_cand, 1)) != NMRFIT_OK) return rc;
+        }
         if (it % check_every == 0 || it == maxiter) {
             int32_t stop = 0;
             if ((rc = nmrfit_pso_status(pso, nullptr, &stop, nullptr)) != NMRFIT_OK) return rc;

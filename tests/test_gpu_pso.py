@@ -20,12 +20,13 @@ def problem():
     ev.close()
 
 
-def test_device_swarm_matches_numpy_mirror_bitwise(problem):
+@pytest.mark.parametrize("S", [204, 700])     # 204 x 13: fused single-workgroup tail; 700 x 13: one kernel per phase
+def test_device_swarm_matches_numpy_mirror_bitwise(problem, S):
     """Same Philox stream, same IEEE update arithmetic (no FMA contraction in the swarm
     kernels), same objective values (the mirror evaluates through the same GPU kernel with
     the same launch geometry) => x, v, p, fp, g identical bit for bit after 10 generations."""
     sp, ev = problem
-    S, seed = 204, 77
+    seed = 77
     dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
     host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
     dev.init()
@@ -95,7 +96,7 @@ def test_stop_flag_on_device_and_run_polling(problem):
     sp, ev = problem
     res = []
     for ce in (1, 7, 64):
-        sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 64, seed=3)
+        sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 64, seed=3)      # fused generation loop
         sw.run(400, check_every=ce)
         st = sw.status()
         res.append((st["stop"], st["iteration"], sw.best()))
@@ -110,6 +111,17 @@ def test_stop_flag_on_device_and_run_polling(problem):
     xh, fh = pso.run_sharded(host, pso.LocalExchange(), 400)
     assert host.stop == res[0][0] and host.iteration == res[0][1]
     np.testing.assert_array_equal(xh, res[0][2][0])
+    # the same for a swarm large enough to take the unfused loop
+    sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 600, seed=4)
+    sw.run(300, check_every=5)
+    st = sw.status()
+    host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], 600, seed=4)
+    xh, fh = pso.run_sharded(host, pso.LocalExchange(), 300)
+    assert (st["stop"], st["iteration"]) == (host.stop, host.iteration)
+    xb, fb = sw.best()
+    np.testing.assert_array_equal(xb, xh)
+    assert fb == fh
+    sw.close()
 
 
 def test_bounds_validation(problem):

@@ -51,7 +51,10 @@ enum {
     NMRFIT_VARIANT_NOSKIP = 2,    /* tuned arithmetic, Gaussian evaluated everywhere                 */
     NMRFIT_VARIANT_SINGLE = 3,    /* one reciprocal per unit + Gaussian window skip                  */
     NMRFIT_VARIANT_QUAD = 4,      /* 4 Lorentzians per reciprocal + Gaussian window skip             */
-    NMRFIT_VARIANT_STAGED = 5     /* DEFAULT + LDS-DMA staging of u/v/weights (pays only for P <= 2)  */
+    NMRFIT_VARIANT_STAGED = 5,    /* DEFAULT + LDS-DMA staging of u/v/weights (pays only for P <= 2)  */
+    NMRFIT_VARIANT_FARFIELD = 6   /* opt-in: Lorentzian tails of distant peaks through one shared
+                                     Taylor expansion per 512-point chunk (truncation <= 1e-16 of each
+                                     term); not the default because it changes the per-unit work      */
 };
 
 /* What the objective compares besides the real part (nmrfit/equations.py:197-209).

@@ -16,7 +16,7 @@ BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4, -5
 FIT_IM_OFF, FIT_IM_REFERENCE, FIT_IM_SUM = 0, 1, 2
-VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED = 0, 1, 2, 3, 4, 5
+VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED, VARIANT_FARFIELD = 0, 1, 2, 3, 4, 5, 6
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_void_pp = ctypes.POINTER(ctypes.c_void_p)

@@ -246,7 +246,7 @@ int nmrfit_ctx_set_stream(nmrfit_ctx *ctx, void *hip_stream)
 
 int nmrfit_ctx_set_variant(nmrfit_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > NMRFIT_VARIANT_STAGED) {
+    if (!ctx || variant < 0 || variant > NMRFIT_VARIANT_FARFIELD) {
         set_error("bad context or variant");
         return NMRFIT_E_INVALID;
     }

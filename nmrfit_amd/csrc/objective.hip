@@ -51,6 +51,8 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kInvPi = 0.31830988618379067154;
 constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
+constexpr int kFarTerms = 16;      // Taylor terms of the far-field expansion (rho <= 0.1 -> 1e-16)
+constexpr int kFarPad = 65;        // row stride (doubles) of the per-wave coefficient scratch in LDS
 constexpr int kMaxBlocks = 16;     // blocks per grid (blk_chunks = ceil(n_chunks/16))
 constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
 
@@ -286,6 +288,8 @@ __device__ __forceinline__ void gauss_add(const PeakLor *r, const double (&wv)[k
 //          NMRFIT_VARIANT_NOSKIP   8 per reciprocal, Gaussian evaluated everywhere
 //          NMRFIT_VARIANT_SINGLE   one reciprocal per unit + Gaussian window skip
 //          NMRFIT_VARIANT_QUAD     4 per reciprocal + Gaussian window skip
+//          NMRFIT_VARIANT_FARFIELD Lorentzian tails of distant peaks through a shared Taylor
+//                                  expansion per chunk (opt-in; see the chunk loop)
 // Wave g = blockIdx.x*4 + wave  ->  particle g / nseg, segment g % nseg;
 // a segment is seg_len (multiple of 512) consecutive grid points.
 template <int VARIANT, bool WRITE_R, int FIT_IM>
@@ -296,7 +300,7 @@ template <int VARIANT, bool WRITE_R, int FIT_IM>
 // ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
 // With the imaginary part the epilogue also evaluates dispersion lines (Dawson polynomials):
 // 2 waves per SIMD rather than spilling.
-__global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_STAGED) ? 3 : 4) void objective_kernel(
+__global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_STAGED || VARIANT == NMRFIT_VARIANT_FARFIELD) ? 3 : 4) void objective_kernel(
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax,
     const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, double wspan, int nseg,
@@ -317,6 +321,10 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     double2 *seeds = reinterpret_cast<double2 *>(lds_tail) + (size_t)wave * kMaxBlocks;
     double *stage = reinterpret_cast<double *>(lds_tail + (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2)) +
                     (size_t)wave * (3 * kChunk);
+    // FARFIELD: per-wave scratch [kFarTerms][kFarPad] for the cross-peak coefficient sums
+    // (shares the offset of `stage`; the two variants are exclusive)
+    double *ffs = reinterpret_cast<double *>(lds_tail + (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2)) +
+                  (size_t)wave * (kFarTerms * kFarPad);
 
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const bool active = g < S * nseg;
@@ -383,6 +391,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     const double base = wave_uniform((double)P * yoff);   // yoff is added once per peak (equations.py:147,195)
     double ss = 0.0, ss_im = 0.0;
     constexpr bool kSkip = (VARIANT != NMRFIT_VARIANT_NOSKIP && VARIANT != NMRFIT_VARIANT_BASELINE);
+    constexpr bool kFar = (VARIANT == NMRFIT_VARIANT_FARFIELD);
     constexpr int kGroup = (VARIANT == NMRFIT_VARIANT_SINGLE) ? 1 : (VARIANT == NMRFIT_VARIANT_QUAD) ? 4 : 8;
 
     double wnext[kPointsPerLane];
@@ -452,6 +461,82 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
         } else {
             double2 mm = make_double2(0.0, 0.0);
             if (kSkip) mm = chunk_minmax[jb / kChunk];
+            if constexpr (kFar) {
+                // ---- far-field form --------------------------------------------------------
+                // For a peak whose centre is far from this chunk (rho = chunk half-span /
+                // |distance to the pole of 1/(1+t^2)| <= 0.1) the Lorentzian is summed through a
+                // Taylor expansion about the chunk centre: 1/(1+(tc+tau)^2) = Im sum_n
+                // (-tau)^n q^(n+1), q = 1/(tc - i).  The expansions of ALL far peaks share one
+                // set of kFarTerms coefficients in u = (w - centre)/half-span, so their cost per
+                // point is one degree-15 Horner instead of ~6 ops per peak; truncation
+                // <= 0.1^16 of each peak's term.  Near peaks are evaluated directly.
+                const double wcen = wave_uniform(0.5 * (mm.x + mm.y));
+                const double hw = wave_uniform(0.5 * (mm.y - mm.x));
+                double csum = 0.0;    // lane l: coefficient of order l >> 2 (all 4 lanes of a quad)
+                for (int kb = 0; kb < P; kb += kWave) {
+                    const int k = kb + lane;
+                    const bool act = k < P;
+                    bool far = false, ghit = false;
+                    double zr = 0.0, zi = 0.0, mr = 0.0, mi = 0.0, al = 0.0;
+                    if (act) {
+                        const PeakLor rec = lor[k];
+                        const PeakWin wn = win[k];
+                        ghit = (mm.y >= (double)wn.lo) && (mm.x <= (double)wn.hi);
+                        const double tc = __builtin_fma(wcen, rec.ihw, rec.c);
+                        const double hk = hw * rec.ihw;
+                        const double den = __builtin_fma(tc, tc, 1.0);
+                        far = den >= 100.0 * hk * hk;            // rho^2 <= 0.01 (false for NaN)
+                        const double rq = rcp64(den);
+                        zr = tc * rq;                             // q = (tc + i)/(tc^2 + 1)
+                        zi = rq;
+                        mr = -hk * zr;                            // multiplier -hk*q per order
+                        mi = -hk * zi;
+                        al = rec.al;
+                    }
+                    const unsigned long long farmask = __ballot(far);
+                    const unsigned long long nearmask = __ballot(act && !far);
+                    const unsigned long long hits = __ballot(ghit);
+                    if (farmask) {
+#pragma unroll
+                        for (int n = 0; n < kFarTerms; ++n) {
+                            ffs[n * kFarPad + lane] = far ? al * zi : 0.0;
+                            const double nz = __builtin_fma(zr, mr, -(zi * mi));
+                            zi = __builtin_fma(zr, mi, zi * mr);
+                            zr = nz;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
+                        // lane l sums order l>>2 over peaks 16*(l&3) .. +15, then the quad combines
+                        const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 16;
+                        double part = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) part += row[j];
+                        part += __shfl_xor(part, 1, kWave);
+                        part += __shfl_xor(part, 2, kWave);
+                        csum += part;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites
+                    }
+                    for (unsigned long long m = nearmask; m; m &= m - 1)
+                        lorentz_group<1>(lor + kb + __builtin_ctzll(m), wv, acc);
+                    for (unsigned long long m = hits; m; m &= m - 1)
+                        gauss_add(lor + kb + __builtin_ctzll(m), wv, acc);
+                }
+                // broadcast the kFarTerms sums through LDS and evaluate them at the lane's points
+                if ((lane & 3) == 0) ffs[lane >> 2] = csum;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                double cf[kFarTerms];
+#pragma unroll
+                for (int n = 0; n < kFarTerms; ++n) cf[n] = ffs[n];
+                const double ihwc = (hw > 0.0) ? rcp64(hw) : 0.0;
+#pragma unroll
+                for (int q = 0; q < kPointsPerLane; ++q) {
+                    const double uu = (wv[q] - wcen) * ihwc;
+                    double pz = cf[kFarTerms - 1];
+#pragma unroll
+                    for (int n = kFarTerms - 2; n >= 0; --n) pz = __builtin_fma(pz, uu, cf[n]);
+                    acc[q] += pz;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else
             for (int kb = 0; kb < P; kb += kWave) {
                 const int kend = (P < kb + kWave) ? P : kb + kWave;
                 // which of peaks kb..kb+63 have their Gaussian window inside this chunk's
@@ -715,6 +800,13 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
     const int64_t blk_len = (int64_t)blk_chunks * kChunk;
     int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(n_blocks, (target_waves + S - 1) / S));
+    // Short grids: a wave's prologue (parameter staging, phase seeds) costs about as much as a
+    // chunk or two, so prefer >= 4 chunks per wave as long as two waves per SIMD remain
+    // (measured on C2, S=1024 N=4096: 8 segments 26.2 us, 2 segments 22.2 us).
+    if (ctx->target_waves == 0) {
+        const int64_t simds = (int64_t)ctx->compute_units * 4;
+        while (nseg > 1 && n_chunks / nseg < 4 && S * ((nseg + 1) / 2) >= 2 * simds) nseg = (nseg + 1) / 2;
+    }
     int64_t seg_len = ((n_blocks + nseg - 1) / nseg) * blk_len;
     nseg = (N + seg_len - 1) / seg_len;
     const int64_t waves = S * nseg;
@@ -730,7 +822,9 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     // runs the unstaged kernel.
     int variant = ctx->variant;
     if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
-    const size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0);
+    const size_t lds_far = (size_t)kWavesPerBlock * kFarTerms * kFarPad * sizeof(double);
+    const size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
+                       (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : 0);
     double *out = df;
     if (nseg > 1) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));
@@ -750,6 +844,9 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
             break;
         case NMRFIT_VARIANT_QUAD:
             rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
+            break;
+        case NMRFIT_VARIANT_FARFIELD:
+            rc = launch_variant<NMRFIT_VARIANT_FARFIELD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
             break;
         case NMRFIT_VARIANT_STAGED:
             rc = launch_variant<NMRFIT_VARIANT_STAGED>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);

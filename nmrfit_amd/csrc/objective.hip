@@ -52,7 +52,9 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kInvPi = 0.31830988618379067154;
 constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 constexpr int kFarTerms = 16;      // Taylor terms of the far-field expansion (rho <= 0.1 -> 1e-16)
-constexpr int kFarPad = 65;        // row stride (doubles) of the per-wave coefficient scratch in LDS
+constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coefficient scratch in LDS:
+                                   // lane l sits at column l + l/16, which makes the transposed
+                                   // quarter-row reads below bank-conflict free
 constexpr int kMaxBlocks = 16;     // blocks per grid (blk_chunks = ceil(n_chunks/16))
 constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
 
@@ -499,14 +501,14 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                     if (farmask) {
 #pragma unroll
                         for (int n = 0; n < kFarTerms; ++n) {
-                            ffs[n * kFarPad + lane] = far ? al * zi : 0.0;
+                            ffs[n * kFarPad + lane + (lane >> 4)] = far ? al * zi : 0.0;
                             const double nz = __builtin_fma(zr, mr, -(zi * mi));
                             zi = __builtin_fma(zr, mi, zi * mr);
                             zr = nz;
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
                         // lane l sums order l>>2 over peaks 16*(l&3) .. +15, then the quad combines
-                        const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 16;
+                        const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
                         double part = 0.0;
 #pragma unroll
                         for (int j = 0; j < 16; ++j) part += row[j];

@@ -217,6 +217,39 @@ def main():
                     "note": "NMRFIT_VARIANT_FARFIELD: Lorentzian tails of distant peaks through one shared Taylor "
                             "expansion per 512-point chunk (fp64, truncation <= 1e-16 per term); opt-in, not the "
                             "configuration `value` is measured on"}
+    # the other single-GPU configs of BASELINE.json, kernel-only (HIP events), for reference
+    others = None
+    if rank == 0 and world == 1 and args.workload == "C3":
+        others = {}
+        for name in ("C2", "C5"):
+            c = synth.CONFIGS[name]
+            sp2 = synth.make_spectrum(c.N, c.P, seed=1)
+            if name == "C5":      # D+1 rows of a forward-difference Jacobian, residual vectors out
+                X2, _ = synth.jacobian_rows(synth.make_swarm(sp2["lower"], sp2["upper"], 2, seed=4)[1])
+            else:
+                X2 = synth.make_swarm(sp2["lower"], sp2["upper"], c.S, seed=2, x_true=sp2["x_true"])
+            with Evaluator(sp2["w"], sp2["u"], sp2["v"], sp2["weights"], device=device) as ev2:
+                B, D2 = X2.shape
+                dX2 = ev2.dev_alloc(X2.nbytes)
+                df2 = ev2.dev_alloc(B * 8)
+                dR2 = ev2.dev_alloc(B * c.N * 8) if name == "C5" else None
+                ev2.upload(dX2, X2)
+                run = ((lambda: ev2.residual_batch_dev(B, c.P, dX2, dR2, df2)) if name == "C5"
+                       else (lambda: ev2.objective_batch_dev(B, c.P, dX2, df2)))
+                for _ in range(5):
+                    run()
+                ev2.synchronize()
+                ev2.timer_begin()
+                for _ in range(50):
+                    run()
+                ms2 = ev2.timer_end() / 50
+                others[name] = {"shape": {"rows": B, "grid": c.N, "peaks": c.P}, "kernel_ms": ms2,
+                                "units_per_s": float(B) * c.N * c.P / (ms2 * 1e-3),
+                                "kind": "residual_batch (R rows written)" if name == "C5" else "objective_batch"}
+                ev2.dev_free(dX2)
+                ev2.dev_free(df2)
+                if dR2 is not None:
+                    ev2.dev_free(dR2)
     # the host-pointer entry point (X uploaded, f downloaded every call): the PCIe-inclusive
     # rate, reported beside the resident one -- never as `value`
     host_ms = None
@@ -267,6 +300,8 @@ def main():
         }
         if farfield is not None:
             line["farfield_variant"] = farfield
+        if others:
+            line["other_configs"] = others
         if host_ms is not None:
             line["host_pointer_call"] = {"ms": host_ms, "units_per_s": units_launch / (host_ms * 1e-3),
                                          "note": "nmrfit_objective_batch with host X/f (H2D + kernel + D2H per call)"}

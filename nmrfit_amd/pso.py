@@ -223,6 +223,12 @@ class DeviceSwarm:
                                                 ctypes.byref(self._h)))
 
     def close(self):
+        if getattr(self, "_d_gather", None) is not None:
+            try:
+                self.ev.dev_free(self._d_gather)
+            except Exception:
+                pass
+            self._d_gather = None
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.nmrfit_pso_destroy(self._h)
             self._h = ctypes.c_void_p()
@@ -257,6 +263,8 @@ class DeviceSwarm:
         """Host-array form: uploads the gathered records (used with gloo / tests)."""
         cands = _cabi.f64(cands).reshape(-1, self.D + 1)
         if getattr(self, "_d_gather", None) is None or self._gather_rows < cands.shape[0]:
+            if getattr(self, "_d_gather", None) is not None:
+                self.ev.dev_free(self._d_gather)
             self._d_gather = self.ev.dev_alloc(cands.nbytes)
             self._gather_rows = cands.shape[0]
         self.ev.upload(self._d_gather, cands)

@@ -21,19 +21,20 @@
 //     t = (w-loc)*(2/width), s = 1 + t^2:  L = (2/(pi*width))/s  and
 //     exp(-((w-loc)/(width/(2 sqrt(ln2))))^2) = 2^(-t^2) = 2*2^(-s), so one fma chain per
 //     point and peak: t = fma(wc, ihw, c); s = fma(t, t, 1); acc += AL*rcp(s) + AG2*exp2(-s);
-//   * the Lorentzians of four peaks share one reciprocal (common denominator s0 s1 s2 s3);
-//     rcp: v_rcp_f64 + one Newton step (relative error 2.2e-15);
+//   * the Lorentzians of eight peaks share one reciprocal (common denominator, combined up
+//     a binary tree of (numerator, denominator) pairs); rcp: v_rcp_f64 + one Newton step
+//     (relative error 2.2e-15);
 //     exp2(-s): round-to-nearest split + degree-11 polynomial + v_ldexp_f64 (<= 3e-16);
 //   * the Gaussian term is < 2^-64 of its amplitude once |w-loc| > 3.97*width; a wave
 //     skips it for a whole 512-point chunk when the chunk's [min,max] of w (precomputed
 //     at context creation) misses that window -- a wave-uniform branch, exact to fp64
 //     rounding, and the common case (a line is ~100x narrower than the spectrum);
-//   * the phase ramp is a complex rotation recurrence z <- z*rho (4 fp64 ops per point)
-//     seeded once per lane by sincos;
-//   * sum of squares: per-lane fp64 accumulation, then a wave64 shuffle tree.  With one
-//     segment per particle the wave writes f directly; otherwise a tiny second kernel adds
-//     the per-chunk sums in grid order (deterministic, no atomics, and the same order whatever
-//     the segmentation: f does not depend on launch geometry or on sharding).
+//   * the phase ramp is a complex rotation recurrence z <- z*rho (4 fp64 ops per point),
+//     re-seeded at the start of each of <= 16 blocks of the grid;
+//   * sum of squares: per-lane fp64 accumulation over a block, then a wave64 shuffle tree.
+//     With one segment per particle the wave writes f directly; otherwise a tiny second
+//     kernel adds the per-block sums in grid order (deterministic, no atomics, and the same
+//     order whatever the segmentation: f does not depend on launch geometry or on sharding).
 #include "nmrfit_internal.h"
 
 #define NMRFIT_DAWSON_QUAL __device__ const

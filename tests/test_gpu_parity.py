@@ -219,7 +219,7 @@ def test_many_peaks(eq, P):
     X = synth.make_swarm(sp["lower"], sp["upper"], 9, seed=62, x_true=sp["x_true"])
     ref_R, ref_f = c_oracle.residual_batch(X, sp["w"], sp["u"], sp["v"], sp["weights"], threads=8)
     with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
-        for variant in (_cabi.VARIANT_DEFAULT, _cabi.VARIANT_STAGED, _cabi.VARIANT_QUAD):
+        for variant in (_cabi.VARIANT_DEFAULT, _cabi.VARIANT_STAGED, _cabi.VARIANT_QUAD, _cabi.VARIANT_FARFIELD):
             ev.set_variant(variant)
             _close_f(ev.objective_batch(X), ref_f)
         ev.set_variant(_cabi.VARIANT_DEFAULT)
@@ -243,10 +243,12 @@ def test_non_finite_parameters_do_not_crash(eq):
     X[3, 6] = np.inf         # area inf
     X[4, 0] = np.nan         # p0 NaN
     with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
-        f = ev.objective_batch(X)
-        f_good = ev.objective_batch(good)
-    assert np.isfinite(f[[0, 5]]).all() and (f[[0, 5]] == f_good[[0, 5]]).all()
-    assert not np.isfinite(f[1:5]).any()
+        for variant in VARIANTS:
+            ev.set_variant(variant)
+            f = ev.objective_batch(X)
+            f_good = ev.objective_batch(good)
+            assert np.isfinite(f[[0, 5]]).all() and (f[[0, 5]] == f_good[[0, 5]]).all(), variant
+            assert not np.isfinite(f[1:5]).any(), variant
 
 
 def test_context_churn_does_not_leak(eq):

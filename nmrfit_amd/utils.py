@@ -46,6 +46,32 @@ def compute_weights(w, peaks, expon=0.5):
     return equations.laplace1d(weights)
 
 
+def generate_solution_bounds(peaks, p0=0.0, p1=0.0, force_p0=False, force_p1=False):
+    """Parameter box for a fit, as Data.generate_solution_bounds builds it
+    (nmrfit/containers.py:175-217): phases in [-pi, pi] (or the estimate +- 0.001 when forced),
+    r in [0, 1], yoff in [-0.01, 0.01], then per peak width in [0.5, 1.5]*width,
+    loc - 0.1*(loc - bounds[0|1]) and area in [0.5, 1.5]*area.  Returns (lower, upper) lists."""
+    lower, upper = [], []
+    if force_p0 is True:
+        upper.append(p0 + 0.001)
+        lower.append(p0 - 0.001)
+    else:
+        upper.append(np.pi)
+        lower.append(-np.pi)
+    if force_p1 is True:
+        upper.append(p1 + 0.001)
+        lower.append(p1 - 0.001)
+    else:
+        upper.append(np.pi)
+        lower.append(-np.pi)
+    upper.extend([1.0, 0.01])
+    lower.extend([0.0, -0.01])
+    for p in peaks:
+        lower.extend([p.width * 0.5, p.loc - 0.1 * (p.loc - p.bounds[0]), p.area * 0.5])
+        upper.extend([p.width * 1.5, p.loc - 0.1 * (p.loc - p.bounds[1]), p.area * 1.5])
+    return lower, upper
+
+
 class FitUtility:
     """Interface used to perform a fit of the data (reference: nmrfit/utils.py:96)."""
 

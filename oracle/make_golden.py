@@ -216,6 +216,24 @@ def main():
         print("compute_weights fixture written (min %.4f max %.4f)" % (wts.min(), wts.max()))
     np.savez_compressed(os.path.join(OUT, "weights.npz"), **d)
 
+    # --- 6b. Data.generate_solution_bounds (containers.py:175-217), loaded like utils.py ---------
+    try:
+        spec = importlib.util.spec_from_file_location("nmrfit.containers", os.path.join(REF, "containers.py"))
+        cm = importlib.util.module_from_spec(spec)
+        sys.modules["nmrfit.containers"] = cm
+        spec.loader.exec_module(cm)
+        sp = synth.make_spectrum(4096, 6, seed=1)
+        dat = cm.Data(sp["w"], sp["u"], sp["v"])
+        dat.peaks = sp["peaks"]
+        dat.p0, dat.p1 = 0.31, -0.17
+        lo1, up1 = dat.generate_solution_bounds()
+        lo2, up2 = dat.generate_solution_bounds(force_p0=True, force_p1=True)
+        np.savez_compressed(os.path.join(OUT, "bounds.npz"), seed=1, p0=0.31, p1=-0.17, lower=np.array(lo1),
+                            upper=np.array(up1), lower_forced=np.array(lo2), upper_forced=np.array(up2))
+        print("bounds fixture written")
+    except Exception as e:
+        print("containers.py not loadable (%s: %s); bounds fixture skipped" % (type(e).__name__, e))
+
     # --- 7. Kramers-Kronig path: fit_im=True objective and generate_result pieces ---------------
     # (reference: scipy quad per grid point, ~4 ms each -> small grids only)
     sp = synth.make_spectrum(160, 3, seed=7, physical=True)

@@ -65,3 +65,19 @@ def test_fit_without_a_gpu_raises():
     assert equations.fit_im_mode("sum") == 2
     with pytest.raises(ValueError):
         equations.fit_im_mode("both")
+
+
+def test_generate_solution_bounds_matches_reference_golden(golden_dir):
+    """Data.generate_solution_bounds (containers.py:175-217), fixture produced by the reference."""
+    g = np.load(os.path.join(golden_dir, "bounds.npz"))
+    sp = synth.make_spectrum(4096, 6, seed=int(g["seed"]))
+    lo, up = utils.generate_solution_bounds(sp["peaks"])
+    np.testing.assert_array_equal(lo, g["lower"])
+    np.testing.assert_array_equal(up, g["upper"])
+    lo, up = utils.generate_solution_bounds(sp["peaks"], p0=float(g["p0"]), p1=float(g["p1"]), force_p0=True,
+                                            force_p1=True)
+    np.testing.assert_array_equal(lo, g["lower_forced"])
+    np.testing.assert_array_equal(up, g["upper_forced"])
+    # the synthetic generator's box is the same box
+    np.testing.assert_allclose(sp["lower"], g["lower"], rtol=1e-15)
+    np.testing.assert_allclose(sp["upper"], g["upper"], rtol=1e-15)

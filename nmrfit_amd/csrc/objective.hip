@@ -553,19 +553,13 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                     }
                     hits = __ballot(h);
                 }
+                // Lorentzians first, in straight-line groups; then the (few) Gaussians whose
+                // window touches this chunk, one scalar loop over the set bits of the mask
                 int k = kb;
-                for (; k + kGroup <= kend; k += kGroup) {
-                    lorentz_group<kGroup>(lor + k, wv, acc);
-                    unsigned hg = (unsigned)(hits >> (k - kb)) & ((1u << kGroup) - 1u);
-                    for (int g = 0; hg; ++g, hg >>= 1)
-                        if (hg & 1u) gauss_add(lor + k + g, wv, acc);
-                }
-                if (k < kend) {   // fewer than kGroup peaks left: one smaller group
-                    lorentz_tail<kGroup>(kend - k, lor + k, wv, acc);
-                    unsigned hg = (unsigned)(hits >> (k - kb)) & ((1u << (kend - k)) - 1u);
-                    for (int g = 0; hg; ++g, hg >>= 1)
-                        if (hg & 1u) gauss_add(lor + k + g, wv, acc);
-                }
+                for (; k + kGroup <= kend; k += kGroup) lorentz_group<kGroup>(lor + k, wv, acc);
+                if (k < kend) lorentz_tail<kGroup>(kend - k, lor + k, wv, acc);   // one smaller group
+                if (kend - kb < kWave) hits &= (1ull << (kend - kb)) - 1ull;
+                for (unsigned long long m = hits; m; m &= m - 1) gauss_add(lor + kb + __builtin_ctzll(m), wv, acc);
             }
         }
 

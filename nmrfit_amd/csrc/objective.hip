@@ -236,9 +236,9 @@ __device__ __forceinline__ void lorentz_group(const PeakLor *r, const double (&w
         c[g] = r[g].c;
         a[g] = r[g].al;
     }
-    // how many points the scheduler may interleave: all 8 at once needs > 128 VGPRs (spills),
-    // which costs more than the extra latency hiding buys
-    constexpr int kInterleave = (G <= 4) ? 4 : 1;
+    // how many points the scheduler may interleave (a scheduling fence every kInterleave
+    // points): measured on C3 with 8-peak groups 1 -> 1.545 ms, 2 or 4 -> 1.464 ms, 8 -> 1.493 ms
+    constexpr int kInterleave = 4;
 #pragma unroll
     for (int q = 0; q < kPointsPerLane; ++q) {
         double s[G];

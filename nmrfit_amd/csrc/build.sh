@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds libnmrfit_amd.so for gfx950 (cross-compiles without a GPU).
 # Usage: nmrfit_amd/csrc/build.sh [extra hipcc flags]
+#        NMRFIT_LIBNAME=libab_x.so nmrfit_amd/csrc/build.sh -DNMRFIT_INTERLEAVE=2   (A/B builds for tools/ab.py)
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
@@ -11,5 +12,5 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
     -ffp-contract=on -fno-fast-math \
     -I"$ROOT/include" -I"$HERE" \
     "$HERE/objective.hip" "$HERE/pso.hip" "$HERE/cabi.hip" \
-    -o "$OUT/libnmrfit_amd.so" "$@"
-echo "built $OUT/libnmrfit_amd.so"
+    -o "$OUT/${NMRFIT_LIBNAME:-libnmrfit_amd.so}" "$@"
+echo "built $OUT/${NMRFIT_LIBNAME:-libnmrfit_amd.so}"

@@ -52,6 +52,9 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kInvPi = 0.31830988618379067154;
 constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
+#ifndef NMRFIT_INTERLEAVE
+#define NMRFIT_INTERLEAVE 4     // tuning knob, A/B-tested with tools/ab.py
+#endif
 constexpr int kFarTerms = 16;      // Taylor terms of the far-field expansion (rho <= 0.1 -> 1e-16)
 constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coefficient scratch in LDS:
                                    // lane l sits at column l + l/16, which makes the transposed
@@ -236,9 +239,10 @@ __device__ __forceinline__ void lorentz_group(const PeakLor *r, const double (&w
         c[g] = r[g].c;
         a[g] = r[g].al;
     }
-    // how many points the scheduler may interleave (a scheduling fence every kInterleave
-    // points): measured on C3 with 8-peak groups 1 -> 1.545 ms, 2 or 4 -> 1.464 ms, 8 -> 1.493 ms
-    constexpr int kInterleave = 4;
+    // a scheduling fence every kInterleave points bounds how many points the scheduler may
+    // interleave (register pressure); interleaved A/B on one device (tools/ab.py) shows no
+    // difference between 1, 2, 4 and 8 on C3 (within +-0.4 %)
+    constexpr int kInterleave = NMRFIT_INTERLEAVE;
 #pragma unroll
     for (int q = 0; q < kPointsPerLane; ++q) {
         double s[G];

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""A/B timing of several builds of libnmrfit_amd in ONE process on ONE device, interleaved
+rounds, median and min reported (perf deltas from separate runs or boxes are not comparable:
+devices differ by several per cent).  Usage:
+    NMRFIT_LIBNAME=libab_i2.so nmrfit_amd/csrc/build.sh -DNMRFIT_INTERLEAVE=2
+    python tools/ab.py nmrfit_amd/lib/libnmrfit_amd.so nmrfit_amd/lib/libab_i2.so [--variant 0] [--workload C3]
+"""
+import argparse, ctypes, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nmrfit_amd import _cabi, synth
+from nmrfit_amd.equations import Evaluator
+
+
+def load(path):
+    L = ctypes.CDLL(os.path.abspath(path))
+    for name, argtypes in _cabi.SIGNATURES.items():
+        fn = getattr(L, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
+    L.nmrfit_last_error.argtypes = []; L.nmrfit_last_error.restype = ctypes.c_char_p
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    cfg = synth.CONFIGS[a.workload]
+    sp = synth.make_spectrum(cfg.N, cfg.P, seed=1)
+    X = synth.make_swarm(sp["lower"], sp["upper"], cfg.S, seed=2, x_true=sp["x_true"])
+    libs = [load(p) for p in a.libs]
+    times = {p: [] for p in a.libs}
+    for r in range(a.rounds):
+        for p, L in zip(a.libs, libs):
+            _cabi._LIB = L
+            with Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+                ev.set_variant(a.variant)
+                dX = ev.dev_alloc(X.nbytes); df = ev.dev_alloc(8 * cfg.S)
+                ev.upload(dX, X)
+                for _ in range(3):
+                    ev.objective_batch_dev(cfg.S, cfg.P, dX, df)
+                ev.synchronize()
+                ev.timer_begin()
+                for _ in range(a.reps):
+                    ev.objective_batch_dev(cfg.S, cfg.P, dX, df)
+                times[p].append(ev.timer_end() / a.reps)
+                ev.dev_free(dX); ev.dev_free(df)
+    base = statistics.median(times[a.libs[0]])
+    for p in a.libs:
+        t = times[p]
+        print("%-44s median %.4f ms  min %.4f  max %.4f  (%.3fx of first)" % (os.path.basename(p), statistics.median(t), min(t), max(t), statistics.median(t) / base))
+
+
+if __name__ == "__main__":
+    main()

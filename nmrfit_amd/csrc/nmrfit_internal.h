@@ -12,7 +12,10 @@ namespace nmrfit {
 constexpr int kWave = 64;            // gfx950 wavefront
 constexpr int kWavesPerBlock = 4;    // 256-thread workgroups: one wave per SIMD of a CU
 constexpr int kBlock = kWave * kWavesPerBlock;
-constexpr int kPointsPerLane = 8;    // grid points register-blocked per lane per chunk
+#ifndef NMRFIT_POINTS
+#define NMRFIT_POINTS 8   // tuning knob (tools/ab.py)
+#endif
+constexpr int kPointsPerLane = NMRFIT_POINTS;    // grid points register-blocked per lane per chunk
 constexpr int kChunk = kWave * kPointsPerLane;   // 512 grid points per wave per chunk
 constexpr int kMaxPeaks = 1000;      // LDS: 4 waves x P x 40 B + 1 KiB of block seeds <= 160 KiB
 

@@ -53,7 +53,13 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kInvPi = 0.31830988618379067154;
 constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 #ifndef NMRFIT_INTERLEAVE
-#define NMRFIT_INTERLEAVE 4     // tuning knob, A/B-tested with tools/ab.py
+#define NMRFIT_INTERLEAVE 4     // tuning knobs, A/B-tested with tools/ab.py
+#endif
+#ifndef NMRFIT_GROUP
+#define NMRFIT_GROUP 8
+#endif
+#ifndef NMRFIT_MIN_WAVES
+#define NMRFIT_MIN_WAVES 3
 #endif
 constexpr int kFarTerms = 16;      // Taylor terms of the far-field expansion (rho <= 0.1 -> 1e-16)
 constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coefficient scratch in LDS:
@@ -307,7 +313,7 @@ template <int VARIANT, bool WRITE_R, int FIT_IM>
 // ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
 // With the imaginary part the epilogue also evaluates dispersion lines (Dawson polynomials):
 // 2 waves per SIMD rather than spilling.
-__global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_STAGED || VARIANT == NMRFIT_VARIANT_FARFIELD) ? 3 : 4) void objective_kernel(
+__global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_STAGED || VARIANT == NMRFIT_VARIANT_FARFIELD) ? NMRFIT_MIN_WAVES : 4) void objective_kernel(
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax,
     const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, double wspan, int nseg,
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     double ss = 0.0, ss_im = 0.0;
     constexpr bool kSkip = (VARIANT != NMRFIT_VARIANT_NOSKIP && VARIANT != NMRFIT_VARIANT_BASELINE);
     constexpr bool kFar = (VARIANT == NMRFIT_VARIANT_FARFIELD);
-    constexpr int kGroup = (VARIANT == NMRFIT_VARIANT_SINGLE) ? 1 : (VARIANT == NMRFIT_VARIANT_QUAD) ? 4 : 8;
+    constexpr int kGroup = (VARIANT == NMRFIT_VARIANT_SINGLE) ? 1 : (VARIANT == NMRFIT_VARIANT_QUAD) ? 4 : NMRFIT_GROUP;
 
     double wnext[kPointsPerLane];
     if (kStage) {

@@ -126,20 +126,11 @@ def main():
                      S_local=S_local, seed=1234, minstep=-1.0, minfunc=-1.0)   # never stop while timing
 
     if use_dist and backend == "nccl":
-        # run our launches and the RCCL all-gather on ONE explicit stream, so they are ordered
-        # without host synchronisation (torch's default stream is the null stream, whose
-        # handle 0 the C-ABI reads as "use the context's own stream": hence a real stream)
-        stream = torch.cuda.Stream(device=device)
-        torch.cuda.set_stream(stream)
-        ev.set_stream(stream.cuda_stream)
-        send = torch.zeros(D + 1, dtype=torch.float64, device="cuda")
-        recv = torch.zeros(world * (D + 1), dtype=torch.float64, device="cuda")
-        sw.set_candidate_dev(send.data_ptr())
-        ex = TorchExchange()
-
-        def fold():
-            ex.gather_device(send, recv)
-            sw.apply_global_dev(recv.data_ptr(), world)
+        # swarm kernels and the RCCL all-gather on ONE explicit stream, no host synchronisation
+        # inside a generation: the same object nmrfit_amd.fit() uses for multi-GPU fits
+        from nmrfit_amd.pso import RcclGeneration
+        gen = RcclGeneration(sw, TorchExchange())
+        fold = gen.fold
 
         def sync():
             torch.cuda.synchronize()

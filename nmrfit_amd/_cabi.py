@@ -74,6 +74,7 @@ SIGNATURES = {
 }
 
 _LIB = None
+_LOADED_BEFORE_TORCH = False
 
 
 def build(verbose=False):
@@ -93,6 +94,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NmrfitError(E_NO_DEVICE, "%s not found: build it with nmrfit_amd/csrc/build.sh "
                               "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        import sys
+        global _LOADED_BEFORE_TORCH
+        _LOADED_BEFORE_TORCH = "torch" not in sys.modules
         L = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
@@ -102,6 +106,15 @@ def lib():
         L.nmrfit_last_error.restype = ctypes.c_char_p
         _LIB = L
     return _LIB
+
+
+def loaded_before_torch():
+    """True when libnmrfit_amd (and with it the system HIP runtime) was loaded before torch was
+    imported.  torch bundles its own copy of the HIP runtime under the same SONAME: if torch
+    comes first both share that copy (streams and device pointers can be exchanged); if
+    libnmrfit_amd comes first the process ends up with two HIP runtimes and torch cannot
+    initialise the GPU.  Only the RCCL exchange path (pso.TorchExchange on "nccl") cares."""
+    return _LOADED_BEFORE_TORCH
 
 
 def check(rc):

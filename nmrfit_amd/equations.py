@@ -91,7 +91,8 @@ class Evaluator:
     def set_stream(self, stream_handle):
         """Run on an externally owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream)
         so that launches order with a collective library's work without host syncs."""
-        _cabi.check(self._lib.nmrfit_ctx_set_stream(self._ctx, ctypes.c_void_p(stream_handle)))
+        _cabi.check(self._lib.nmrfit_ctx_set_stream(self._ctx, ctypes.c_void_p(stream_handle) if stream_handle
+                                                    else None))
 
     def synchronize(self):
         _cabi.check(self._lib.nmrfit_ctx_synchronize(self._ctx))

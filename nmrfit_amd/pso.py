@@ -95,13 +95,14 @@ class TorchExchange:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.backend = dist.get_backend(group)
 
     def gather_host(self, cand):
         """Host-array form (fit() on several ranks, CPU tests): with the nccl backend the
         record takes a round trip through a CUDA tensor, with gloo it stays on the host."""
         import torch
         t = torch.from_numpy(np.ascontiguousarray(cand))
-        on_gpu = self._dist.get_backend(self.group) == "nccl"
+        on_gpu = self.backend == "nccl"
         if on_gpu:
             t = t.cuda()
         out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)   # flat: gloo needs 1-D
@@ -216,6 +217,7 @@ class DeviceSwarm:
         self.S_global = int(swarmsize)
         self.offset = int(offset)
         self.S = self.S_global if S_local is None else int(S_local)
+        self._minstep, self._minfunc = minstep, minfunc
         prm = _cabi.PsoParams(omega, phip, phig, minstep, minfunc, int(seed) & 0xFFFFFFFFFFFFFFFF)
         self._h = ctypes.c_void_p()
         _cabi.check(self._lib.nmrfit_pso_create(evaluator.handle, self.S, self.S_global, self.offset, self.P,
@@ -252,6 +254,14 @@ class DeviceSwarm:
 
     def set_candidate_dev(self, dptr):
         _cabi.check(self._lib.nmrfit_pso_set_candidate_dev(self._h, ctypes.c_void_p(dptr) if dptr else None))
+
+    @property
+    def minfunc(self):
+        return self._minfunc
+
+    @property
+    def minstep(self):
+        return self._minstep
 
     def candidate(self):
         return self.ev.download(self.candidate_dev(), (self.D + 1,))
@@ -298,17 +308,79 @@ STOP_MESSAGES = {
 }
 
 
+class RcclGeneration:
+    """One generation of a sharded DeviceSwarm with the candidate exchange on the GPU: the
+    swarm kernels and the RCCL all-gather (torch.distributed "nccl" backend) are enqueued on
+    ONE explicit HIP stream, so a generation needs no host synchronisation at all.
+
+    (torch's default stream is the null stream, whose handle 0 the C-ABI reads as "use the
+    context's own stream" -- hence a dedicated torch stream made current.)"""
+
+    def __init__(self, swarm, exchange):
+        if _cabi.loaded_before_torch():
+            raise RuntimeError("import torch before the first nmrfit_amd GPU call when exchanging candidates over "
+                               "RCCL: torch bundles its own HIP runtime and both libraries must share it "
+                               "(see nmrfit_amd._cabi.loaded_before_torch)")
+        import torch
+        self.torch = torch
+        self.swarm, self.exchange = swarm, exchange
+        dev = torch.device("cuda", swarm.ev.device)
+        self.stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(self.stream)
+        swarm.ev.set_stream(self.stream.cuda_stream)
+        n = swarm.D + 1
+        self.send = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.recv = torch.zeros(exchange.world * n, dtype=torch.float64, device=dev)
+        swarm.set_candidate_dev(self.send.data_ptr())
+
+    def fold(self):
+        self.exchange.gather_device(self.send, self.recv)
+        self.swarm.apply_global_dev(self.recv.data_ptr(), self.exchange.world)
+
+    def init(self):
+        self.swarm.init()
+        self.fold()
+
+    def step(self):
+        self.swarm.step_local()
+        self.fold()
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def close(self):
+        """Detach from the torch stream and buffers (before they are freed)."""
+        self.synchronize()
+        self.swarm.set_candidate_dev(None)
+        self.swarm.ev.set_stream(None)
+
+
 def run_sharded(swarm, exchange, maxiter, check_every=1, verbose=False):
-    """Generation loop for a (possibly sharded) swarm with host-side candidate exchange.
-    Works for HostSwarm and DeviceSwarm; every rank must call it.  Returns (x_best, f_best)."""
-    swarm.init()
-    swarm.apply_global(exchange.gather_host(swarm.candidate()))
+    """Generation loop for a (possibly sharded) swarm; every rank must call it.  Returns
+    (x_best, f_best).  A DeviceSwarm over an "nccl" process group exchanges candidates on the
+    GPU (RcclGeneration); otherwise (HostSwarm, gloo) the (D+1)-double record goes through
+    the host."""
+    on_gpu = (isinstance(swarm, DeviceSwarm) and isinstance(exchange, TorchExchange)
+              and exchange.backend == "nccl")
+    if on_gpu:
+        gen = RcclGeneration(swarm, exchange)
+        init, step = gen.init, gen.step
+    else:
+        gen = None
+
+        def init():
+            swarm.init()
+            swarm.apply_global(exchange.gather_host(swarm.candidate()))
+
+        def step():
+            swarm.step_local()
+            swarm.apply_global(exchange.gather_host(swarm.candidate()))
+    init()
     it = 0
     stopped = 0
     while it < maxiter:
         it += 1
-        swarm.step_local()
-        swarm.apply_global(exchange.gather_host(swarm.candidate()))
+        step()
         if it % check_every == 0 or it == maxiter:
             stopped = swarm.stop if isinstance(swarm, HostSwarm) else swarm.status()["stop"]
             if stopped:
@@ -321,7 +393,10 @@ def run_sharded(swarm, exchange, maxiter, check_every=1, verbose=False):
             print('Stopping search: maximum iterations reached --> {:}'.format(maxiter))
     if isinstance(swarm, HostSwarm):
         return swarm.best_x.copy(), float(swarm.best_f)
-    return swarm.best()
+    best = swarm.best()
+    if gen is not None:
+        gen.close()
+    return best
 
 
 def pso(evaluator, lb, ub, swarmsize=100, omega=0.5, phip=0.5, phig=0.5, maxiter=100, minstep=1e-8,

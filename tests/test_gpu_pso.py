@@ -159,3 +159,69 @@ def test_fit_api_end_to_end(problem, capsys):
     assert (res2.weights == 1.0).all()
     with pytest.raises(ValueError):
         nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im="nonsense", summary=False)
+
+
+_RCCL_SCRIPT = r"""
+import socket, sys
+import torch                      # before any nmrfit_amd GPU call: one shared HIP runtime
+import torch.distributed as dist
+import numpy as np
+sys.path.insert(0, %r)
+import nmrfit_amd
+from nmrfit_amd import pso, synth
+from nmrfit_amd.equations import Evaluator
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% port, rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+sp = synth.make_spectrum(2048, 3, seed=5)
+ev = Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"])
+ex = pso.TorchExchange()
+assert ex.backend == "nccl" and ex.world == 1
+a = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 300, seed=9)
+xa, fa = pso.run_sharded(a, ex, 120, check_every=7)
+st = a.status(); a.close()
+b = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 300, seed=9)
+b.run(120, check_every=7)
+xb, fb = b.best()
+assert b.status() == st, (b.status(), st)
+b.close()
+assert (xa == xb).all() and fa == fb
+f = ev.objective_batch(xa)        # the context is back on its own stream and still usable
+assert abs(f[0] - fa) <= 1e-12 * fa
+data = synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"])
+r1 = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False,
+                    options={"swarmsize": 100, "maxiter": 40, "seed": 5, "exchange": pso.TorchExchange()})
+r2 = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False,
+                    options={"swarmsize": 100, "maxiter": 40, "seed": 5})
+assert (r1.params == r2.params).all() and r1.error == r2.error
+ev.close()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_run_sharded_over_rccl_single_rank():
+    """pso.run_sharded with a torch "nccl" group (one rank): the candidate all-gather runs on the
+    GPU on the same stream as the swarm kernels (RcclGeneration) and the result equals the plain
+    device loop; nmrfit_amd.fit(options={"exchange": ...}) takes the same route.  Runs in its own
+    process because torch must be imported before libnmrfit_amd is loaded (shared HIP runtime)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT % root], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stderr[-3000:]
+
+
+def test_rccl_needs_torch_first(problem):
+    """In THIS process libnmrfit_amd was loaded first: the RCCL generation must refuse loudly
+    instead of letting torch fail to find the GPU."""
+    sp, ev = problem
+    if not _cabi.loaded_before_torch():
+        pytest.skip("torch was imported before the library in this process")
+    sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 16, seed=1)
+    with pytest.raises(RuntimeError, match="import torch before"):
+        pso.RcclGeneration(sw, pso.LocalExchange())
+    sw.close()

@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--swarm-per-gpu", type=int, default=0, help="override the workload's swarm size per GPU")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the far-field / other-config / host-pointer extras (profiling runs)")
     return ap.parse_args()
 
 
@@ -191,7 +193,7 @@ def main():
     geom = ev.last_launch()
     # opt-in far-field variant: same inputs, objective-only launches
     farfield = None
-    if rank == 0 and args.variant == 0:
+    if rank == 0 and args.variant == 0 and not args.no_extras:
         f_def = ev.download(d_f, (S_local,))
         ev.set_variant(_cabi.VARIANT_FARFIELD)
         for _ in range(2):
@@ -210,7 +212,7 @@ def main():
                             "configuration `value` is measured on"}
     # the other single-GPU configs of BASELINE.json, kernel-only (HIP events), for reference
     others = None
-    if rank == 0 and world == 1 and args.workload == "C3":
+    if rank == 0 and world == 1 and args.workload == "C3" and not args.no_extras:
         others = {}
         for name in ("C2", "C5"):
             c = synth.CONFIGS[name]
@@ -244,7 +246,7 @@ def main():
     # the host-pointer entry point (X uploaded, f downloaded every call): the PCIe-inclusive
     # rate, reported beside the resident one -- never as `value`
     host_ms = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extras:
         Xh = sw.state()["x"]
         ev.objective_batch(Xh)
         t1 = time.perf_counter()

@@ -278,3 +278,20 @@ def test_farfield_variant_full_size_and_geometry(eq):
         ev.set_variant(_cabi.VARIANT_BASELINE)
         Rb = ev.residual_batch(X[:2])
     np.testing.assert_allclose(R, Rb, rtol=0, atol=1e-14 * np.abs(Rb).max())
+
+
+def test_float32_spectra_as_nmrglue_delivers_them(eq):
+    """nmrfit.load hands out float32 u, v (complex64 FFT output) as reversed views (core.py:52-60).
+    The reference then rotates in complex64 (proc_autophase.py:29-32); the ABI upcasts to float64.
+    The two differ by the float32 rounding of the rotation only: ~1e-9 relative on f, far inside
+    the 1e-6 bar (asserted at 1e-7 against the numpy oracle running the reference's float32 path)."""
+    from oracle import nmrfit_oracle as onp
+    sp = synth.make_spectrum(4096, 6, seed=1)
+    X = synth.make_swarm(sp["lower"], sp["upper"], 5, seed=2, x_true=sp["x_true"])
+    u32, v32 = sp["u"].astype(np.float32)[::-1], sp["v"].astype(np.float32)[::-1]
+    w, wt = sp["w"][::-1], sp["weights"][::-1]
+    ref = np.array([onp.objective(X[i], w, u32, v32, wt) for i in range(5)])
+    with eq.Evaluator(w, u32, v32, wt) as ev:
+        f = ev.objective_batch(X)
+    np.testing.assert_allclose(f, ref, rtol=1e-7)
+    assert np.max(np.abs(f - ref) / ref) < 5e-8

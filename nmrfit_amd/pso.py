@@ -223,6 +223,7 @@ class DeviceSwarm:
         _cabi.check(self._lib.nmrfit_pso_create(evaluator.handle, self.S, self.S_global, self.offset, self.P,
                                                 _cabi.ptr(lb), _cabi.ptr(ub), ctypes.byref(prm),
                                                 ctypes.byref(self._h)))
+        evaluator._children.add(self)
 
     def close(self):
         if getattr(self, "_d_gather", None) is not None:

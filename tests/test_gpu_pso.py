@@ -225,3 +225,15 @@ def test_rccl_needs_torch_first(problem):
     with pytest.raises(RuntimeError, match="import torch before"):
         pso.RcclGeneration(sw, pso.LocalExchange())
     sw.close()
+
+
+def test_closing_the_evaluator_closes_its_swarms():
+    from nmrfit_amd import equations
+    sp = synth.make_spectrum(512, 1, seed=3)
+    ev = equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"])
+    sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 8, seed=1)
+    sw.run(3)
+    ev.close()                  # must not leave the swarm with a dangling context
+    assert not sw._h.value
+    sw.close()                  # idempotent
+    del sw, ev

@@ -295,3 +295,27 @@ def test_float32_spectra_as_nmrglue_delivers_them(eq):
     with eq.Evaluator(w, u32, v32, wt) as ev:
         f = ev.objective_batch(X)
     np.testing.assert_allclose(f, ref, rtol=5e-7)
+
+
+def test_large_shapes(eq):
+    """A million-point grid and a 200k-particle swarm: 64-bit indexing, block table, multi-pass
+    launches.  Sampled particles against the oracle."""
+    from oracle import c_oracle
+    sp = synth.make_spectrum(1 << 20, 40, seed=91)
+    X = synth.make_swarm(sp["lower"], sp["upper"], 600, seed=92, x_true=sp["x_true"])
+    with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        f = ev.objective_batch(X)
+        ev.set_variant(_cabi.VARIANT_FARFIELD)
+        ff = ev.objective_batch(X)
+    idx = np.array([0, 1, 299, 599])
+    ref = c_oracle.objective_batch(X[idx], sp["w"], sp["u"], sp["v"], sp["weights"], threads=16)
+    _close_f(f[idx], ref)
+    np.testing.assert_allclose(ff, f, rtol=1e-12)
+    sp = synth.make_spectrum(4096, 6, seed=93)
+    X = synth.make_swarm(sp["lower"], sp["upper"], 200000, seed=94, x_true=sp["x_true"])
+    with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        f = ev.objective_batch(X)
+    idx = np.arange(0, 200000, 9973)
+    ref = c_oracle.objective_batch(X[idx], sp["w"], sp["u"], sp["v"], sp["weights"], threads=16)
+    _close_f(f[idx], ref)
+    assert np.isfinite(f).all()

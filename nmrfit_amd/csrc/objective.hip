@@ -830,7 +830,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     int variant = ctx->variant;
     if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
     const size_t lds_far = (size_t)kWavesPerBlock * kFarTerms * kFarPad * sizeof(double);
-    if (variant == NMRFIT_VARIANT_FARFIELD && lds_recs + lds_far > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;   // P > ~800
+    if (variant == NMRFIT_VARIANT_FARFIELD && (lds_recs + lds_far > 160 * 1024 || fit_im != 0))
+        variant = NMRFIT_VARIANT_DEFAULT;   // P > ~800, or the imaginary part (direct kernel only)
     const size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
                        (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : 0);
     double *out = df;

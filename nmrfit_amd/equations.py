@@ -248,3 +248,14 @@ def kk_relation_vectorized(w, r, yoff, width, loc, a):
     Dawson's integral), which the quadrature approximates to ~1e-12."""
     x = np.array([0.0, 0.0, r, yoff, width, loc, a], dtype=np.float64)
     return _grid_evaluator(w).contributions(x)[1][0]
+
+
+def kk_relation(w, r, yoff, width, loc, a):
+    """nmrfit.equations.kk_relation (equations.py:52-80): the transform at ONE frequency w."""
+    return float(kk_relation_vectorized(np.array([w], dtype=np.float64), r, yoff, width, loc, a)[0])
+
+
+def kk_relation_parallel(w, r, yoff, width, loc, a, pool=None):
+    """nmrfit.equations.kk_relation_parallel (equations.py:83-112).  ``pool`` is accepted for
+    signature compatibility and ignored: the whole array is one GPU launch."""
+    return kk_relation_vectorized(w, r, yoff, width, loc, a)

@@ -54,6 +54,8 @@ def test_reference_named_shims(eq, g):
     np.testing.assert_allclose(im, g["imag_needle"], rtol=0, atol=2e-8 * np.abs(g["imag_needle"]).max())
     cf = synth._dispersion(g["w2"], a[0], a[2], a[3], a[4])
     np.testing.assert_allclose(im, cf, rtol=0, atol=1e-13 * np.abs(cf).max())
+    assert eq.kk_relation(g["w2"][7], *a) == pytest.approx(im[7], rel=1e-12, abs=1e-15)
+    np.testing.assert_array_equal(eq.kk_relation_parallel(g["w2"], *a, pool=None), im)
     from oracle import nmrfit_oracle as onp
     x = g["x"]
     np.testing.assert_allclose(eq.voigt(g["w"], x[2], x[3], x[4], x[5], x[6]),

@@ -149,3 +149,38 @@ def test_fit_with_imaginary_part(eq):
     ph = res.params[0] + frac * res.params[1]
     assert abs(ph - (sp["x_true"][0] + frac * sp["x_true"][1])) < 0.02
     assert res.params[6] == pytest.approx(sp["x_true"][6], rel=0.1)
+
+
+def test_randomized_fit_im_against_closed_form(eq):
+    """120 random shapes (N in [1, 3000], P in [1, 40]): both imaginary-channel modes against
+    numpy + scipy.special.dawsn (synth._dispersion), the same closed form the golden vectors pin
+    to the reference's quadrature at 1e-8."""
+    from nmrfit_amd import proc_autophase
+    from oracle import nmrfit_oracle as onp
+    rng = np.random.default_rng(77)
+    for case in range(120):
+        N = int(rng.integers(1, 3001)) if case % 6 else int(rng.choice([1, 2, 64, 65, 512, 513, 1025]))
+        P = int(rng.integers(1, 41))
+        S = int(rng.integers(1, 7))
+        w = np.linspace(-1.0, 5.0, N) if case % 2 else np.sort(rng.uniform(-1.0, 5.0, N))
+        u, v = rng.standard_normal(N), rng.standard_normal(N)
+        wt = 0.5 + rng.random(N)
+        X = np.empty((S, 4 + 3 * P))
+        X[:, 0] = rng.uniform(-4, 4, S)
+        X[:, 1] = rng.uniform(-4, 4, S)
+        X[:, 2] = rng.uniform(0, 1, S)
+        X[:, 3] = rng.uniform(-0.05, 0.05, S)
+        X[:, 4::3] = 6.0 * 10.0 ** rng.uniform(-4, 0.3, (S, P))
+        X[:, 5::3] = rng.uniform(-1.5, 5.5, (S, P))
+        X[:, 6::3] = rng.uniform(0.0, 2.0, (S, P))
+        want_ref, want_sum = np.empty(S), np.empty(S)
+        for s, x in enumerate(X):
+            V, I = proc_autophase.ps2(u, v, x[0], x[1])
+            Vf = sum(onp.voigt(w, x[2], x[3], *x[4 + 3 * k:7 + 3 * k]) for k in range(P))
+            Ik = [synth._dispersion(w, x[2], *x[4 + 3 * k:7 + 3 * k]) for k in range(P)]
+            rr = np.sqrt(np.mean((wt * (V - Vf)) ** 2))
+            want_ref[s] = 0.5 * (rr + np.sqrt(np.mean((wt * (I - Ik[-1])) ** 2)))
+            want_sum[s] = 0.5 * (rr + np.sqrt(np.mean((wt * (I - sum(Ik))) ** 2)))
+        with eq.Evaluator(w, u, v, wt) as ev:
+            np.testing.assert_allclose(ev.objective_batch(X, fit_im=True), want_ref, rtol=1e-11, err_msg=str((case, N, P)))
+            np.testing.assert_allclose(ev.objective_batch(X, fit_im="sum"), want_sum, rtol=1e-11, err_msg=str((case, N, P)))

@@ -319,3 +319,45 @@ def test_large_shapes(eq):
     ref = c_oracle.objective_batch(X[idx], sp["w"], sp["u"], sp["v"], sp["weights"], threads=16)
     _close_f(f[idx], ref)
     assert np.isfinite(f).all()
+
+
+def test_randomized_shapes_and_parameters(eq):
+    """300 random cases: N in [1, 5000] (non-uniform, unsorted and reversed grids included),
+    P in [0, 70], widths from needles to wider than the grid, lines on and off the grid, phases
+    up to +-60 rad; every kernel variant against the plain-C oracle."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(20261003)
+    worst = 0.0
+    for case in range(300):
+        N = int(rng.integers(1, 5001)) if case % 7 else int(rng.choice([1, 2, 63, 64, 65, 511, 512, 513, 1024, 4097]))
+        P = int(rng.integers(0, 71)) if case % 5 else int(rng.choice([0, 1, 7, 8, 9, 15, 16, 17, 63, 64, 65]))
+        S = int(rng.integers(1, 12))
+        kind = case % 4
+        if kind == 0:
+            w = np.linspace(rng.uniform(-5, 5), rng.uniform(6, 12), N)
+        elif kind == 1:
+            w = np.sort(rng.uniform(-3.0, 9.0, N))
+        elif kind == 2:
+            w = np.linspace(8.0, -2.0, N)                       # descending, as nmrfit.load delivers
+        else:
+            w = rng.uniform(0.0, 4.0, N)                          # unsorted
+        span = max(float(np.ptp(w)), 1.0)
+        u, v = rng.standard_normal(N), rng.standard_normal(N)
+        wt = 0.25 + rng.random(N)
+        X = np.empty((S, 4 + 3 * P))
+        X[:, 0] = rng.uniform(-60, 60, S)
+        X[:, 1] = rng.uniform(-60, 60, S)
+        X[:, 2] = rng.uniform(-0.2, 1.2, S)
+        X[:, 3] = rng.uniform(-0.05, 0.05, S)
+        X[:, 4::3] = span * 10.0 ** rng.uniform(-5, 0.5, (S, P))  # widths: needles ... wider than the grid
+        X[:, 5::3] = rng.uniform(w.min() - 0.2 * span, w.max() + 0.2 * span, (S, P))
+        X[:, 6::3] = rng.uniform(-1.0, 3.0, (S, P))
+        ref = c_oracle.objective_batch(X, w, u, v, wt, threads=4)
+        with eq.Evaluator(w, u, v, wt) as ev:
+            for variant in VARIANTS:
+                ev.set_variant(variant)
+                f = ev.objective_batch(X)
+                err = np.max(np.abs(f - ref) / np.maximum(np.abs(ref), F_FLOOR))
+                worst = max(worst, err)
+                assert err <= RTOL_F, (case, N, P, S, kind, variant, err)
+    assert worst < 1e-10, worst

@@ -45,12 +45,15 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--swarm-per-gpu", type=int, default=0, help="override the workload's swarm size per GPU")
+    ap.add_argument("--cpu-pool", type=int, default=0, metavar="PROCS",
+                    help="also time the reference's multiprocessing mode (Pool.map of the numpy oracle over PROCS "
+                         "spawned workers); off by default, never use under rocprofv3 (workers inherit its preload)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the far-field / other-config / host-pointer extras (profiling runs)")
     return ap.parse_args()
 
 
-def cpu_baseline(spec, lower, upper, P, budget_s):
+def cpu_baseline(spec, lower, upper, P, budget_s, pool_procs=0):
     """Reference-plumbing baseline: the numpy oracle, one particle per call, 1 core."""
     from oracle import nmrfit_oracle as onp
     from nmrfit_amd import synth
@@ -79,6 +82,12 @@ def cpu_baseline(spec, lower, upper, P, budget_s):
         out["c_openmp"] = {"value": m * N * P / dt, "cores": th, "sample": "%d particles, %.2f s" % (m, dt)}
     except Exception as e:  # the C oracle is optional for the baseline
         out["c_openmp"] = {"error": str(e)}
+    if pool_procs > 0:
+        # the reference's only parallel mode (utils.py:176-182, processes=n): Pool.map over particles
+        from oracle import pool_baseline
+        n, dt, _ = pool_baseline.timed_map(X, spec["w"], spec["u"], spec["v"], spec["weights"], pool_procs,
+                                           max(2.0, budget_s / 3))
+        out["numpy_pool"] = {"value": n * N * P / dt, "cores": pool_procs, "sample": "%d particles, %.2f s" % (n, dt)}
     return out
 
 
@@ -299,7 +308,7 @@ def main():
             line["host_pointer_call"] = {"ms": host_ms, "units_per_s": units_launch / (host_ms * 1e-3),
                                          "note": "nmrfit_objective_batch with host X/f (H2D + kernel + D2H per call)"}
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(spec, spec["lower"], spec["upper"], P, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(spec, spec["lower"], spec["upper"], P, args.cpu_seconds, args.cpu_pool)
         print(json.dumps(line))
         sys.stdout.flush()
     ev.dev_free(d_x)

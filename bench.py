@@ -75,9 +75,12 @@ def cpu_baseline(spec, lower, upper, P, budget_s, pool_procs=0):
         from oracle import c_oracle
         th = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         th = min(th, 16)     # a one-GPU box's CPU share
-        m = min(X.shape[0], max(th, 4 * th))
-        t0 = time.perf_counter()
-        c_oracle.objective_batch(X[:m], spec["w"], spec["u"], spec["v"], spec["weights"], threads=th)
+        per = min(X.shape[0], 4 * th)
+        c_oracle.objective_batch(X[:per], spec["w"], spec["u"], spec["v"], spec["weights"], threads=th)   # warm the team
+        m, t0 = 0, time.perf_counter()
+        while m + per <= X.shape[0] and time.perf_counter() - t0 < 2.0:
+            c_oracle.objective_batch(X[m:m + per], spec["w"], spec["u"], spec["v"], spec["weights"], threads=th)
+            m += per
         dt = time.perf_counter() - t0
         out["c_openmp"] = {"value": m * N * P / dt, "cores": th, "sample": "%d particles, %.2f s" % (m, dt)}
     except Exception as e:  # the C oracle is optional for the baseline

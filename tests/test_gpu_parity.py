@@ -361,3 +361,38 @@ def test_randomized_shapes_and_parameters(eq):
                 worst = max(worst, err)
                 assert err <= RTOL_F, (case, N, P, S, kind, variant, err)
     assert worst < 1e-10, worst
+
+
+def test_contexts_on_concurrent_host_threads(eq):
+    """include/nmrfit_amd.h: 'different contexts may be driven from different host threads'.
+    Six threads, one context (own stream, own workspaces) each, different spectra and shapes,
+    interleaved calls; every result equals the same call made serially."""
+    import threading
+    jobs = []
+    for t in range(6):
+        sp = synth.make_spectrum(1500 + 700 * t, 2 + 3 * t, seed=40 + t)
+        X = synth.make_swarm(sp["lower"], sp["upper"], 30 + 25 * t, seed=50 + t)
+        with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+            want_f, want_r = ev.objective_batch(X), ev.residual_batch(X[:3])
+        jobs.append((sp, X, want_f, want_r))
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def work(sp, X, want_f, want_r):
+        try:
+            with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+                start.wait()
+                for it in range(40):
+                    np.testing.assert_array_equal(ev.objective_batch(X), want_f)
+                    if it % 8 == 0:
+                        np.testing.assert_array_equal(ev.residual_batch(X[:3]), want_r)
+        except BaseException as e:      # surfaced in the main thread below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert not errors, errors[0]
+    assert not any(th.is_alive() for th in threads)

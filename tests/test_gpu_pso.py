@@ -237,3 +237,29 @@ def test_closing_the_evaluator_closes_its_swarms():
     assert not sw._h.value
     sw.close()                  # idempotent
     del sw, ev
+
+
+@pytest.mark.parametrize("S,P", [(12, 100), (12, 300), (300, 120), (3, 1000), (1, 2), (2, 0)])
+def test_device_swarm_wide_parameter_vectors(S, P):
+    """Many-peak models (D = 4 + 3P up to 3004) and degenerate swarms, on both sides of the
+    fused-tail threshold: still bit-identical to the numpy mirror."""
+    from nmrfit_amd import equations
+    sp = synth.make_spectrum(1024, P, seed=9)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=31, minfunc=-1.0, minstep=-1.0)
+        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=31, minfunc=-1.0, minstep=-1.0)
+        dev.init(); host.init()
+        for _ in range(4):
+            np.testing.assert_array_equal(dev.candidate(), host.candidate())
+            dev.apply_global(dev.candidate()[None, :]); host.apply_global(host.candidate()[None, :])
+            dev.step_local(); host.step_local()
+        st = dev.state()
+        for k in ("x", "v", "p", "fx", "fp"):
+            np.testing.assert_array_equal(st[k], getattr(host, k), err_msg=k)
+        # the fused loop (nmrfit_pso_run) from the same start reaches the same state
+        dev2 = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=31, minfunc=-1.0, minstep=-1.0)
+        dev2.run(4, check_every=3)
+        dev.apply_global(dev.candidate()[None, :])
+        np.testing.assert_array_equal(dev2.state()["x"], dev.state()["x"])
+        assert dev2.best()[1] == dev.best()[1]
+        dev.close(); dev2.close()

@@ -486,6 +486,8 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                 const double wcen = wave_uniform(0.5 * (mm.x + mm.y));
                 const double hw = wave_uniform(0.5 * (mm.y - mm.x));
                 double csum = 0.0;    // lane l: coefficient of order l >> 2 (all 4 lanes of a quad)
+                const bool few = P <= 32;                                    // one pass, half a wave of peaks
+                const int fslot = !few ? lane + (lane >> 4) : (lane < 32) ? lane + (lane >> 3) : lane + 4;   // lanes >= 32: unread slots
                 for (int kb = 0; kb < P; kb += kWave) {
                     const int k = kb + lane;
                     const bool act = k < P;
@@ -510,19 +512,35 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                     const unsigned long long nearmask = __ballot(act && !far);
                     const unsigned long long hits = __ballot(ghit);
                     if (farmask) {
+                        // order n carries al * Im(q m^n), m = -hk q.  Both roots of the real
+                        // recurrence y[n+1] = 2 Re(m) y[n] - |m|^2 y[n-1] have modulus |m|, so
+                        // it is as stable as the complex product and costs two operations a term.
+                        const double a2 = far ? mr + mr : 0.0;       // lanes without a far peak carry exact zeros
+                        const double b2 = far ? -__builtin_fma(mr, mr, mi * mi) : 0.0;
+                        double y0 = far ? al * zi : 0.0;
+                        double y1 = far ? al * __builtin_fma(zr, mi, zi * mr) : 0.0;
+                        double *dst = ffs + fslot;
 #pragma unroll
                         for (int n = 0; n < kFarTerms; ++n) {
-                            ffs[n * kFarPad + lane + (lane >> 4)] = far ? al * zi : 0.0;
-                            const double nz = __builtin_fma(zr, mr, -(zi * mi));
-                            zi = __builtin_fma(zr, mi, zi * mr);
-                            zr = nz;
+                            dst[n * kFarPad] = y0;
+                            const double y2 = __builtin_fma(a2, y1, b2 * y0);
+                            y0 = y1;
+                            y1 = y2;
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
-                        // lane l sums order l>>2 over peaks 16*(l&3) .. +15, then the quad combines
-                        const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
+                        // lane l sums order l>>2 over a quarter of the peaks of this pass, then
+                        // the quad combines (quarters of 8 peaks padded to 9 when P <= 32, else 16
+                        // padded to 17: conflict-free reads either way)
                         double part = 0.0;
+                        if (few) {
+                            const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 9;
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) part += row[j];
+                            for (int j = 0; j < 8; ++j) part += row[j];
+                        } else {
+                            const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) part += row[j];
+                        }
                         part += __shfl_xor(part, 1, kWave);
                         part += __shfl_xor(part, 2, kWave);
                         csum += part;

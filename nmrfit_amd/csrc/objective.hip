@@ -407,6 +407,8 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     constexpr bool kFar = (VARIANT == NMRFIT_VARIANT_FARFIELD);
     constexpr int kGroup = (VARIANT == NMRFIT_VARIANT_SINGLE) ? 1 : (VARIANT == NMRFIT_VARIANT_QUAD) ? 4 : NMRFIT_GROUP;
 
+    bool ff_odd = false;                       // FARFIELD, P <= 32: this chunk's expansion was made by the previous one
+    unsigned pend_near = 0, pend_hits = 0;     // ... together with its near-peak and Gaussian-window masks
     double wnext[kPointsPerLane];
     if (kStage) {
 #pragma unroll
@@ -485,9 +487,86 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                 // <= 0.1^16 of each peak's term.  Near peaks are evaluated directly.
                 const double wcen = wave_uniform(0.5 * (mm.x + mm.y));
                 const double hw = wave_uniform(0.5 * (mm.y - mm.x));
+                double cf[kFarTerms];
+                if (P <= 32) {
+                    // Half a wave of peaks: the even chunks of a segment work out the expansions
+                    // of TWO chunks at once -- lanes 0..31 for this chunk, lanes 32..63 for the
+                    // next -- and park the second set (sums in LDS, masks in SGPRs) for the odd
+                    // chunk that follows.  Either half runs the same operations in the same
+                    // order, so a chunk's coefficients do not depend on which half made them.
+                    unsigned near_c, hits_c;
+                    if (!ff_odd) {
+                        const bool has_next = jb + kChunk < j1;                  // wave-uniform
+                        double2 mn = mm;
+                        if (has_next) mn = chunk_minmax[jb / kChunk + 1];
+                        const bool upper = lane >= 32;
+                        const int k = lane & 31;
+                        const double lo_w = upper ? mn.x : mm.x, hi_w = upper ? mn.y : mm.y;
+                        const bool act = (k < P) && (!upper || has_next);
+                        bool far = false, ghit = false;
+                        double a2 = 0.0, b2 = 0.0, y0 = 0.0, y1 = 0.0;
+                        if (act) {
+                            const PeakLor rec = lor[k];
+                            const PeakWin wn = win[k];
+                            ghit = (hi_w >= (double)wn.lo) && (lo_w <= (double)wn.hi);
+                            const double tc = __builtin_fma(0.5 * (lo_w + hi_w), rec.ihw, rec.c);
+                            const double hk = (0.5 * (hi_w - lo_w)) * rec.ihw;
+                            const double den = __builtin_fma(tc, tc, 1.0);
+                            far = den >= 100.0 * hk * hk;            // rho^2 <= 0.01 (false for NaN)
+                            if (far) {
+                                const double rq = rcp64(den);
+                                const double qr = tc * rq;            // q = (tc + i)/(tc^2 + 1)
+                                const double mr = -hk * qr, mi = -hk * rq;   // m = -hk q
+                                a2 = mr + mr;
+                                b2 = -__builtin_fma(mr, mr, mi * mi);
+                                y0 = rec.al * rq;
+                                y1 = rec.al * __builtin_fma(qr, mi, rq * mr);
+                            }
+                        }
+                        const unsigned long long farmask = __ballot(far);
+                        const unsigned long long nearmask = __ballot(act && !far);
+                        const unsigned long long hits = __ballot(ghit);
+                        double part = 0.0;
+                        if (farmask) {
+                            // order n carries al * Im(q m^n); both roots of the real recurrence
+                            // y[n+1] = 2 Re(m) y[n] - |m|^2 y[n-1] have modulus |m| (stable), two
+                            // operations a term; lanes without a far peak carry exact zeros
+                            double *dst = ffs + lane + (lane >> 4);
+#pragma unroll
+                            for (int n = 0; n < kFarTerms; ++n) {
+                                dst[n * kFarPad] = y0;
+                                const double y2 = __builtin_fma(a2, y1, b2 * y0);
+                                y0 = y1;
+                                y1 = y2;
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
+                            // lane l sums order l>>2 over 16 peaks (quarters padded to 17:
+                            // conflict-free); lanes l, l^1 hold the halves of one chunk
+                            const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) part += row[j];
+                            part += __shfl_xor(part, 1, kWave);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the sums overwrite row 0
+                        }
+                        // sums of this chunk -> slots 0..15, of the next -> slots 16..31
+                        if ((lane & 1) == 0) ffs[((lane & 2) << 3) + (lane >> 2)] = part;
+                        near_c = (unsigned)nearmask;
+                        hits_c = (unsigned)hits;
+                        pend_near = (unsigned)(nearmask >> 32);
+                        pend_hits = (unsigned)(hits >> 32);
+                    } else {
+                        near_c = pend_near;
+                        hits_c = pend_hits;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const double *src = ffs + (ff_odd ? kFarTerms : 0);
+#pragma unroll
+                    for (int n = 0; n < kFarTerms; ++n) cf[n] = src[n];
+                    ff_odd = !ff_odd;
+                    for (unsigned m = near_c; m; m &= m - 1) lorentz_group<1>(lor + __builtin_ctz(m), wv, acc);
+                    for (unsigned m = hits_c; m; m &= m - 1) gauss_add(lor + __builtin_ctz(m), wv, acc);
+                } else {
                 double csum = 0.0;    // lane l: coefficient of order l >> 2 (all 4 lanes of a quad)
-                const bool few = P <= 32;                                    // one pass, half a wave of peaks
-                const int fslot = !few ? lane + (lane >> 4) : (lane < 32) ? lane + (lane >> 3) : lane + 4;   // lanes >= 32: unread slots
                 for (int kb = 0; kb < P; kb += kWave) {
                     const int k = kb + lane;
                     const bool act = k < P;
@@ -519,7 +598,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                         const double b2 = far ? -__builtin_fma(mr, mr, mi * mi) : 0.0;
                         double y0 = far ? al * zi : 0.0;
                         double y1 = far ? al * __builtin_fma(zr, mi, zi * mr) : 0.0;
-                        double *dst = ffs + fslot;
+                        double *dst = ffs + lane + (lane >> 4);
 #pragma unroll
                         for (int n = 0; n < kFarTerms; ++n) {
                             dst[n * kFarPad] = y0;
@@ -528,19 +607,12 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                             y1 = y2;
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
-                        // lane l sums order l>>2 over a quarter of the peaks of this pass, then
-                        // the quad combines (quarters of 8 peaks padded to 9 when P <= 32, else 16
-                        // padded to 17: conflict-free reads either way)
+                        // lane l sums order l>>2 over 16 peaks of this pass (quarters padded to
+                        // 17: conflict-free reads), then the quad combines
                         double part = 0.0;
-                        if (few) {
-                            const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 9;
+                        const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) part += row[j];
-                        } else {
-                            const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) part += row[j];
-                        }
+                        for (int j = 0; j < 16; ++j) part += row[j];
                         part += __shfl_xor(part, 1, kWave);
                         part += __shfl_xor(part, 2, kWave);
                         csum += part;
@@ -554,9 +626,9 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                 // broadcast the kFarTerms sums through LDS and evaluate them at the lane's points
                 if ((lane & 3) == 0) ffs[lane >> 2] = csum;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                double cf[kFarTerms];
 #pragma unroll
                 for (int n = 0; n < kFarTerms; ++n) cf[n] = ffs[n];
+                }
                 const double ihwc = (hw > 0.0) ? rcp64(hw) : 0.0;
 #pragma unroll
                 for (int q = 0; q < kPointsPerLane; ++q) {

@@ -396,3 +396,41 @@ def test_contexts_on_concurrent_host_threads(eq):
         th.join(120)
     assert not errors, errors[0]
     assert not any(th.is_alive() for th in threads)
+
+
+def test_source_derived_properties_on_the_gpu(eq):
+    """SURVEY section 4, properties 1-4, asserted on the HIP path itself (no oracle involved)."""
+    from nmrfit_amd import proc_autophase
+    # 1. voigt is area-normalised: the per-peak real contribution integrates to `a`
+    w = np.linspace(-2000.0, 2000.0, 2_000_001)
+    zeros = np.zeros_like(w)
+    with eq.Evaluator(w, zeros, zeros, np.ones_like(w)) as ev:
+        for r in (0.0, 0.4, 1.0):
+            real, _ = ev.contributions(np.array([0.0, 0.0, r, 0.0, 0.7, 0.3, 2.5]))
+            area = np.sum(0.5 * (real[0][1:] + real[0][:-1]) * np.diff(w))
+            assert area == pytest.approx(2.5, abs=2.5 * r * 0.7 / (np.pi * 2000) * 1.1 + 1e-9)
+    # 2. ps2 round trip: rotating by (p0, p1) and back returns the data
+    sp = synth.make_spectrum(4096, 6, seed=1, noise=0.0)
+    V, I = proc_autophase.ps2(sp["u"], sp["v"], 0.7, -1.3)
+    ub, vb = proc_autophase.ps2(V, I, 0.7, -1.3, inv=True)
+    np.testing.assert_allclose(ub, sp["u"], atol=1e-15)
+    np.testing.assert_allclose(vb, sp["v"], atol=1e-15)
+    with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        # 3. the objective of a noiseless spectrum at its generating parameters is rounding noise
+        assert ev.objective_batch(sp["x_true"])[0] < 1e-14
+        X = synth.make_swarm(sp["lower"], sp["upper"], 8, seed=6)
+        f0 = ev.objective_batch(X)
+    # 4. invariant to shifting w and every loc together ...
+    X2 = X.copy()
+    X2[:, 5::3] += 0.25
+    with eq.Evaluator(sp["w"] + 0.25, sp["u"], sp["v"], sp["weights"]) as ev:
+        np.testing.assert_allclose(ev.objective_batch(X2), f0, rtol=1e-10)
+    # ... but not to reversing the arrays: the phase ramp runs over the array index (proc_autophase.py:30-31)
+    with eq.Evaluator(sp["w"][::-1], sp["u"][::-1], sp["v"][::-1], sp["weights"][::-1]) as ev:
+        f_rev = ev.objective_batch(X)
+    assert not np.allclose(f_rev, f0, rtol=1e-3)
+    Xr = X.copy()
+    Xr[:, 0] = X[:, 0] + X[:, 1] * (1.0 - 1.0 / sp["w"].size)    # ramp reversed: phi'_j = p0 + p1 (N-1-j)/N
+    Xr[:, 1] = -X[:, 1]
+    with eq.Evaluator(sp["w"][::-1], sp["u"][::-1], sp["v"][::-1], sp["weights"][::-1]) as ev:
+        np.testing.assert_allclose(ev.objective_batch(Xr), f0, rtol=1e-10)

@@ -17,7 +17,7 @@
 // counter (generation, dimension, GLOBAL particle index): the swarm's trajectory does not
 // depend on how it is sharded.  After a stop is flagged on the device every later launch is
 // a no-op, so the host may poll the flag every k generations without changing the result.
-// Small swarms (S*D <= 4608, e.g. the reference's default 204 particles x 6 peaks) are launch-bound:
+// Small swarms (S*D <= 2560, e.g. 50 particles x 6 peaks) are launch-bound:
 // for them everything after the objective launch runs in ONE single-workgroup kernel
 // (pso_tail_kernel), two launches per generation instead of six.
 #include "nmrfit_internal.h"
@@ -40,6 +40,9 @@ struct nmrfit_pso {
     double *d_cand_own = nullptr;
     long long *d_flags = nullptr;      // [0] completed generations, [1] stop code
     double *d_best = nullptr;          // [0] fg, [1] best_f, [2..2+D) g, [2+D..2+2D) best_x
+    double *d_part_val = nullptr;      // pso_select_kernel: per-workgroup (min fp, index) posts
+    long long *d_part_idx = nullptr;
+    unsigned *d_ticket = nullptr;
     bool initialized = false;    // nmrfit_pso_init has run
     bool seeded = false;         // the generation-0 candidates have been folded into (g, fg)
 };
@@ -355,6 +358,130 @@ __global__ __launch_bounds__(1024) void pso_tail_kernel(TailArgs a)
 }
 
 
+// ---- large swarms: everything between the objective launch and the next position update in
+// ONE many-workgroup kernel.  Every launch costs ~4.8 us on this part however little it does
+// (measured: profiles/r01/small_swarm_kernel_trace.txt), so finalize + pbest + argmin (+ apply)
+// as four launches cost more than a 1024 x 4096 x 6 objective.  One wave per particle adds the
+// block sums of its objective (finalize), updates the personal best, and the workgroup posts
+// its (fp, index) minimum; the workgroup that draws the last ticket -- all others have fenced
+// their writes by then -- reduces the posted minima, writes the candidate record and, for a
+// single-rank run, folds it into (g, fg) with the stopping rule.
+constexpr int kSelectWaves = 4;         // particles per workgroup pass (one device-scope fence per workgroup)
+constexpr int kSelectMaxBlocks = 1024;  // larger swarms: workgroups stride over the particles
+
+__device__ __forceinline__ bool lex_less(double v, long long i, double bv, long long bi)
+{
+    return v < bv || (v == bv && i < bi);
+}
+
+__global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArgs a, double *part_val,
+                                                                          long long *part_idx, unsigned *ticket)
+{
+    if (a.flags[1] != 0) return;
+    __shared__ double s_val[kSelectWaves];
+    __shared__ long long s_idx[kSelectWaves];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    double mine = INFINITY;
+    long long mi = 0x7fffffffffffffffLL;
+    for (int64_t i = (int64_t)blockIdx.x * kSelectWaves + wave; i < a.S; i += (int64_t)gridDim.x * kSelectWaves) {
+        double f;
+        if (a.phases & kTailFinalize) {   // same arithmetic and order as finalize_kernel
+            if (a.fit_im == 0) {
+                double ss = 0.0;
+                for (int64_t c = 0; c < a.n_blocks; ++c) ss += a.partial[i * a.n_blocks + c];
+                f = sqrt(ss / (double)a.N);
+            } else {
+                double ss = 0.0, si = 0.0;
+                for (int64_t c = 0; c < a.n_blocks; ++c) {
+                    ss += a.partial[(i * a.n_blocks + c) * 2];
+                    si += a.partial[(i * a.n_blocks + c) * 2 + 1];
+                }
+                f = 0.5 * (sqrt(ss / (double)a.N) + sqrt(si / (double)a.N));
+            }
+            if (lane == 0) a.fx[i] = f;
+        } else {
+            f = a.fx[i];
+        }
+        double cur = a.fp[i];
+        if (f < cur) {   // pyswarm: i_update = fx < fp
+            for (int64_t d = lane; d < a.D; d += kWave) a.p[i * a.D + d] = a.x[i * a.D + d];
+            if (lane == 0) a.fp[i] = f;
+            cur = f;
+        }
+        if (lex_less(cur, i, mine, mi)) {
+            mine = cur;
+            mi = i;
+        }
+    }
+    if (lane == 0) {
+        s_val[wave] = mine;
+        s_idx[wave] = mi;
+    }
+    __syncthreads();   // the workgroup's p / fp writes have reached L2 ...
+    if (threadIdx.x == 0) {
+        double b = s_val[0];
+        long long bi = s_idx[0];
+        for (int w = 1; w < kSelectWaves; ++w)
+            if (lex_less(s_val[w], s_idx[w], b, bi)) {
+                b = s_val[w];
+                bi = s_idx[w];
+            }
+        part_val[blockIdx.x] = b;
+        part_idx[blockIdx.x] = bi;
+        __threadfence();   // ... and one device-scope release per workgroup (cumulative) publishes them with the post
+        s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();   // acquire: the other workgroups' posts and rows
+    const volatile double *pv = part_val;
+    const volatile long long *pi = part_idx;
+    double best = INFINITY;
+    long long bi = 0x7fffffffffffffffLL;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+        const double v = pv[b];
+        const long long ix = pi[b];
+        if (lex_less(v, ix, best, bi)) {
+            best = v;
+            bi = ix;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(best, off, kWave);
+        const long long oi = __shfl_down(bi, off, kWave);
+        if (lex_less(ob, oi, best, bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    __syncthreads();   // s_val / s_idx are free again
+    if (lane == 0) {
+        s_val[wave] = best;
+        s_idx[wave] = bi;
+    }
+    __syncthreads();
+    best = s_val[0];
+    bi = s_idx[0];
+    for (int w = 1; w < kSelectWaves; ++w)
+        if (lex_less(s_val[w], s_idx[w], best, bi)) {
+            best = s_val[w];
+            bi = s_idx[w];
+        }
+    if (bi >= a.S) bi = 0;   // np.argmin of an all-inf array
+    const volatile double *fpv = a.fp, *ppv = a.p;
+    if (threadIdx.x == 0) {
+        a.cand[0] = fpv[bi];
+        *ticket = 0u;        // ready for the next launch
+    }
+    for (int64_t d = threadIdx.x; d < a.D; d += blockDim.x) a.cand[1 + d] = ppv[bi * a.D + d];
+    if (a.phases & kTailApply) {
+        __syncthreads();
+        if (wave == 0) apply_wave(lane, a.D, a.nranks, a.is_init, a.minstep, a.minfunc, a.cands, a.flags, a.best);
+    }
+}
+
+
 int bind_pso(const nmrfit_pso *pso)
 {
     if (!pso || !pso->ctx) {
@@ -365,14 +492,14 @@ int bind_pso(const nmrfit_pso *pso)
     return NMRFIT_OK;
 }
 
-// One workgroup handles the whole tail only while that is cheaper than five more launches:
-// measured: 50 x 22 elements 14.8 vs 23.7 us per generation, 204 x 22 22.2 vs 24.7, but
-// 204 x 40 41.4 vs 36.3 -- the cross-over is near 5k swarm elements.
+// One workgroup handles the whole tail only while that is cheaper than the two launches of the
+// many-workgroup form (select + update, ~4.8 us each): the single-workgroup tail takes
+// ~5.5 us + 1.55 us per 1000 swarm elements (7.2 us at 50 x 22, 12.5 us at 204 x 22).
 int64_t tail_max_elems()
 {
     static const int64_t v = [] {
         const char *e = getenv("NMRFIT_TAIL_MAX_ELEMS");   // tuning knob
-        return e ? (int64_t)atoll(e) : (int64_t)4608;
+        return e ? (int64_t)atoll(e) : (int64_t)2560;
     }();
     return v;
 }
@@ -433,14 +560,19 @@ int evaluate_and_select(nmrfit_pso *pso, int more = 0, int is_init = 0)
         a.is_init = is_init;
         return launch_tail(pso, a);
     }
-    int rc = launch_objective(ctx, S, pso->P, pso->d_x, pso->d_fx, nullptr);
-    if (rc != NMRFIT_OK) return rc;
     if (S > 0) {
-        const int wpb = 4;
-        hipLaunchKernelGGL(pso_pbest_kernel, dim3((unsigned)((S + wpb - 1) / wpb)), dim3(kWave * wpb), 0, ctx->stream, S,
-                           D, pso->d_flags, pso->d_x, pso->d_fx, pso->d_p, pso->d_fp);
+        ObjectiveDeferred def;
+        int rc = launch_objective(ctx, S, pso->P, pso->d_x, pso->d_fx, nullptr, &def);
+        if (rc != NMRFIT_OK) return rc;
+        TailArgs a = tail_args(pso, def, (def.needed ? kTailFinalize : 0) | kTailPbest | kTailArgmin | (more & kTailApply));
+        a.is_init = is_init;
+        const unsigned nb = (unsigned)std::min<int64_t>((S + kSelectWaves - 1) / kSelectWaves, kSelectMaxBlocks);
+        hipLaunchKernelGGL(pso_select_kernel, dim3(nb), dim3(kWave * kSelectWaves), 0, ctx->stream, a, pso->d_part_val,
+                           pso->d_part_idx, pso->d_ticket);
         NMRFIT_HIP(hipGetLastError());
+        return NMRFIT_OK;
     }
+    // an empty shard still posts its (+inf, zeros) candidate
     hipLaunchKernelGGL(pso_argmin_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, D, pso->d_flags, pso->d_fp, pso->d_p,
                        pso->d_cand);
     NMRFIT_HIP(hipGetLastError());
@@ -509,6 +641,13 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
     pso->d_cand = pso->d_cand_own;
     PSO_HIP(hipMalloc((void **)&pso->d_flags, 2 * sizeof(long long)));
     PSO_HIP(hipMalloc((void **)&pso->d_best, (size_t)(2 + 2 * D) * sizeof(double)));
+    {
+        const size_t nb = (size_t)kSelectMaxBlocks;
+        PSO_HIP(hipMalloc((void **)&pso->d_part_val, nb * sizeof(double)));
+        PSO_HIP(hipMalloc((void **)&pso->d_part_idx, nb * sizeof(long long)));
+        PSO_HIP(hipMalloc((void **)&pso->d_ticket, sizeof(unsigned)));
+        PSO_HIP(hipMemsetAsync(pso->d_ticket, 0, sizeof(unsigned), ctx->stream));
+    }
     PSO_HIP(hipMemcpyAsync(pso->d_lb, lower, (size_t)D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PSO_HIP(hipMemcpyAsync(pso->d_ub, upper, (size_t)D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PSO_HIP(hipMemsetAsync(pso->d_flags, 0, 2 * sizeof(long long), ctx->stream));
@@ -526,7 +665,8 @@ int nmrfit_pso_destroy(nmrfit_pso *pso)
         (void)hipSetDevice(pso->ctx->device);
         (void)hipStreamSynchronize(pso->ctx->stream);
     }
-    void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_p, pso->d_fx, pso->d_fp, pso->d_cand_own, pso->d_flags, pso->d_best};
+    void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_p, pso->d_fx, pso->d_fp, pso->d_cand_own, pso->d_flags, pso->d_best,
+                    pso->d_part_val, pso->d_part_idx, pso->d_ticket};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete pso;
@@ -673,6 +813,15 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
             // unfused sequence leaves behind
             rc = evaluate_and_select(pso, kTailApply | (it < maxiter ? kTailUpdate : 0));
             if (rc != NMRFIT_OK) return rc;
+        } else if (pso->S > 0) {
+            // three launches: positions, objective, select (+ fold and stopping rule)
+            const int64_t n = pso->S * pso->D;
+            hipLaunchKernelGGL(pso_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pso->ctx->stream,
+                               pso->S, pso->D, pso->offset, pso->prm.seed, pso->prm.omega, pso->prm.phip,
+                               pso->prm.phig, pso->d_flags, pso->d_best, pso->d_lb, pso->d_ub, pso->d_p, pso->d_x,
+                               pso->d_v);
+            NMRFIT_HIP(hipGetLastError());
+            if ((rc = evaluate_and_select(pso, kTailApply)) != NMRFIT_OK) return rc;
         } else {
             if ((rc = nmrfit_pso_step_local(pso)) != NMRFIT_OK) return rc;
             if ((rc = nmrfit_pso_apply_global_dev(pso, pso->d_cand, 1)) != NMRFIT_OK) return rc;

@@ -366,14 +366,67 @@ __global__ __launch_bounds__(1024) void pso_tail_kernel(TailArgs a)
 // its (fp, index) minimum; the workgroup that draws the last ticket -- all others have fenced
 // their writes by then -- reduces the posted minima, writes the candidate record and, for a
 // single-rank run, folds it into (g, fg) with the stopping rule.
-constexpr int kSelectWaves = 4;         // particles per workgroup pass (one device-scope fence per workgroup)
-constexpr int kSelectMaxBlocks = 1024;  // larger swarms: workgroups stride over the particles
+constexpr int kSelectWaves = 4;          // particles per workgroup pass
+constexpr int kSelectTicketBlocks = 128;
+constexpr int kSelectMaxPosts = 65536;    // huge swarms: workgroups stride over the particles  // up to this many workgroups the last-ticket form wins (one fence each)
 
 __device__ __forceinline__ bool lex_less(double v, long long i, double bv, long long bi)
 {
     return v < bv || (v == bv && i < bi);
 }
 
+// Reduce the nb posted (min fp, index) pairs, write the candidate record and (kTailApply) fold
+// it.  Called by every thread of ONE workgroup; posts and rows written by other workgroups are
+// read through volatile (device-coherent) loads.
+__device__ __forceinline__ void select_final(const TailArgs &a, const double *part_val, const long long *part_idx,
+                                             unsigned nb, double *s_val, long long *s_idx)
+{
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nw = blockDim.x / kWave;
+    const volatile double *pv = part_val;
+    const volatile long long *pi = part_idx;
+    double best = INFINITY;
+    long long bi = 0x7fffffffffffffffLL;
+    for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) {
+        const double v = pv[b];
+        const long long ix = pi[b];
+        if (lex_less(v, ix, best, bi)) {
+            best = v;
+            bi = ix;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(best, off, kWave);
+        const long long oi = __shfl_down(bi, off, kWave);
+        if (lex_less(ob, oi, best, bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    __syncthreads();   // s_val / s_idx are free
+    if (lane == 0) {
+        s_val[wave] = best;
+        s_idx[wave] = bi;
+    }
+    __syncthreads();
+    best = s_val[0];
+    bi = s_idx[0];
+    for (int w = 1; w < nw; ++w)
+        if (lex_less(s_val[w], s_idx[w], best, bi)) {
+            best = s_val[w];
+            bi = s_idx[w];
+        }
+    if (bi >= a.S) bi = 0;   // np.argmin of an all-inf array
+    const volatile double *fpv = a.fp, *ppv = a.p;
+    if (threadIdx.x == 0) a.cand[0] = fpv[bi];
+    for (int64_t d = threadIdx.x; d < a.D; d += blockDim.x) a.cand[1 + d] = ppv[bi * a.D + d];
+    if (a.phases & kTailApply) {
+        __syncthreads();
+        if (wave == 0) apply_wave(lane, a.D, a.nranks, a.is_init, a.minstep, a.minfunc, a.cands, a.flags, a.best);
+    }
+}
+
+// ticket != nullptr: the workgroup that draws the last ticket runs select_final (one launch);
+// ticket == nullptr: posts only, pso_select_final_kernel follows (two launches, no fences).
 __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArgs a, double *part_val,
                                                                           long long *part_idx, unsigned *ticket)
 {
@@ -429,56 +482,26 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
             }
         part_val[blockIdx.x] = b;
         part_idx[blockIdx.x] = bi;
-        __threadfence();   // ... and one device-scope release per workgroup (cumulative) publishes them with the post
-        s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u);
+        s_last = 0;
+        if (ticket) {
+            __threadfence();   // ... and one device-scope release per workgroup (cumulative) publishes them with the post
+            s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u);
+        }
     }
     __syncthreads();
     if (!s_last) return;
     __threadfence();   // acquire: the other workgroups' posts and rows
-    const volatile double *pv = part_val;
-    const volatile long long *pi = part_idx;
-    double best = INFINITY;
-    long long bi = 0x7fffffffffffffffLL;
-    for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
-        const double v = pv[b];
-        const long long ix = pi[b];
-        if (lex_less(v, ix, best, bi)) {
-            best = v;
-            bi = ix;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ob = __shfl_down(best, off, kWave);
-        const long long oi = __shfl_down(bi, off, kWave);
-        if (lex_less(ob, oi, best, bi)) {
-            best = ob;
-            bi = oi;
-        }
-    }
-    __syncthreads();   // s_val / s_idx are free again
-    if (lane == 0) {
-        s_val[wave] = best;
-        s_idx[wave] = bi;
-    }
-    __syncthreads();
-    best = s_val[0];
-    bi = s_idx[0];
-    for (int w = 1; w < kSelectWaves; ++w)
-        if (lex_less(s_val[w], s_idx[w], best, bi)) {
-            best = s_val[w];
-            bi = s_idx[w];
-        }
-    if (bi >= a.S) bi = 0;   // np.argmin of an all-inf array
-    const volatile double *fpv = a.fp, *ppv = a.p;
-    if (threadIdx.x == 0) {
-        a.cand[0] = fpv[bi];
-        *ticket = 0u;        // ready for the next launch
-    }
-    for (int64_t d = threadIdx.x; d < a.D; d += blockDim.x) a.cand[1 + d] = ppv[bi * a.D + d];
-    if (a.phases & kTailApply) {
-        __syncthreads();
-        if (wave == 0) apply_wave(lane, a.D, a.nranks, a.is_init, a.minstep, a.minfunc, a.cands, a.flags, a.best);
-    }
+    if (threadIdx.x == 0) *ticket = 0u;   // ready for the next launch
+    select_final(a, part_val, part_idx, gridDim.x, s_val, s_idx);
+}
+
+__global__ __launch_bounds__(1024) void pso_select_final_kernel(TailArgs a, const double *part_val,
+                                                                const long long *part_idx, unsigned nb)
+{
+    if (a.flags[1] != 0) return;
+    __shared__ double s_val[16];
+    __shared__ long long s_idx[16];
+    select_final(a, part_val, part_idx, nb, s_val, s_idx);
 }
 
 
@@ -566,10 +589,19 @@ int evaluate_and_select(nmrfit_pso *pso, int more = 0, int is_init = 0)
         if (rc != NMRFIT_OK) return rc;
         TailArgs a = tail_args(pso, def, (def.needed ? kTailFinalize : 0) | kTailPbest | kTailArgmin | (more & kTailApply));
         a.is_init = is_init;
-        const unsigned nb = (unsigned)std::min<int64_t>((S + kSelectWaves - 1) / kSelectWaves, kSelectMaxBlocks);
+        // S <= 512: one launch, the last-ticket workgroup finishes; larger: posts, then a
+        // single-workgroup launch (a fence per workgroup would cost more than the launch)
+        const int64_t nb64 = (S + kSelectWaves - 1) / kSelectWaves;
+        const unsigned nb = (unsigned)std::min<int64_t>(nb64, kSelectMaxPosts);
+        const bool ticket = nb <= (unsigned)kSelectTicketBlocks;
         hipLaunchKernelGGL(pso_select_kernel, dim3(nb), dim3(kWave * kSelectWaves), 0, ctx->stream, a, pso->d_part_val,
-                           pso->d_part_idx, pso->d_ticket);
+                           pso->d_part_idx, ticket ? pso->d_ticket : nullptr);
         NMRFIT_HIP(hipGetLastError());
+        if (!ticket) {
+            hipLaunchKernelGGL(pso_select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, pso->d_part_val,
+                               pso->d_part_idx, nb);
+            NMRFIT_HIP(hipGetLastError());
+        }
         return NMRFIT_OK;
     }
     // an empty shard still posts its (+inf, zeros) candidate
@@ -642,7 +674,7 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
     PSO_HIP(hipMalloc((void **)&pso->d_flags, 2 * sizeof(long long)));
     PSO_HIP(hipMalloc((void **)&pso->d_best, (size_t)(2 + 2 * D) * sizeof(double)));
     {
-        const size_t nb = (size_t)kSelectMaxBlocks;
+        const size_t nb = (size_t)kSelectMaxPosts;
         PSO_HIP(hipMalloc((void **)&pso->d_part_val, nb * sizeof(double)));
         PSO_HIP(hipMalloc((void **)&pso->d_part_idx, nb * sizeof(long long)));
         PSO_HIP(hipMalloc((void **)&pso->d_ticket, sizeof(unsigned)));

@@ -12,19 +12,19 @@ import sys
 def main():
     d = sys.argv[1]
     out = {}
-    st = glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv"))
+    st = sorted(glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if st:
-        rows = list(csv.DictReader(open(st[0])))
+        rows = list(csv.DictReader(open(st[-1])))     # newest run of this tag
         out["kernel_stats"] = [{"name": r["Name"].split("(")[0][-60:], "calls": int(r["Calls"]),
                                 "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
                                 "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])} for r in rows[:8]]
     pmc = {}
     for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds"):
-        fs = glob.glob(os.path.join(d, sub, "*", "*_counter_collection.csv"))
+        fs = sorted(glob.glob(os.path.join(d, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
         if not fs:
             continue
         agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(fs[0])):
+        for r in csv.DictReader(open(fs[-1])):
             if "objective_kernel" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():

@@ -21,6 +21,8 @@ model is the last peak's line only); ``fit_im="sum"`` fits the imaginary part of
 import numpy as np
 
 from . import _cabi, equations, proc_autophase, pso
+from .peaks import (AutoPeakSelector, BoundsSelector, Peak, Peaks, find_peak, rnd_data,  # noqa: F401  (reference names:
+                    sample_noise)                                                          # nmrfit.utils.<name>)
 
 
 def compute_weights(w, peaks, expon=0.5):

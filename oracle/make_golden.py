@@ -265,5 +265,67 @@ def main():
     print("done ->", OUT)
 
 
+
+def data_fixtures(mods):
+    """Section 8: the callers either side of the path -- proc_autophase's estimators
+    (proc_autophase.py:39-219), the Data container's scripted methods (containers.py:51-130,
+    219-252) and the deterministic helpers of utils.py (Peaks :14-55, find_peak :819-853,
+    sample_noise :878-902, BoundsSelector.apply_bounds :416-442).  AutoPeakSelector needs
+    peakutils (absent) and scipy.integrate.simps (removed from scipy): not generated."""
+    from nmrfit_amd import synth
+    pa, ut = mods["proc_autophase"], mods["utils"]
+    spec = importlib.util.spec_from_file_location("nmrfit.containers", os.path.join(REF, "containers.py"))
+    cm = importlib.util.module_from_spec(spec)
+    sys.modules["nmrfit.containers"] = cm
+    spec.loader.exec_module(cm)
+    sp = synth.make_spectrum(2048, 3, seed=21, physical=True)
+    w, u, v = sp["w"], sp["u"], sp["v"]
+    z = u + 1j * v
+    out = dict(w=w, u=u, v=v, seed=21)
+    out["ps_deg"] = pa.ps(z, p0=33.0, p1=-71.5)
+    out["ps_deg_inv"] = pa.ps(z, p0=33.0, p1=-71.5, inv=True)
+    phases = np.array([[0.0, 0.0], [17.2, -11.5], [-40.0, 25.0], [5.0, 180.0]])
+    out["score_phases"] = phases
+    out["acme"] = np.array([pa._ps_acme_score(ph, z) for ph in phases])
+    out["peak_minima"] = np.array([pa._ps_peak_minima_score(ph, z) for ph in phases])
+    out["approx_acme"] = np.array(pa.approximate_phase(z, "acme"))
+    out["approx_minima"] = np.array(pa.approximate_phase(z, "peak_minima", p0=5.0, p1=-3.0))
+    out["autops_acme"] = pa.autops(z, "acme")
+    # Data: manual / auto / brute phase, cropping, area helpers
+    d = cm.Data(w.copy(), u.copy(), v.copy())
+    d.shift_phase(method="manual", p0=0.2, p1=-0.1)
+    out["manual_V"], out["manual_I"] = d.V, d.I
+    d.shift_phase(method="auto")
+    out["auto_p"] = np.array([d.p0, d.p1])
+    out["auto_V"] = d.V
+    d.shift_phase(method="brute", step=np.pi / 90)
+    out["brute_p"] = np.array([d.p0, d.p1])
+    out["brute_V"] = d.V
+    d.select_bounds(low=3.2, high=3.8)
+    out["crop_w"], out["crop_u"], out["crop_v"] = d.w, d.u, d.v
+    d.peaks = sp["peaks"]
+    out["areas"] = np.array(d.approximate_areas())
+    out["area_fraction"] = d.approximate_area_fraction()
+    # utils helpers
+    pk = ut.Peaks()
+    for h in (3.0, -0.4, 2.5, 0.3, 0.35):
+        q = ut.Peak()
+        q.height = h
+        pk.append(q)
+    main, sats = pk.split()
+    out["avg_height"] = pk.average_height()
+    out["split_main"] = np.array([q.height for q in main])
+    out["split_sats"] = np.array([q.height for q in sats])
+    V = out["manual_V"]
+    out["find_peak"] = np.array(ut.find_peak(w, V, 3.3, 3.7), dtype=float)
+    out["sample_noise"] = ut.sample_noise(w, V, 3.0, 3.05)
+    np.savez_compressed(os.path.join(OUT, "data_container.npz"), **out)
+    print("data_container fixture: auto phase", out["auto_p"], "brute", out["brute_p"], "truth", sp["x_true"][:2])
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-data" in sys.argv:
+        data_fixtures(load_reference())
+    else:
+        main()
+        data_fixtures(load_reference())

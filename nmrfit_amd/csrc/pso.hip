@@ -3,7 +3,7 @@
 // Replaces pyswarm.pso as nmrfit calls it (nmrfit/utils.py:176-182; pyswarm is a third-party
 // dependency that is not vendored in the reference, github.com/tisimst/pyswarm master,
 // pso.py -- its published algorithm is restated here).  pyswarm evaluates one particle per
-// Python call; here the whole swarm state stays in HBM and a generation is five launches:
+// Python call; here the whole swarm state stays in HBM and a generation is these phases:
 //
 //   update   v = omega*v + phip*rp*(p-x) + phig*rg*(g-x);  x = clip(x+v, lb, ub)
 //   evaluate fx = objective_batch(x)                        (objective.hip)
@@ -17,9 +17,16 @@
 // counter (generation, dimension, GLOBAL particle index): the swarm's trajectory does not
 // depend on how it is sharded.  After a stop is flagged on the device every later launch is
 // a no-op, so the host may poll the flag every k generations without changing the result.
-// Small swarms (S*D <= 2560, e.g. 50 particles x 6 peaks) are launch-bound:
-// for them everything after the objective launch runs in ONE single-workgroup kernel
-// (pso_tail_kernel), two launches per generation instead of six.
+//
+// Every launch costs ~4.8 us on this part however little it does, so the phases are packed
+// into as few launches as the data dependences allow:
+//   S*D <= 2560 (e.g. 50 particles x 6 peaks): objective + ONE single-workgroup kernel for
+//       everything else (pso_tail_kernel)                                        -> 2 launches
+//   S <= 512: update, objective, pso_select_kernel (objective's block sums + pbest + argmin
+//       [+ apply] in a many-workgroup kernel finished by its last-ticket workgroup) -> 3 launches
+//   larger:  the same with the final reduction as its own single-workgroup launch
+//       (a device-scope fence per workgroup would cost more than the launch)     -> 4 launches
+// Multi-rank generations run apply as its own launch after the all-gather.
 #include "nmrfit_internal.h"
 
 #include <algorithm>

@@ -17,6 +17,19 @@ OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4, -5
 FIT_IM_OFF, FIT_IM_REFERENCE, FIT_IM_SUM = 0, 1, 2
 VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED, VARIANT_FARFIELD = 0, 1, 2, 3, 4, 5, 6
+_VARIANT_NAMES = {"default": 0, "baseline": 1, "noskip": 2, "single": 3, "quad": 4, "staged": 5, "farfield": 6}
+
+
+def variant_id(v):
+    """NMRFIT_VARIANT_* number from a name ("farfield") or a number; ValueError otherwise."""
+    if isinstance(v, str):
+        if v.lower() not in _VARIANT_NAMES:
+            raise ValueError("unknown kernel variant %r (one of %s)" % (v, ", ".join(sorted(_VARIANT_NAMES))))
+        return _VARIANT_NAMES[v.lower()]
+    v = int(v)
+    if v not in _VARIANT_NAMES.values():
+        raise ValueError("unknown kernel variant %d" % v)
+    return v
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_void_pp = ctypes.POINTER(ctypes.c_void_p)

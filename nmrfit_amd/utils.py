@@ -10,7 +10,8 @@ Kept verbatim from the reference interface:
   after fit(): weights, params, error.
   options: swarmsize (204), maxiter (2000), omega (-0.2134), phip (-0.3344), phig (2.3259)
            (utils.py:177-181).  Extra opt-in keys: minstep, minfunc (pyswarm's 1e-8 defaults,
-           which the reference does not forward), seed, device, check_every, exchange.
+           which the reference does not forward), seed, device, check_every, exchange, polish,
+           variant (kernel variant by name or number, e.g. "farfield").
 
 ``processes`` is accepted and ignored: the reference's only use of it is to spread the
 per-particle objective calls (and the Kramers-Kronig quadratures of generate_result) over a
@@ -112,6 +113,8 @@ class FitUtility:
         ev = equations.Evaluator(self.data.w, self.data.u, self.data.v, self.weights, device=opt.get('device', 0))
         try:
             ev.set_fit_im(self.fit_im)     # True: the reference's imaginary term (equations.py:197-209)
+            if 'variant' in opt:           # opt-in kernel variant, e.g. "farfield" 
+                ev.set_variant(_cabi.variant_id(opt['variant']))
             if exchange is None or exchange.world == 1:
                 xopt, fopt = pso.pso(ev, self.lower, self.upper, swarmsize=swarmsize, maxiter=maxiter, seed=seed,
                                      check_every=opt.get('check_every', 16), verbose=True, **kw)

@@ -76,3 +76,13 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in text.lower() or fn == "synth.py" and False, \
                     "%s mentions the oracle: product code must not depend on it" % fn
+
+
+def test_variant_names():
+    import pytest
+    assert _cabi.variant_id("farfield") == _cabi.VARIANT_FARFIELD == 6
+    assert _cabi.variant_id("Default") == 0 and _cabi.variant_id(4) == _cabi.VARIANT_QUAD
+    with pytest.raises(ValueError):
+        _cabi.variant_id("fastest")
+    with pytest.raises(ValueError):
+        _cabi.variant_id(9)

@@ -43,3 +43,16 @@ def test_arrays_to_areas():
     V_data, _ = nmrfit_amd.proc_autophase.ps2(sp["u"], sp["v"], res.params[0], res.params[1])
     V_on_fit_grid = np.interp(res.w, sp["w"], V_data)
     assert np.sqrt(np.mean((V_on_fit_grid - res.V) ** 2)) < 0.02 * np.abs(V_data).max()
+
+
+def test_fit_with_the_farfield_variant():
+    """options={"variant": "farfield"}: same swarm, same seed -> the same trajectory to rounding,
+    since the far-field kernel returns the direct kernel's values to ~4e-16."""
+    sp = synth.make_spectrum(4096, 6, seed=12)
+    data = synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"])
+    opts = {"swarmsize": 128, "maxiter": 40, "seed": 4, "minfunc": -1.0, "minstep": -1.0}
+    a = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False, options=opts)
+    b = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False, options=dict(opts, variant="farfield"))
+    assert b.error == pytest.approx(a.error, rel=1e-6)
+    with pytest.raises(ValueError):
+        nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False, options=dict(opts, variant="nope"))

@@ -46,15 +46,21 @@ enum {
 
 /* Kernel variants (numerics identical to <= 1e-12 relative; for A/B measurement). */
 enum {
-    NMRFIT_VARIANT_DEFAULT = 0,   /* tuned fp64: 8 Lorentzians per reciprocal + Gaussian window skip  */
+    NMRFIT_VARIANT_DEFAULT = 0,   /* tuned fp64: 8 Lorentzians per reciprocal + Gaussian window skip
+                                     (+ Gaussian recurrence on uniform grids, see NOREC)              */
     NMRFIT_VARIANT_BASELINE = 1,  /* plain fp64: IEEE divide + libdevice exp2 per unit, no skipping  */
     NMRFIT_VARIANT_NOSKIP = 2,    /* tuned arithmetic, Gaussian evaluated everywhere                 */
     NMRFIT_VARIANT_SINGLE = 3,    /* one reciprocal per unit + Gaussian window skip                  */
     NMRFIT_VARIANT_QUAD = 4,      /* 4 Lorentzians per reciprocal + Gaussian window skip             */
     NMRFIT_VARIANT_STAGED = 5,    /* DEFAULT + LDS-DMA staging of u/v/weights (pays only for P <= 2)  */
-    NMRFIT_VARIANT_FARFIELD = 6   /* opt-in: Lorentzian tails of distant peaks through one shared
+    NMRFIT_VARIANT_FARFIELD = 6,  /* opt-in: Lorentzian tails of distant peaks through one shared
                                      Taylor expansion per 512-point chunk (truncation <= 1e-16 of each
                                      term); not the default because it changes the per-unit work      */
+    NMRFIT_VARIANT_NOREC = 7      /* DEFAULT with one exp2 for every in-window Gaussian on every grid.
+                                     (DEFAULT and FARFIELD objective launches on a uniformly spaced
+                                     grid run the in-window Gaussians of a lane's 8 points as a
+                                     two-multiply recurrence from one seed; f moves by <= 5e-15.
+                                     Residual rows are always evaluated point by point.)                */
 };
 
 /* What the objective compares besides the real part (nmrfit/equations.py:197-209).

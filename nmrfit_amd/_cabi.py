@@ -17,7 +17,9 @@ OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4, -5
 FIT_IM_OFF, FIT_IM_REFERENCE, FIT_IM_SUM = 0, 1, 2
 VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED, VARIANT_FARFIELD = 0, 1, 2, 3, 4, 5, 6
-_VARIANT_NAMES = {"default": 0, "baseline": 1, "noskip": 2, "single": 3, "quad": 4, "staged": 5, "farfield": 6}
+VARIANT_NOREC = 7
+_VARIANT_NAMES = {"default": 0, "baseline": 1, "noskip": 2, "single": 3, "quad": 4, "staged": 5, "farfield": 6,
+                  "norec": 7}
 
 
 def variant_id(v):

@@ -159,6 +159,17 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
     if (const char *tw = getenv("NMRFIT_TARGET_WAVES")) ctx->target_waves = atoll(tw);   // tuning knob
     ctx->w0 = w[N / 2];
     for (int64_t j = 0; j < N; ++j) ctx->wspan = std::fmax(ctx->wspan, std::fabs(w[j] - ctx->w0));
+    // Uniform spacing (np.linspace grids, ascending or descending)?  Measured on the centred
+    // values the kernel sees: deviation of every point from the straight line through the ends.
+    if (N >= 2 * kChunk) {
+        const double first = w[0] - ctx->w0, step = ((w[N - 1] - ctx->w0) - first) / (double)(N - 1);
+        double dev = 0.0;
+        for (int64_t j = 0; j < N; ++j) dev = std::fmax(dev, std::fabs((w[j] - ctx->w0) - (first + (double)j * step)));
+        if (step != 0.0 && dev <= 1.0e-6 * std::fabs(step)) {   // NaN fails the test
+            ctx->lane_step = step * kWave;
+            ctx->grid_dev = 2.0 * dev;
+        }
+    }
     const size_t bytes = (size_t)N * sizeof(double);
     double *d_w_raw = nullptr;
 #define CTX_HIP(call)                                                              \
@@ -246,7 +257,7 @@ int nmrfit_ctx_set_stream(nmrfit_ctx *ctx, void *hip_stream)
 
 int nmrfit_ctx_set_variant(nmrfit_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > NMRFIT_VARIANT_FARFIELD) {
+    if (!ctx || variant < 0 || variant > NMRFIT_VARIANT_NOREC) {
         set_error("bad context or variant");
         return NMRFIT_E_INVALID;
     }

@@ -56,6 +56,8 @@ struct nmrfit_ctx {
     int64_t N = 0;
     double w0 = 0.0;             // centring offset: d_wc[j] = w[j] - w0
     double wspan = 0.0;          // max_j |w[j] - w0|
+    double lane_step = 0.0;      // 64 * grid spacing when the grid is uniformly spaced, else 0 (Gaussian recurrence)
+    double grid_dev = 0.0;       // bound on |(w[j+k] - w[j]) - k*spacing| over the grid (Gaussian recurrence)
     int64_t target_waves = 0;    // launch-geometry override (0 = heuristic)
     double *d_wc = nullptr;      // centred grid
     double *d_u = nullptr, *d_v = nullptr, *d_wt = nullptr;

@@ -290,8 +290,40 @@ __device__ __forceinline__ void gauss_add(const PeakLor *r, const double (&wv)[k
     }
 }
 
+// The same over one FULL chunk of a uniformly spaced grid, by recurrence from the lane's first
+// point: with t[q] = t[0] + q*d (d = 64 grid steps in half-widths) the ratio of successive values
+// is R[q] = 2^-(2 t[q] d + d^2) and the ratio of successive ratios is the constant C = 2^-(2 d^2),
+// so seven of the eight exp2 become two multiplies each.  Valid while nothing leaves the fp64
+// range: |d| <= 2 bounds |t| of every lane of a chunk that touches the window by 8 + 16, i.e.
+// 2^-577 <= 2^-s and R <= 2^100.  The grid's departure from uniform spacing (`devk`, scaled so
+// that |ihw|*devk <= 1 means <= 1e-10 relative on the in-window values; a linspace grid gives
+// ~4e-12) decides per peak when its constants are staged: (d, C) sit in LDS beside the other
+// per-peak records, C = 0 marking a peak that takes the direct form.
+__device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *rec, const double (&wv)[kPointsPerLane],
+                                              double (&acc)[kPointsPerLane])
+{
+    const double2 dc = *rec;     // (d, C), C == 0: this peak takes the direct form
+    if (!__builtin_amdgcn_readfirstlane((int)(dc.y != 0.0))) {   // the same peak in every lane: wave-uniform
+        gauss_add(r, wv, acc);
+        return;
+    }
+    const double ihw = r->ihw, c = r->c, ag2 = r->ag2;
+    const double t0 = __builtin_fma(wv[0], ihw, c);
+    double g = ag2 * exp2_neg(-__builtin_fma(t0, t0, 1.0));
+    double ratio = exp2_neg(-__builtin_fma(t0 + t0, dc.x, dc.x * dc.x));
+    acc[0] += g;
+#pragma unroll
+    for (int q = 1; q < kPointsPerLane; ++q) {
+        g *= ratio;
+        acc[q] += g;
+        if (q + 1 < kPointsPerLane) ratio *= dc.y;
+    }
+}
+
 // ---- the kernel ----------------------------------------------------------------------------
-// VARIANT: NMRFIT_VARIANT_DEFAULT  8 Lorentzians per reciprocal + Gaussian window skip
+// VARIANT: NMRFIT_VARIANT_DEFAULT  8 Lorentzians per reciprocal + Gaussian window skip (+ on uniform
+//                                  grids the Gaussian recurrence, objective launches only)
+//          NMRFIT_VARIANT_NOREC    the same without the recurrence
 //          NMRFIT_VARIANT_STAGED   the same + u/v/weights of each chunk prefetched into LDS by
 //                                  global_load_lds (LDS-DMA) and w of the next chunk into
 //                                  registers: hides the load latency when there are very few
@@ -313,11 +345,11 @@ template <int VARIANT, bool WRITE_R, int FIT_IM>
 // ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
 // With the imaginary part the epilogue also evaluates dispersion lines (Dawson polynomials):
 // 2 waves per SIMD rather than spilling.
-__global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_STAGED || VARIANT == NMRFIT_VARIANT_FARFIELD) ? NMRFIT_MIN_WAVES : 4) void objective_kernel(
+__global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_STAGED || VARIANT == NMRFIT_VARIANT_FARFIELD || VARIANT == NMRFIT_VARIANT_NOREC) ? NMRFIT_MIN_WAVES : 4) void objective_kernel(
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax,
     const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, double wspan, int nseg,
-    int64_t seg_len, int blk_chunks,
+    int64_t seg_len, int blk_chunks, double lane_step, double rec_devk,
     double *__restrict__ out,       // nseg == 1: f[S];  else per-block sums [S * n_blocks] (x2 with FIT_IM)
     double *__restrict__ R_out)     // WRITE_R: residual rows [S*N]
 {
@@ -338,6 +370,15 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     // (shares the offset of `stage`; the two variants are exclusive)
     double *ffs = reinterpret_cast<double *>(lds_tail + (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2)) +
                   (size_t)wave * (kFarTerms * kFarPad);
+
+    // objective launches of DEFAULT / FARFIELD: per-peak (d, C) of the Gaussian recurrence, after
+    // everything else (residual rows are evaluated point by point: they feed finite differences)
+    constexpr bool kRec = !WRITE_R && (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_FARFIELD);
+    double2 *grec = reinterpret_cast<double2 *>(
+                        lds_tail + (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2) +
+                        (kStage ? (size_t)kWavesPerBlock * 3 * kChunk * sizeof(double)
+                                : (VARIANT == NMRFIT_VARIANT_FARFIELD) ? (size_t)kWavesPerBlock * kFarTerms * kFarPad * sizeof(double) : 0)) +
+                    (size_t)wave * P;
 
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const bool active = g < S * nseg;
@@ -367,6 +408,11 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
         const double gw = kGaussWindow * fabs(width);
         const double wlo = locc - gw, whi = locc + gw;
         win[k] = PeakWin{(float)(wlo - fabs(wlo) * 1.2e-7 - 1e-37), (float)(whi + fabs(whi) * 1.2e-7 + 1e-37)};
+        if (kRec) {
+            const double d = lane_step * it;
+            const bool ok = (lane_step != 0.0) && (fabs(d) <= 2.0) && (fabs(it) * rec_devk <= 1.0);
+            grec[k] = make_double2(d, ok ? exp2_neg(-2.0 * d * d) : 0.0);
+        }
     }
     __syncthreads();
     if (!active) return;
@@ -564,7 +610,11 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                     for (int n = 0; n < kFarTerms; ++n) cf[n] = src[n];
                     ff_odd = !ff_odd;
                     for (unsigned m = near_c; m; m &= m - 1) lorentz_group<1>(lor + __builtin_ctz(m), wv, acc);
-                    for (unsigned m = hits_c; m; m &= m - 1) gauss_add(lor + __builtin_ctz(m), wv, acc);
+                    if (kRec && full) {
+                        for (unsigned m = hits_c; m; m &= m - 1) gauss_add_rec(lor + __builtin_ctz(m), grec + __builtin_ctz(m), wv, acc);
+                    } else {
+                        for (unsigned m = hits_c; m; m &= m - 1) gauss_add(lor + __builtin_ctz(m), wv, acc);
+                    }
                 } else {
                 double csum = 0.0;    // lane l: coefficient of order l >> 2 (all 4 lanes of a quad)
                 for (int kb = 0; kb < P; kb += kWave) {
@@ -620,8 +670,13 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                     }
                     for (unsigned long long m = nearmask; m; m &= m - 1)
                         lorentz_group<1>(lor + kb + __builtin_ctzll(m), wv, acc);
-                    for (unsigned long long m = hits; m; m &= m - 1)
-                        gauss_add(lor + kb + __builtin_ctzll(m), wv, acc);
+                    for (unsigned long long m = hits; m; m &= m - 1) {
+                        const int k1 = kb + __builtin_ctzll(m);
+                        if (kRec && full)
+                            gauss_add_rec(lor + k1, grec + k1, wv, acc);
+                        else
+                            gauss_add(lor + k1, wv, acc);
+                    }
                 }
                 // broadcast the kFarTerms sums through LDS and evaluate them at the lane's points
                 if ((lane & 3) == 0) ffs[lane >> 2] = csum;
@@ -659,6 +714,12 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                 for (; k + kGroup <= kend; k += kGroup) lorentz_group<kGroup>(lor + k, wv, acc);
                 if (k < kend) lorentz_tail<kGroup>(kend - k, lor + k, wv, acc);   // one smaller group
                 if (kend - kb < kWave) hits &= (1ull << (kend - kb)) - 1ull;
+                if (kRec && full) {
+                    for (unsigned long long m = hits; m; m &= m - 1) {
+                        const int k1 = kb + __builtin_ctzll(m);
+                        gauss_add_rec(lor + k1, grec + k1, wv, acc);
+                    }
+                } else
                 for (unsigned long long m = hits; m; m &= m - 1) gauss_add(lor + kb + __builtin_ctzll(m), wv, acc);
             }
         }
@@ -842,18 +903,19 @@ int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, doub
 #define NMRFIT_LAUNCH(WR, FI)                                                                                   \
     hipLaunchKernelGGL((objective_kernel<VARIANT, WR, FI>), dim3((unsigned)blocks), dim3(kBlock), lds,         \
                        ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,     \
-                       ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, blk_chunks, out, dR)
+                       ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, blk_chunks, ctx->lane_step,                 \
+                       ctx->grid_dev * 11.0e10, out, dR)
     if (dR) {
         NMRFIT_LAUNCH(true, 0);
     } else if (fit_im == 0) {
         NMRFIT_LAUNCH(false, 0);
-    } else if constexpr (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_STAGED) {
+    } else if constexpr (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_STAGED || VARIANT == NMRFIT_VARIANT_NOREC) {
         if (fit_im == 1)
             NMRFIT_LAUNCH(false, 1);
         else
             NMRFIT_LAUNCH(false, 2);
     } else {
-        set_error("fit_im is implemented for the DEFAULT kernel variant only");
+        set_error("fit_im is implemented for the DEFAULT, NOREC and STAGED kernel variants only");
         return NMRFIT_E_UNSUPPORTED;
     }
 #undef NMRFIT_LAUNCH
@@ -920,10 +982,15 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     int variant = ctx->variant;
     if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
     const size_t lds_far = (size_t)kWavesPerBlock * kFarTerms * kFarPad * sizeof(double);
-    if (variant == NMRFIT_VARIANT_FARFIELD && (lds_recs + lds_far > 160 * 1024 || fit_im != 0))
-        variant = NMRFIT_VARIANT_DEFAULT;   // P > ~800, or the imaginary part (direct kernel only)
+    // Gaussian recurrence constants (d, C) per peak: objective launches of DEFAULT / FARFIELD
+    const size_t lds_rec = dR ? 0 : (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(double2);
+    if (variant == NMRFIT_VARIANT_FARFIELD && (lds_recs + lds_far + lds_rec > 160 * 1024 || fit_im != 0))
+        variant = NMRFIT_VARIANT_DEFAULT;   // P > ~600, or the imaginary part (direct kernel only)
+    if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_rec > 160 * 1024)
+        variant = NMRFIT_VARIANT_NOREC;     // P > ~700: no room for the recurrence records
     const size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
-                       (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : 0);
+                       (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : 0) +
+                       ((variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_DEFAULT) ? lds_rec : 0);
     double *out = df;
     if (nseg > 1) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));
@@ -946,6 +1013,9 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
             break;
         case NMRFIT_VARIANT_FARFIELD:
             rc = launch_variant<NMRFIT_VARIANT_FARFIELD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
+            break;
+        case NMRFIT_VARIANT_NOREC:
+            rc = launch_variant<NMRFIT_VARIANT_NOREC>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
             break;
         case NMRFIT_VARIANT_STAGED:
             rc = launch_variant<NMRFIT_VARIANT_STAGED>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 RTOL_F = 1e-9
 F_FLOOR = 1e-6
 VARIANTS = [_cabi.VARIANT_DEFAULT, _cabi.VARIANT_BASELINE, _cabi.VARIANT_NOSKIP, _cabi.VARIANT_SINGLE,
-            _cabi.VARIANT_QUAD, _cabi.VARIANT_STAGED, _cabi.VARIANT_FARFIELD]
+            _cabi.VARIANT_QUAD, _cabi.VARIANT_STAGED, _cabi.VARIANT_FARFIELD, _cabi.VARIANT_NOREC]
 
 
 def _close_f(f, ref, rtol=RTOL_F):

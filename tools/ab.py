@@ -4,6 +4,9 @@ rounds, median and min reported (perf deltas from separate runs or boxes are not
 devices differ by several per cent).  Usage:
     NMRFIT_LIBNAME=libab_i2.so nmrfit_amd/csrc/build.sh -DNMRFIT_INTERLEAVE=2
     python tools/ab.py nmrfit_amd/lib/libnmrfit_amd.so nmrfit_amd/lib/libab_i2.so [--variant 0] [--workload C3]
+A spec may carry its own variant after a colon (same build, two kernel variants):
+    python tools/ab.py nmrfit_amd/lib/libnmrfit_amd.so:0 nmrfit_amd/lib/libnmrfit_amd.so:7
+Also prints the largest relative difference of f from the first spec's values.
 """
 import argparse, ctypes, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,13 +33,18 @@ def main():
     cfg = synth.CONFIGS[a.workload]
     sp = synth.make_spectrum(cfg.N, cfg.P, seed=1)
     X = synth.make_swarm(sp["lower"], sp["upper"], cfg.S, seed=2, x_true=sp["x_true"])
-    libs = [load(p) for p in a.libs]
+    import numpy as np
+    paths = [p.rsplit(":", 1)[0] if p.rsplit(":", 1)[-1].isdigit() else p for p in a.libs]
+    variants = [int(p.rsplit(":", 1)[1]) if p.rsplit(":", 1)[-1].isdigit() else a.variant for p in a.libs]
+    handles = {}
+    libs = [handles.setdefault(q, load(q)) if q not in handles else handles[q] for q in paths]
     times = {p: [] for p in a.libs}
+    values = {}
     for r in range(a.rounds):
-        for p, L in zip(a.libs, libs):
+        for p, L, var in zip(a.libs, libs, variants):
             _cabi._LIB = L
             with Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
-                ev.set_variant(a.variant)
+                ev.set_variant(var)
                 dX = ev.dev_alloc(X.nbytes); df = ev.dev_alloc(8 * cfg.S)
                 ev.upload(dX, X)
                 for _ in range(3):
@@ -46,11 +54,14 @@ def main():
                 for _ in range(a.reps):
                     ev.objective_batch_dev(cfg.S, cfg.P, dX, df)
                 times[p].append(ev.timer_end() / a.reps)
+                values[p] = ev.download(df, (cfg.S,))
                 ev.dev_free(dX); ev.dev_free(df)
     base = statistics.median(times[a.libs[0]])
     for p in a.libs:
         t = times[p]
-        print("%-44s median %.4f ms  min %.4f  max %.4f  (%.3fx of first)" % (os.path.basename(p), statistics.median(t), min(t), max(t), statistics.median(t) / base))
+        diff = float(np.max(np.abs(values[p] - values[a.libs[0]]) / np.maximum(np.abs(values[a.libs[0]]), 1e-6)))
+        print("%-44s median %.4f ms  min %.4f  max %.4f  (%.3fx of first)  max rel diff of f %.2e" % (
+            os.path.basename(p), statistics.median(t), min(t), max(t), statistics.median(t) / base, diff))
 
 
 if __name__ == "__main__":

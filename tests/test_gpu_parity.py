@@ -434,3 +434,48 @@ def test_source_derived_properties_on_the_gpu(eq):
     Xr[:, 1] = -X[:, 1]
     with eq.Evaluator(sp["w"][::-1], sp["u"][::-1], sp["v"][::-1], sp["weights"][::-1]) as ev:
         np.testing.assert_allclose(ev.objective_batch(Xr), f0, rtol=1e-10)
+
+
+def test_gaussian_recurrence_against_point_by_point(eq):
+    """DEFAULT runs the in-window Gaussians of a uniformly spaced grid by recurrence; NOREC is the
+    same kernel with one exp2 per point.  Scan line widths across the |d| <= 2 switch (d = 64 grid
+    steps in half-widths), ascending / descending / jittered / non-uniform grids, pure Gaussians
+    (r = 0, the worst case for the recurrence) and the ragged tail: f agrees to 1e-12."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(8)
+    N = 40000 + 77                                   # ragged tail chunk
+    grids = {
+        "ascending": np.linspace(3.0, 4.0, N),
+        "descending": np.linspace(4.0, 3.0, N),
+        "jitter 1e-9 of a step": np.linspace(3.0, 4.0, N) + 1e-9 / N * rng.standard_normal(N),
+        "non-uniform": np.sort(rng.uniform(3.0, 4.0, N)),
+        "far from zero": np.linspace(3.0e3, 3.0e3 + 1.0, N),
+    }
+    step = 1.0 / (N - 1)
+    for name, w in grids.items():
+        u, v = rng.standard_normal(N), rng.standard_normal(N)
+        wt = 0.5 + rng.random(N)
+        P, S = 9, 12
+        X = np.empty((S, 4 + 3 * P))
+        X[:, 0:2] = rng.uniform(-1, 1, (S, 2))
+        X[:, 2] = np.linspace(0.0, 1.0, S)                       # from pure Gaussian to pure Lorentzian
+        X[:, 3] = 0.001
+        # widths from 8 to 4000 grid steps: d = 128 step / width runs from 16 down to 0.03
+        X[:, 4::3] = step * 2.0 ** rng.uniform(3, 12, (S, P))
+        X[:, 5::3] = rng.uniform(w.min(), w.max(), (S, P))
+        X[:, 6::3] = rng.uniform(0.5, 2.0, (S, P)) * X[:, 4::3] * 100
+        with eq.Evaluator(w, u, v, wt) as ev:
+            f = ev.objective_batch(X)
+            ev.set_variant(_cabi.VARIANT_FARFIELD)
+            ff = ev.objective_batch(X)
+            ev.set_variant(_cabi.VARIANT_NOREC)
+            f_direct = ev.objective_batch(X)
+            Rrow = ev.residual_batch(X[:2])
+            ev.set_variant(_cabi.VARIANT_DEFAULT)
+            np.testing.assert_array_equal(ev.residual_batch(X[:2]), Rrow)        # rows: always point by point
+        np.testing.assert_allclose(f, f_direct, rtol=1e-12, err_msg=name)
+        np.testing.assert_allclose(ff, f_direct, rtol=1e-12, err_msg=name)
+        ref = c_oracle.objective_batch(X, w, u, v, wt, threads=8)
+        _close_f(f, ref)
+        if name == "non-uniform":
+            np.testing.assert_array_equal(f, f_direct)                           # the recurrence is off

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Point-by-point accuracy of the kernel variants on C3: residual rows and f of DEFAULT (0), NOREC (7)
+and FARFIELD (6) against BASELINE (IEEE divide + libdevice exp2).  Run on the GPU box."""
 import sys; sys.path.insert(0, ".")
 import numpy as np
 from nmrfit_amd import _cabi, synth, equations as eq

@@ -20,7 +20,7 @@ def problem():
     ev.close()
 
 
-@pytest.mark.parametrize("S", [100, 204, 700, 4099])   # 100 x 13: fused single-workgroup tail; larger: the many-workgroup select kernel
+@pytest.mark.parametrize("S", [100, 204, 512, 516, 700, 4099])   # 100 x 13: fused single-workgroup tail; larger: the many-workgroup select kernel
 def test_device_swarm_matches_numpy_mirror_bitwise(problem, S):
     """Same Philox stream, same IEEE update arithmetic (no FMA contraction in the swarm
     kernels), same objective values (the mirror evaluates through the same GPU kernel with

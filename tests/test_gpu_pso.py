@@ -263,3 +263,26 @@ def test_device_swarm_wide_parameter_vectors(S, P):
         np.testing.assert_array_equal(dev2.state()["x"], dev.state()["x"])
         assert dev2.best()[1] == dev.best()[1]
         dev.close(); dev2.close()
+
+
+def test_ticket_select_long_run(problem):
+    """600 generations through nmrfit_pso_run at S = 512 (the last-ticket select kernel with its
+    cross-workgroup hand-over, 128 workgroups) against the numpy mirror stepped on the host: any
+    stale read of another workgroup's personal bests would show up as a diverging trajectory."""
+    sp, ev = problem
+    S, seed, gens = 512, 19, 600
+    dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+    host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+    dev.run(gens, check_every=200)
+    host.init()
+    host.apply_global(host.candidate()[None, :])
+    for _ in range(gens):
+        host.step_local()
+        host.apply_global(host.candidate()[None, :])
+    st = dev.state()
+    for k in ("p", "fp", "fx"):
+        np.testing.assert_array_equal(st[k], getattr(host, k), err_msg=k)
+    xb, fb = dev.best()
+    np.testing.assert_array_equal(xb, host.best_x)
+    assert fb == host.best_f and dev.status()["iteration"] == gens
+    dev.close()

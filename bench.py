@@ -279,6 +279,19 @@ def main():
                 traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # VALU counters of the same command under rocprofv3 (separate --pmc pass), when committed
+        valu_pmc = {}
+        summ = os.path.join(ROOT, "profiles", "r01", "bench_c3_pmc_summary.json")
+        if args.workload == "C3" and args.variant == 0 and os.path.exists(summ):
+            try:
+                sm = json.load(open(summ))
+                insts = sm["objective_kernel_pmc"]["SQ_INSTS_VALU"]["mean"]
+                valu_pmc = {"valu_busy_frac_pmc": sm.get("valu_busy_frac"),
+                            "valu_instructions_per_unit_pmc": insts * 64.0 / (4096.0 * 65536.0 * 24.0),
+                            "valu_cycles_per_instruction_pmc": sm.get("valu_cycles_per_inst"),
+                            "pmc_source": "profiles/r01/bench_c3_pmc_summary.json"}
+            except Exception:
+                valu_pmc = {}
         line = {
             "metric": "objective evals/sec (swarm x grid x peaks)",
             "value": value, "unit": "particle*gridpoint*peak/s",
@@ -301,7 +314,7 @@ def main():
             "valu": {"units_per_s_kernel": units_launch / (t_kernel_ms * 1e-3),
                      "fp64_lane_ops_peak_per_s": FP64_VALU_PEAK_TFLOPS * 1e12 / 2,
                      "note": "binding resource is fp64 vector-ALU issue; see DESIGN.md for the per-unit "
-                             "instruction count and the measured per-instruction costs"},
+                             "instruction count and the measured per-instruction costs", **valu_pmc},
         }
         if farfield is not None:
             line["farfield_variant"] = farfield

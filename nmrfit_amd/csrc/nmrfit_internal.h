@@ -26,6 +26,13 @@ struct PeakLor {
     double al;    // area*r*(2/(pi*width))    Lorentzian amplitude
     double ag2;   // 2*area*(1-r)*(2/width)*sqrt(ln2/pi)   Gaussian amplitude, factor 2 folds exp2(1)
 };
+struct PeakFast {   // the same Lorentzian as a plain reciprocal: al/(1+t^2) = 1/(ia + t'^2)
+    double ihs;   // ihw / sqrt(al)
+    double cs;    // c / sqrt(al)             so that t' = (w_j - w0)*ihs + cs = t / sqrt(al)
+    double ia;    // 1 / al
+    double ok;    // (first peak of a group of 8) != 0: every peak of the group has al > 0 and the
+                  // product of the eight denominators stays inside the fp64 range
+};
 struct PeakWin {
     float lo;     // (loc - w0) - G*width     the Gaussian is < 2^-64 of its amplitude outside [lo, hi]
     float hi;     // (f32, rounded outwards: 8 B per peak keep three workgroups per CU at P = 24)

@@ -58,6 +58,9 @@ constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 #ifndef NMRFIT_GROUP
 #define NMRFIT_GROUP 8
 #endif
+#ifndef NMRFIT_FASTPAIR
+#define NMRFIT_FASTPAIR 1     // two-operation pair form for groups of positive Lorentzian amplitudes
+#endif
 #ifndef NMRFIT_MIN_WAVES
 #define NMRFIT_MIN_WAVES 3
 #endif
@@ -264,6 +267,43 @@ __device__ __forceinline__ void lorentz_group(const PeakLor *r, const double (&w
     }
 }
 
+// The same group when every amplitude is positive: al/(1+t^2) = 1/s', s' = ia + t'^2 with
+// t' = t/sqrt(al), ia = 1/al (scaled constants staged beside the plain ones).  A pair of plain
+// reciprocals combines in TWO operations, 1/s0 + 1/s1 = (s0 + s1)/(s0 s1), instead of three,
+// so a group of 8 costs 16 + 8 + 6 + 3 + 4 = 37 operations per point instead of 41.  Staging
+// marks the groups for which this is safe (PeakFast::ok); the others take lorentz_group.
+template <int G>
+__device__ __forceinline__ void lorentz_group_fast(const PeakFast *r, const double (&wv)[kPointsPerLane],
+                                                   double (&acc)[kPointsPerLane])
+{
+    static_assert(G % 2 == 0, "pairs");
+    double ih[G], c[G], ia[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        ih[g] = r[g].ihs;
+        c[g] = r[g].cs;
+        ia[g] = r[g].ia;
+    }
+    constexpr int kInterleave = NMRFIT_INTERLEAVE;
+#pragma unroll
+    for (int q = 0; q < kPointsPerLane; ++q) {
+        double pn[G / 2], pd[G / 2];
+#pragma unroll
+        for (int g = 0; g < G; g += 2) {
+            const double t0 = __builtin_fma(wv[q], ih[g], c[g]);
+            const double t1 = __builtin_fma(wv[q], ih[g + 1], c[g + 1]);
+            const double s0 = __builtin_fma(t0, t0, ia[g]);
+            const double s1 = __builtin_fma(t1, t1, ia[g + 1]);
+            pn[g / 2] = s0 + s1;
+            pd[g / 2] = s0 * s1;
+        }
+        double num, den;
+        lorentz_tree<G / 2, 0, G / 2>(pn, pd, num, den);
+        acc[q] = __builtin_fma(num, rcp64(den), acc[q]);
+        if ((q + 1) % kInterleave == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // group of a run-time size 1..GMAX-1 (tail of a pass)
 template <int GMAX>
 __device__ __forceinline__ void lorentz_tail(int n, const PeakLor *r, const double (&wv)[kPointsPerLane],
@@ -380,6 +420,12 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                                 : (VARIANT == NMRFIT_VARIANT_FARFIELD) ? (size_t)kWavesPerBlock * kFarTerms * kFarPad * sizeof(double) : 0)) +
                     (size_t)wave * P;
 
+    // DEFAULT: scaled Lorentzian constants for the two-operation pair form, after grec
+    constexpr bool kFast = (NMRFIT_FASTPAIR != 0) && (VARIANT == NMRFIT_VARIANT_DEFAULT) && (NMRFIT_GROUP == 8);
+    PeakFast *lorf = reinterpret_cast<PeakFast *>(reinterpret_cast<unsigned char *>(grec - (size_t)wave * P) +
+                                                  (kRec ? (size_t)kWavesPerBlock * P * sizeof(double2) : 0)) +
+                     (size_t)wave * P;
+
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const bool active = g < S * nseg;
     const int64_t particle = active ? g / nseg : 0;
@@ -408,6 +454,28 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
         const double gw = kGaussWindow * fabs(width);
         const double wlo = locc - gw, whi = locc + gw;
         win[k] = PeakWin{(float)(wlo - fabs(wlo) * 1.2e-7 - 1e-37), (float)(whi + fabs(whi) * 1.2e-7 + 1e-37)};
+        if (kFast) {
+            // exponent budget of the group's denominator: s' <= (1 + tmax^2)/al, s' >= 1/al
+            const double al = rec.al;
+            const double tmax = fabs(it) * (wspan + fabs(locc));
+            const bool pos = al > 0.0 && al < 1.0e300;                  // false for NaN
+            const double ia = pos ? 1.0 / al : 1.0;
+            const double rs = pos ? sqrt(ia) : 1.0;
+            int ehi = pos ? ilogb(__builtin_fma(tmax, tmax, 1.0) * ia) + 2 : 100000;
+            int elo = pos ? ilogb(ia) : -100000;
+            if (ehi > 100000) ehi = 100000;                              // inf / overflow
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) {
+                ehi += __shfl_xor(ehi, m, kWave);
+                elo += __shfl_xor(elo, m, kWave);
+            }
+            // the whole group of 8 must exist (k | 7 < P) and stay within 2^+-1000
+            const bool ok = ((k | 7) < P) && ehi < 1000 && elo > -1000;
+            // cs from the ROUNDED ihs (one rounding, like c from ihw): the zero of t' then sits at
+            // loc to the same accuracy as the zero of t
+            const double ihs = it * rs;
+            lorf[k] = PeakFast{ihs, -locc * ihs, ia, ok ? 1.0 : 0.0};
+        }
         if (kRec) {
             const double d = lane_step * it;
             const bool ok = (lane_step != 0.0) && (fabs(d) <= 2.0) && (fabs(it) * rec_devk <= 1.0);
@@ -711,7 +779,15 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                 // Lorentzians first, in straight-line groups; then the (few) Gaussians whose
                 // window touches this chunk, one scalar loop over the set bits of the mask
                 int k = kb;
-                for (; k + kGroup <= kend; k += kGroup) lorentz_group<kGroup>(lor + k, wv, acc);
+                for (; k + kGroup <= kend; k += kGroup) {
+                    if constexpr (kFast) {
+                        if (__builtin_amdgcn_readfirstlane((int)(lorf[k].ok != 0.0))) {
+                            lorentz_group_fast<kGroup>(lorf + k, wv, acc);
+                            continue;
+                        }
+                    }
+                    lorentz_group<kGroup>(lor + k, wv, acc);
+                }
                 if (k < kend) lorentz_tail<kGroup>(kend - k, lor + k, wv, acc);   // one smaller group
                 if (kend - kb < kWave) hits &= (1ull << (kend - kb)) - 1ull;
                 if (kRec && full) {
@@ -986,11 +1062,14 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     const size_t lds_rec = dR ? 0 : (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(double2);
     if (variant == NMRFIT_VARIANT_FARFIELD && (lds_recs + lds_far + lds_rec > 160 * 1024 || fit_im != 0))
         variant = NMRFIT_VARIANT_DEFAULT;   // P > ~600, or the imaginary part (direct kernel only)
-    if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_rec > 160 * 1024)
-        variant = NMRFIT_VARIANT_NOREC;     // P > ~700: no room for the recurrence records
+    const size_t lds_fast = (NMRFIT_FASTPAIR != 0 && NMRFIT_GROUP == 8)
+                                ? (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(PeakFast) : 0;
+    if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_rec + lds_fast > 160 * 1024)
+        variant = NMRFIT_VARIANT_NOREC;     // P > ~450: no room for the recurrence / scaled records
     const size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
                        (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : 0) +
-                       ((variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_DEFAULT) ? lds_rec : 0);
+                       ((variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_DEFAULT) ? lds_rec : 0) +
+                       (variant == NMRFIT_VARIANT_DEFAULT ? lds_fast : 0);
     double *out = df;
     if (nseg > 1) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));

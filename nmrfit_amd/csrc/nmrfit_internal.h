@@ -30,8 +30,7 @@ struct PeakFast {   // the same Lorentzian as a plain reciprocal: al/(1+t^2) = 1
     double ihs;   // ihw / sqrt(al)
     double cs;    // c / sqrt(al)             so that t' = (w_j - w0)*ihs + cs = t / sqrt(al)
     double ia;    // 1 / al
-    double ok;    // (first peak of a group of 8) != 0: every peak of the group has al > 0 and the
-                  // product of the eight denominators stays inside the fp64 range
+    double pad;   // (32 B records: one ds_read_b128 + one ds_read_b64 per peak, like PeakLor)
 };
 struct PeakWin {
     float lo;     // (loc - w0) - G*width     the Gaussian is < 2^-64 of its amplitude outside [lo, hi]

@@ -337,16 +337,14 @@ __device__ __forceinline__ void gauss_add(const PeakLor *r, const double (&wv)[k
 // range: |d| <= 2 bounds |t| of every lane of a chunk that touches the window by 8 + 16, i.e.
 // 2^-577 <= 2^-s and R <= 2^100.  The grid's departure from uniform spacing (`devk`, scaled so
 // that |ihw|*devk <= 1 means <= 1e-10 relative on the in-window values; a linspace grid gives
-// ~4e-12) decides per peak when its constants are staged: (d, C) sit in LDS beside the other
-// per-peak records, C = 0 marking a peak that takes the direct form.
+// ~4e-12) decides when the constants are staged: (d, C) sit in LDS beside the other per-peak
+// records, and ONE flag per particle says whether every peak qualifies -- the recurrence and the
+// direct form then run as two separate loops (a branch per peak would make the compiler copy the
+// eight accumulators on every arm).
 __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *rec, const double (&wv)[kPointsPerLane],
                                               double (&acc)[kPointsPerLane])
 {
-    const double2 dc = *rec;     // (d, C), C == 0: this peak takes the direct form
-    if (!__builtin_amdgcn_readfirstlane((int)(dc.y != 0.0))) {   // the same peak in every lane: wave-uniform
-        gauss_add(r, wv, acc);
-        return;
-    }
+    const double2 dc = *rec;     // (d, C)
     const double ihw = r->ihw, c = r->c, ag2 = r->ag2;
     const double t0 = __builtin_fma(wv[0], ihw, c);
     double g = ag2 * exp2_neg(-__builtin_fma(t0, t0, 1.0));
@@ -436,6 +434,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     const double p0 = x[0], p1 = x[1], r = x[2], yoff = x[3];   // equations.py:177
 
     // stage this particle's per-peak constants in the wave's LDS slices
+    bool fast_bad = false, rec_bad = false;
     for (int k = lane; k < P; k += kWave) {
         const double width = x[4 + 3 * k], loc = x[5 + 3 * k], a = x[6 + 3 * k];
         const double ihw = 2.0 / width;
@@ -469,19 +468,27 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                 ehi += __shfl_xor(ehi, m, kWave);
                 elo += __shfl_xor(elo, m, kWave);
             }
-            // the whole group of 8 must exist (k | 7 < P) and stay within 2^+-1000
-            const bool ok = ((k | 7) < P) && ehi < 1000 && elo > -1000;
+            // a whole group of 8 (k | 7 < P; the short tail group always takes the general form)
+            // must stay within 2^+-1000; ONE flag per particle -- every whole group qualifies or
+            // none does -- keeps the chunk loop free of a per-group branch (whose two arms cost
+            // 16 register copies per group in phi moves: measured, it ate the gain)
+            const bool whole = (k | 7) < P;
+            if (whole && !(ehi < 1000 && elo > -1000)) fast_bad = true;
             // cs from the ROUNDED ihs (one rounding, like c from ihw): the zero of t' then sits at
             // loc to the same accuracy as the zero of t
             const double ihs = it * rs;
-            lorf[k] = PeakFast{ihs, -locc * ihs, ia, ok ? 1.0 : 0.0};
+            lorf[k] = PeakFast{ihs, -locc * ihs, ia, 0.0};
         }
         if (kRec) {
             const double d = lane_step * it;
             const bool ok = (lane_step != 0.0) && (fabs(d) <= 2.0) && (fabs(it) * rec_devk <= 1.0);
+            if (!ok) rec_bad = true;
             grec[k] = make_double2(d, ok ? exp2_neg(-2.0 * d * d) : 0.0);
         }
     }
+    // wave-uniform: every whole group of this particle may take the two-operation pair form
+    const bool fast_all = kFast && (__ballot(fast_bad) == 0ull);
+    const bool rec_all = kRec && (__ballot(rec_bad) == 0ull);   // every peak may take the Gaussian recurrence
     __syncthreads();
     if (!active) return;
 
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                     for (int n = 0; n < kFarTerms; ++n) cf[n] = src[n];
                     ff_odd = !ff_odd;
                     for (unsigned m = near_c; m; m &= m - 1) lorentz_group<1>(lor + __builtin_ctz(m), wv, acc);
-                    if (kRec && full) {
+                    if (kRec && full && rec_all) {
                         for (unsigned m = hits_c; m; m &= m - 1) gauss_add_rec(lor + __builtin_ctz(m), grec + __builtin_ctz(m), wv, acc);
                     } else {
                         for (unsigned m = hits_c; m; m &= m - 1) gauss_add(lor + __builtin_ctz(m), wv, acc);
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                         lorentz_group<1>(lor + kb + __builtin_ctzll(m), wv, acc);
                     for (unsigned long long m = hits; m; m &= m - 1) {
                         const int k1 = kb + __builtin_ctzll(m);
-                        if (kRec && full)
+                        if (kRec && full && rec_all)
                             gauss_add_rec(lor + k1, grec + k1, wv, acc);
                         else
                             gauss_add(lor + k1, wv, acc);
@@ -779,18 +786,15 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                 // Lorentzians first, in straight-line groups; then the (few) Gaussians whose
                 // window touches this chunk, one scalar loop over the set bits of the mask
                 int k = kb;
-                for (; k + kGroup <= kend; k += kGroup) {
-                    if constexpr (kFast) {
-                        if (__builtin_amdgcn_readfirstlane((int)(lorf[k].ok != 0.0))) {
-                            lorentz_group_fast<kGroup>(lorf + k, wv, acc);
-                            continue;
-                        }
-                    }
-                    lorentz_group<kGroup>(lor + k, wv, acc);
+                if (fast_all) {
+                    if constexpr (kFast)
+                        for (; k + kGroup <= kend; k += kGroup) lorentz_group_fast<kGroup>(lorf + k, wv, acc);
+                } else {
+                    for (; k + kGroup <= kend; k += kGroup) lorentz_group<kGroup>(lor + k, wv, acc);
                 }
                 if (k < kend) lorentz_tail<kGroup>(kend - k, lor + k, wv, acc);   // one smaller group
                 if (kend - kb < kWave) hits &= (1ull << (kend - kb)) - 1ull;
-                if (kRec && full) {
+                if (kRec && full && rec_all) {
                     for (unsigned long long m = hits; m; m &= m - 1) {
                         const int k1 = kb + __builtin_ctzll(m);
                         gauss_add_rec(lor + k1, grec + k1, wv, acc);

@@ -58,12 +58,16 @@ constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 #ifndef NMRFIT_GROUP
 #define NMRFIT_GROUP 8
 #endif
+#ifndef NMRFIT_BATCHINV
+#define NMRFIT_BATCHINV 4     // points sharing one reciprocal in the pair-form groups (1, 2 or 4)
+#endif
 #ifndef NMRFIT_FASTPAIR
 #define NMRFIT_FASTPAIR 1     // two-operation pair form for groups of positive Lorentzian amplitudes
 #endif
 #ifndef NMRFIT_MIN_WAVES
 #define NMRFIT_MIN_WAVES 3
 #endif
+constexpr int kBatchInv = NMRFIT_BATCHINV;
 constexpr int kFarTerms = 16;      // Taylor terms of the far-field expansion (rho <= 0.1 -> 1e-16)
 constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coefficient scratch in LDS:
                                    // lane l sits at column l + l/16, which makes the transposed
@@ -284,23 +288,71 @@ __device__ __forceinline__ void lorentz_group_fast(const PeakFast *r, const doub
         c[g] = r[g].cs;
         ia[g] = r[g].ia;
     }
+    // One reciprocal serves kBatchInv points (batch inversion): r = 1/(d0 d1), 1/d0 = r d1,
+    // 1/d1 = r d0 -- a multiply is ~4 cycles, v_rcp_f64 16.  The staging bound on the group's
+    // denominator is divided by kBatchInv accordingly.
     constexpr int kInterleave = NMRFIT_INTERLEAVE;
+    constexpr int B = kBatchInv;
+    static_assert(kPointsPerLane % B == 0, "batch");
 #pragma unroll
-    for (int q = 0; q < kPointsPerLane; ++q) {
-        double pn[G / 2], pd[G / 2];
+    for (int q0 = 0; q0 < kPointsPerLane; q0 += B) {
+        double num[B], den[B];
 #pragma unroll
-        for (int g = 0; g < G; g += 2) {
-            const double t0 = __builtin_fma(wv[q], ih[g], c[g]);
-            const double t1 = __builtin_fma(wv[q], ih[g + 1], c[g + 1]);
-            const double s0 = __builtin_fma(t0, t0, ia[g]);
-            const double s1 = __builtin_fma(t1, t1, ia[g + 1]);
-            pn[g / 2] = s0 + s1;
-            pd[g / 2] = s0 * s1;
+        for (int b = 0; b < B; ++b) {
+            double pn[G / 2], pd[G / 2];
+#pragma unroll
+            for (int g = 0; g < G; g += 2) {
+                const double t0 = __builtin_fma(wv[q0 + b], ih[g], c[g]);
+                const double t1 = __builtin_fma(wv[q0 + b], ih[g + 1], c[g + 1]);
+                const double s0 = __builtin_fma(t0, t0, ia[g]);
+                const double s1 = __builtin_fma(t1, t1, ia[g + 1]);
+                pn[g / 2] = s0 + s1;
+                pd[g / 2] = s0 * s1;
+            }
+            lorentz_tree<G / 2, 0, G / 2>(pn, pd, num[b], den[b]);
         }
-        double num, den;
-        lorentz_tree<G / 2, 0, G / 2>(pn, pd, num, den);
-        acc[q] = __builtin_fma(num, rcp64(den), acc[q]);
-        if ((q + 1) % kInterleave == 0) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (B == 1) {
+            acc[q0] = __builtin_fma(num[0], rcp64(den[0]), acc[q0]);
+        } else if constexpr (B == 2) {
+            const double r = rcp64(den[0] * den[1]);
+            acc[q0] = __builtin_fma(num[0], r * den[1], acc[q0]);
+            acc[q0 + 1] = __builtin_fma(num[1], r * den[0], acc[q0 + 1]);
+        } else {
+            static_assert(B == 4, "1, 2 or 4");
+            const double p01 = den[0] * den[1], p23 = den[2] * den[3];
+            const double r = rcp64(p01 * p23);
+            const double r01 = r * p23, r23 = r * p01;
+            acc[q0] = __builtin_fma(num[0], r01 * den[1], acc[q0]);
+            acc[q0 + 1] = __builtin_fma(num[1], r01 * den[0], acc[q0 + 1]);
+            acc[q0 + 2] = __builtin_fma(num[2], r23 * den[3], acc[q0 + 2]);
+            acc[q0 + 3] = __builtin_fma(num[3], r23 * den[2], acc[q0 + 3]);
+        }
+        if ((q0 + B) % kInterleave == 0 || B > kInterleave) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// One peak over the lane's points with one reciprocal per four points (batch inversion; with
+// s >= 1 and |t| <= 1e18 the product of four stays below 1e145): the near peaks of FARFIELD.
+__device__ __forceinline__ void lorentz_one(const PeakLor *r, const double (&wv)[kPointsPerLane],
+                                            double (&acc)[kPointsPerLane])
+{
+    static_assert(kPointsPerLane % 4 == 0, "four points per reciprocal");
+    const double ih = r->ihw, c = r->c, al = r->al;
+#pragma unroll
+    for (int q0 = 0; q0 < kPointsPerLane; q0 += 4) {
+        double s[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const double t = __builtin_fma(wv[q0 + b], ih, c);
+            s[b] = __builtin_fma(t, t, 1.0);
+        }
+        const double p01 = s[0] * s[1], p23 = s[2] * s[3];
+        const double rr = rcp64(p01 * p23);
+        const double a01 = al * (rr * p23), a23 = al * (rr * p01);
+        acc[q0] = __builtin_fma(a01, s[1], acc[q0]);
+        acc[q0 + 1] = __builtin_fma(a01, s[0], acc[q0 + 1]);
+        acc[q0 + 2] = __builtin_fma(a23, s[3], acc[q0 + 2]);
+        acc[q0 + 3] = __builtin_fma(a23, s[2], acc[q0 + 3]);
     }
 }
 
@@ -473,7 +525,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
             // none does -- keeps the chunk loop free of a per-group branch (whose two arms cost
             // 16 register copies per group in phi moves: measured, it ate the gain)
             const bool whole = (k | 7) < P;
-            if (whole && !(ehi < 1000 && elo > -1000)) fast_bad = true;
+            if (whole && !(ehi < 1000 / kBatchInv && elo > -1000 / kBatchInv)) fast_bad = true;
             // cs from the ROUNDED ihs (one rounding, like c from ihw): the zero of t' then sits at
             // loc to the same accuracy as the zero of t
             const double ihs = it * rs;
@@ -684,7 +736,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
 #pragma unroll
                     for (int n = 0; n < kFarTerms; ++n) cf[n] = src[n];
                     ff_odd = !ff_odd;
-                    for (unsigned m = near_c; m; m &= m - 1) lorentz_group<1>(lor + __builtin_ctz(m), wv, acc);
+                    for (unsigned m = near_c; m; m &= m - 1) lorentz_one(lor + __builtin_ctz(m), wv, acc);
                     if (kRec && full && rec_all) {
                         for (unsigned m = hits_c; m; m &= m - 1) gauss_add_rec(lor + __builtin_ctz(m), grec + __builtin_ctz(m), wv, acc);
                     } else {
@@ -744,7 +796,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites
                     }
                     for (unsigned long long m = nearmask; m; m &= m - 1)
-                        lorentz_group<1>(lor + kb + __builtin_ctzll(m), wv, acc);
+                        lorentz_one(lor + kb + __builtin_ctzll(m), wv, acc);
                     for (unsigned long long m = hits; m; m &= m - 1) {
                         const int k1 = kb + __builtin_ctzll(m);
                         if (kRec && full && rec_all)

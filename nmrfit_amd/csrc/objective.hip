@@ -331,6 +331,45 @@ __device__ __forceinline__ void lorentz_group_fast(const PeakFast *r, const doub
     }
 }
 
+// A single peak in the scaled form (the odd one out of a short tail group): 1/s' per point, one
+// reciprocal per four points.
+__device__ __forceinline__ void lorentz_one_fast(const PeakFast *r, const double (&wv)[kPointsPerLane],
+                                                 double (&acc)[kPointsPerLane])
+{
+    static_assert(kPointsPerLane % 4 == 0, "four points per reciprocal");
+    const double ih = r->ihs, c = r->cs, ia = r->ia;
+#pragma unroll
+    for (int q0 = 0; q0 < kPointsPerLane; q0 += 4) {
+        double s[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const double t = __builtin_fma(wv[q0 + b], ih, c);
+            s[b] = __builtin_fma(t, t, ia);
+        }
+        const double p01 = s[0] * s[1], p23 = s[2] * s[3];
+        const double rr = rcp64(p01 * p23);
+        const double a01 = rr * p23, a23 = rr * p01;
+        acc[q0] = __builtin_fma(a01, s[1], acc[q0]);
+        acc[q0 + 1] = __builtin_fma(a01, s[0], acc[q0 + 1]);
+        acc[q0 + 2] = __builtin_fma(a23, s[3], acc[q0 + 2]);
+        acc[q0 + 3] = __builtin_fma(a23, s[2], acc[q0 + 3]);
+    }
+}
+
+// The short tail group (1..7 peaks) in the scaled form: an even-sized group, then the odd peak.
+__device__ __forceinline__ void lorentz_tail_fast(int n, const PeakFast *r, const double (&wv)[kPointsPerLane],
+                                                  double (&acc)[kPointsPerLane])
+{
+    const int even = n & ~1;
+    if (even == 6)
+        lorentz_group_fast<6>(r, wv, acc);
+    else if (even == 4)
+        lorentz_group_fast<4>(r, wv, acc);
+    else if (even == 2)
+        lorentz_group_fast<2>(r, wv, acc);
+    if (n & 1) lorentz_one_fast(r + even, wv, acc);
+}
+
 // One peak over the lane's points with one reciprocal per four points (batch inversion; with
 // s >= 1 and |t| <= 1e18 the product of four stays below 1e145): the near peaks of FARFIELD.
 __device__ __forceinline__ void lorentz_one(const PeakLor *r, const double (&wv)[kPointsPerLane],
@@ -487,8 +526,11 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
 
     // stage this particle's per-peak constants in the wave's LDS slices
     bool fast_bad = false, rec_bad = false;
-    for (int k = lane; k < P; k += kWave) {
-        const double width = x[4 + 3 * k], loc = x[5 + 3 * k], a = x[6 + 3 * k];
+    for (int kb0 = 0; kb0 < P; kb0 += kWave) {   // every lane iterates (the group sums below shuffle)
+        const int k = kb0 + lane;
+        const bool have = k < P;
+        const int kx = have ? k : 0;
+        const double width = x[4 + 3 * kx], loc = x[5 + 3 * kx], a = x[6 + 3 * kx];
         const double ihw = 2.0 / width;
         const double locc = loc - w0;
         // |t| <= 1e18 keeps the grouped denominators finite; the cap only engages for widths
@@ -500,11 +542,11 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
         rec.c = -locc * it;
         rec.al = a * r * ihw * kInvPi;                            // a*r*(2/(pi*width))
         rec.ag2 = 2.0 * a * (1.0 - r) * ihw * kSqrtLn2OverPi;     // 2 * a*(1-r)*(2/width)*sqrt(ln2/pi)
-        lor[k] = rec;
+        if (have) lor[k] = rec;
         // window bounds in f32, rounded outwards (a slightly wider window is still exact)
         const double gw = kGaussWindow * fabs(width);
         const double wlo = locc - gw, whi = locc + gw;
-        win[k] = PeakWin{(float)(wlo - fabs(wlo) * 1.2e-7 - 1e-37), (float)(whi + fabs(whi) * 1.2e-7 + 1e-37)};
+        if (have) win[k] = PeakWin{(float)(wlo - fabs(wlo) * 1.2e-7 - 1e-37), (float)(whi + fabs(whi) * 1.2e-7 + 1e-37)};
         if (kFast) {
             // exponent budget of the group's denominator: s' <= (1 + tmax^2)/al, s' >= 1/al
             const double al = rec.al;
@@ -515,30 +557,30 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
             int ehi = pos ? ilogb(__builtin_fma(tmax, tmax, 1.0) * ia) + 2 : 100000;
             int elo = pos ? ilogb(ia) : -100000;
             if (ehi > 100000) ehi = 100000;                              // inf / overflow
+            if (!have) ehi = elo = 0;                                    // beyond the last peak: no factor
 #pragma unroll
             for (int m = 1; m < 8; m <<= 1) {
                 ehi += __shfl_xor(ehi, m, kWave);
                 elo += __shfl_xor(elo, m, kWave);
             }
-            // a whole group of 8 (k | 7 < P; the short tail group always takes the general form)
-            // must stay within 2^+-1000; ONE flag per particle -- every whole group qualifies or
-            // none does -- keeps the chunk loop free of a per-group branch (whose two arms cost
-            // 16 register copies per group in phi moves: measured, it ate the gain)
-            const bool whole = (k | 7) < P;
-            if (whole && !(ehi < 1000 / kBatchInv && elo > -1000 / kBatchInv)) fast_bad = true;
+            // every group of (up to) 8 peaks must have positive amplitudes and a denominator that
+            // stays within 2^+-1000 for kBatchInv points; ONE flag per particle -- all groups
+            // qualify or none does -- keeps the chunk loop free of a per-group branch (whose two
+            // arms cost 16 register copies per group in phi moves: measured, it ate the gain)
+            if (have && !(ehi < 1000 / kBatchInv && elo > -1000 / kBatchInv)) fast_bad = true;
             // cs from the ROUNDED ihs (one rounding, like c from ihw): the zero of t' then sits at
             // loc to the same accuracy as the zero of t
             const double ihs = it * rs;
-            lorf[k] = PeakFast{ihs, -locc * ihs, ia, 0.0};
+            if (have) lorf[k] = PeakFast{ihs, -locc * ihs, ia, 0.0};
         }
         if (kRec) {
             const double d = lane_step * it;
             const bool ok = (lane_step != 0.0) && (fabs(d) <= 2.0) && (fabs(it) * rec_devk <= 1.0);
-            if (!ok) rec_bad = true;
-            grec[k] = make_double2(d, ok ? exp2_neg(-2.0 * d * d) : 0.0);
+            if (have && !ok) rec_bad = true;
+            if (have) grec[k] = make_double2(d, ok ? exp2_neg(-2.0 * d * d) : 0.0);
         }
     }
-    // wave-uniform: every whole group of this particle may take the two-operation pair form
+    // wave-uniform: every group of this particle may take the two-operation pair form
     const bool fast_all = kFast && (__ballot(fast_bad) == 0ull);
     const bool rec_all = kRec && (__ballot(rec_bad) == 0ull);   // every peak may take the Gaussian recurrence
     __syncthreads();
@@ -839,12 +881,14 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                 // window touches this chunk, one scalar loop over the set bits of the mask
                 int k = kb;
                 if (fast_all) {
-                    if constexpr (kFast)
+                    if constexpr (kFast) {
                         for (; k + kGroup <= kend; k += kGroup) lorentz_group_fast<kGroup>(lorf + k, wv, acc);
+                        if (k < kend) lorentz_tail_fast(kend - k, lorf + k, wv, acc);
+                    }
                 } else {
                     for (; k + kGroup <= kend; k += kGroup) lorentz_group<kGroup>(lor + k, wv, acc);
+                    if (k < kend) lorentz_tail<kGroup>(kend - k, lor + k, wv, acc);   // one smaller group
                 }
-                if (k < kend) lorentz_tail<kGroup>(kend - k, lor + k, wv, acc);   // one smaller group
                 if (kend - kb < kWave) hits &= (1ull << (kend - kb)) - 1ull;
                 if (kRec && full && rec_all) {
                     for (unsigned long long m = hits; m; m &= m - 1) {

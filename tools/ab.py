@@ -27,10 +27,15 @@ def main():
     ap.add_argument("libs", nargs="+")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--workload", default="C3")
+    ap.add_argument("--shape", default=None, help="S,N,P instead of a named workload")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=10)
     a = ap.parse_args()
     cfg = synth.CONFIGS[a.workload]
+    if a.shape:
+        import collections
+        S_, N_, P_ = (int(t) for t in a.shape.split(","))
+        cfg = collections.namedtuple("Shape", "S N P")(S_, N_, P_)
     sp = synth.make_spectrum(cfg.N, cfg.P, seed=1)
     X = synth.make_swarm(sp["lower"], sp["upper"], cfg.S, seed=2, x_true=sp["x_true"])
     import numpy as np

@@ -49,7 +49,6 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-constexpr double kPi = 3.14159265358979323846;
 constexpr double kInvPi = 0.31830988618379067154;
 constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 #ifndef NMRFIT_INTERLEAVE

@@ -149,7 +149,7 @@ __device__ __forceinline__ void pbest_particle(int64_t i, int lane, int64_t D, c
     if (lane == 0) fp[i] = f;
 }
 
-// block-wide first index of the minimum of fp (np.argmin) -> candidate record.
+// block-wide first index of the minimum of fp (np.argmin) -> candidate record (fused tail, empty shards).
 // Must be called by every thread of the block (contains a barrier).
 __device__ __forceinline__ void argmin_block(int64_t S, int64_t D, const double *fp, const double *p, double *cand,
                                              double *s_val, long long *s_idx)
@@ -272,17 +272,6 @@ __global__ void pso_update_kernel(int64_t S, int64_t D, int64_t offset, uint64_t
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= S * D) return;
     update_element(idx, D, offset, seed, (uint32_t)(flags[0] + 1), omega, phip, phig, best, lb, ub, p, x, v);
-}
-
-__global__ void pso_pbest_kernel(int64_t S, int64_t D, const long long *__restrict__ flags,
-                                 const double *__restrict__ x, const double *__restrict__ fx, double *__restrict__ p,
-                                 double *__restrict__ fp)
-{
-    if (flags[1] != 0) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
-    if (i >= S) return;
-    pbest_particle(i, lane, D, x, fx, p, fp);
 }
 
 __global__ __launch_bounds__(1024) void pso_argmin_kernel(int64_t S, int64_t D, const long long *__restrict__ flags,

@@ -49,7 +49,11 @@ def parse():
                     help="also time the reference's multiprocessing mode (Pool.map of the numpy oracle over PROCS "
                          "spawned workers); off by default, never use under rocprofv3 (workers inherit its preload)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the far-field / other-config / host-pointer extras (profiling runs)")
+                    help="skip the far-field / host-pointer extras (PMC passes)")
+    ap.add_argument("--other-configs", action="store_true",
+                    help="also time the C2 and C5 shapes (kernel only).  Off by default so that every "
+                         "objective_kernel<0,false,0> launch of the default command has the C3 shape and the "
+                         "rocprofv3 --stats average of that kernel is the number in roofline.kernel_ms")
     return ap.parse_args()
 
 
@@ -224,7 +228,7 @@ def main():
                             "configuration `value` is measured on"}
     # the other single-GPU configs of BASELINE.json, kernel-only (HIP events), for reference
     others = None
-    if rank == 0 and world == 1 and args.workload == "C3" and not args.no_extras:
+    if rank == 0 and world == 1 and args.workload == "C3" and args.other_configs:
         others = {}
         for name in ("C2", "C5"):
             c = synth.CONFIGS[name]

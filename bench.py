@@ -313,6 +313,8 @@ def main():
                                   "w/u/v/weights are shared by all particles and L2-resident, so this is an "
                                   "effective rate, not physical HBM traffic",
                          "kernel": "objective_kernel", "kernel_ms": t_kernel_ms,
+                         "kernel_ms_note": "HIP events around K objective_batch_dev calls; each call is the "
+                                           "objective kernel plus its ~5 us finalize launch when the grid is segmented",
                          "bytes_per_launch": bytes_launch, "units_per_launch": units_launch,
                          "launch": geom},
             "valu": {"units_per_s_kernel": units_launch / (t_kernel_ms * 1e-3),

@@ -40,6 +40,8 @@
 #define NMRFIT_DAWSON_QUAL __device__ const
 #include "dawson_coeffs.h"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cmath>
 
@@ -630,6 +632,11 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
             wnext[q] = (j0 + lane + q * kWave < j1) ? wc[j0 + lane + q * kWave] : 0.0;
     }
 
+    // The chunk loop exists twice, once per Lorentzian group form, chosen ONCE per wave: inside one
+    // copy the accumulators never meet the other form's registers (a merge of the two forms per
+    // chunk costs the compiler 8-16 register copies per chunk).
+    auto chunk_loop = [&](auto fast_tag) {
+    constexpr bool kFastLoop = decltype(fast_tag)::value;
     for (int64_t jb = j0; jb < j1; jb += kChunk) {
         // Full chunks (all but possibly the last of a segment) take unpredicated loads at
         // constant offsets from one pointer; the ragged tail is predicated per point.
@@ -879,11 +886,9 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                 // Lorentzians first, in straight-line groups; then the (few) Gaussians whose
                 // window touches this chunk, one scalar loop over the set bits of the mask
                 int k = kb;
-                if (fast_all) {
-                    if constexpr (kFast) {
-                        for (; k + kGroup <= kend; k += kGroup) lorentz_group_fast<kGroup>(lorf + k, wv, acc);
-                        if (k < kend) lorentz_tail_fast(kend - k, lorf + k, wv, acc);
-                    }
+                if constexpr (kFastLoop) {
+                    for (; k + kGroup <= kend; k += kGroup) lorentz_group_fast<kGroup>(lorf + k, wv, acc);
+                    if (k < kend) lorentz_tail_fast(kend - k, lorf + k, wv, acc);
                 } else {
                     for (; k + kGroup <= kend; k += kGroup) lorentz_group<kGroup>(lor + k, wv, acc);
                     if (k < kend) lorentz_tail<kGroup>(kend - k, lor + k, wv, acc);   // one smaller group
@@ -984,6 +989,11 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
             ++bidx;
         }
     }
+    };
+    if (kFast && fast_all)
+        chunk_loop(std::integral_constant<bool, kFast>{});
+    else
+        chunk_loop(std::false_type{});
 
     if (nseg == 1 && lane == 0) {
         if (FIT_IM == 0)

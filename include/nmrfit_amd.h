@@ -46,8 +46,9 @@ enum {
 
 /* Kernel variants (numerics identical to <= 1e-12 relative; for A/B measurement). */
 enum {
-    NMRFIT_VARIANT_DEFAULT = 0,   /* tuned fp64: 8 Lorentzians per reciprocal + Gaussian window skip
-                                     (+ Gaussian recurrence on uniform grids, see NOREC)              */
+    NMRFIT_VARIANT_DEFAULT = 0,   /* tuned fp64: 8 Lorentzians x 4 points per reciprocal (scaled pair form
+                                     for positive amplitudes) + Gaussian window skip (+ Gaussian
+                                     recurrence on uniform grids, see NOREC)                          */
     NMRFIT_VARIANT_BASELINE = 1,  /* plain fp64: IEEE divide + libdevice exp2 per unit, no skipping  */
     NMRFIT_VARIANT_NOSKIP = 2,    /* tuned arithmetic, Gaussian evaluated everywhere                 */
     NMRFIT_VARIANT_SINGLE = 3,    /* one reciprocal per unit + Gaussian window skip                  */
@@ -56,7 +57,8 @@ enum {
     NMRFIT_VARIANT_FARFIELD = 6,  /* opt-in: Lorentzian tails of distant peaks through one shared
                                      Taylor expansion per 512-point chunk (truncation <= 1e-16 of each
                                      term); not the default because it changes the per-unit work      */
-    NMRFIT_VARIANT_NOREC = 7      /* DEFAULT with one exp2 for every in-window Gaussian on every grid.
+    NMRFIT_VARIANT_NOREC = 7      /* the general form throughout: 8 Lorentzians per reciprocal, one
+                                     reciprocal per point, one exp2 for every in-window Gaussian.
                                      (DEFAULT and FARFIELD objective launches on a uniformly spaced
                                      grid run the in-window Gaussians of a lane's 8 points as a
                                      two-multiply recurrence from one seed; f moves by <= 5e-15.

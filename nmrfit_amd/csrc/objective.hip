@@ -637,10 +637,13 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     // chunk costs the compiler 8-16 register copies per chunk).
     auto chunk_loop = [&](auto fast_tag) {
     constexpr bool kFastLoop = decltype(fast_tag)::value;
-    for (int64_t jb = j0; jb < j1; jb += kChunk) {
+    // ... and the chunk body twice more, for full chunks and for the one ragged chunk at the end of
+    // the grid: `full` is a compile-time constant inside, so the predicated and the unpredicated
+    // loads never merge (each merge is eight register copies).
+    auto chunk = [&](const int64_t jb, auto full_tag) {
         // Full chunks (all but possibly the last of a segment) take unpredicated loads at
         // constant offsets from one pointer; the ragged tail is predicated per point.
-        const bool full = (jb + kChunk <= j1);   // wave-uniform
+        constexpr bool full = decltype(full_tag)::value;
         const int64_t jl = jb + lane;
         // A block = blk_chunks consecutive chunks, a function of N only; segments are whole
         // blocks.  Everything that carries state from point to point restarts at block
@@ -988,7 +991,10 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
             }
             ++bidx;
         }
-    }
+    };
+    int64_t jb = j0;
+    for (; jb + kChunk <= j1; jb += kChunk) chunk(jb, std::true_type{});
+    if (jb < j1) chunk(jb, std::false_type{});
     };
     if (kFast && fast_all)
         chunk_loop(std::integral_constant<bool, kFast>{});

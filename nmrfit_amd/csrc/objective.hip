@@ -623,7 +623,6 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     constexpr bool kFar = (VARIANT == NMRFIT_VARIANT_FARFIELD);
     constexpr int kGroup = (VARIANT == NMRFIT_VARIANT_SINGLE) ? 1 : (VARIANT == NMRFIT_VARIANT_QUAD) ? 4 : NMRFIT_GROUP;
 
-    bool ff_odd = false;                       // FARFIELD, P <= 32: this chunk's expansion was made by the previous one
     unsigned pend_near = 0, pend_hits = 0;     // ... together with its near-peak and Gaussian-window masks
     double wnext[kPointsPerLane];
     if (kStage) {
@@ -640,7 +639,9 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     // ... and the chunk body twice more, for full chunks and for the one ragged chunk at the end of
     // the grid: `full` is a compile-time constant inside, so the predicated and the unpredicated
     // loads never merge (each merge is eight register copies).
-    auto chunk = [&](const int64_t jb, auto full_tag) {
+    auto chunk = [&](const int64_t jb, auto full_tag, auto odd_tag) {
+        // FARFIELD, P <= 32: an odd chunk's expansion was made by the even chunk before it
+        constexpr bool ff_odd = decltype(odd_tag)::value;
         // Full chunks (all but possibly the last of a segment) take unpredicated loads at
         // constant offsets from one pointer; the ragged tail is predicated per point.
         constexpr bool full = decltype(full_tag)::value;
@@ -786,7 +787,6 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                     const double *src = ffs + (ff_odd ? kFarTerms : 0);
 #pragma unroll
                     for (int n = 0; n < kFarTerms; ++n) cf[n] = src[n];
-                    ff_odd = !ff_odd;
                     for (unsigned m = near_c; m; m &= m - 1) lorentz_one(lor + __builtin_ctz(m), wv, acc);
                     if (kRec && full && rec_all) {
                         for (unsigned m = hits_c; m; m &= m - 1) gauss_add_rec(lor + __builtin_ctz(m), grec + __builtin_ctz(m), wv, acc);
@@ -993,8 +993,22 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
         }
     };
     int64_t jb = j0;
-    for (; jb + kChunk <= j1; jb += kChunk) chunk(jb, std::true_type{});
-    if (jb < j1) chunk(jb, std::false_type{});
+    if constexpr (VARIANT == NMRFIT_VARIANT_FARFIELD) {   // chunks alternate even / odd from the segment start
+        for (; jb + 2 * kChunk <= j1; jb += 2 * kChunk) {
+            chunk(jb, std::true_type{}, std::false_type{});
+            chunk(jb + kChunk, std::true_type{}, std::true_type{});
+        }
+        if (jb + kChunk <= j1) {
+            chunk(jb, std::true_type{}, std::false_type{});
+            jb += kChunk;
+            if (jb < j1) chunk(jb, std::false_type{}, std::true_type{});
+        } else if (jb < j1) {
+            chunk(jb, std::false_type{}, std::false_type{});
+        }
+    } else {
+        for (; jb + kChunk <= j1; jb += kChunk) chunk(jb, std::true_type{}, std::false_type{});
+        if (jb < j1) chunk(jb, std::false_type{}, std::false_type{});
+    }
     };
     if (kFast && fast_all)
         chunk_loop(std::integral_constant<bool, kFast>{});

@@ -2,28 +2,46 @@
 """
 bench.py -- objective evaluations per second of the MI355X swarm generation.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launches its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Either form runs one process per GPU.  With WORLD_SIZE unset and --gpus N > 1 this script is the
+launcher: before touching any GPU it starts N rank processes of itself (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), relays rank 0's JSON line and exits non-zero if any
+rank fails.  No PyTorch in any of it: the ranks find each other over standard-library sockets
+(nmrfit_amd/rendezvous.py) and exchange through RCCL inside libnmrfit_amd.so.
+
 Workload (BASELINE.json configs[2] / configs[3]): 24 peaks, 65536-point grid, 4096 particles
 PER GPU (weak scaling: N GPUs evaluate a 4096*N swarm; N=8 is config C4).  One "step" is one
-swarm generation on device-resident state: velocity/position update -> batched objective
-(the hot path, one launch) -> personal-best update -> local argmin -> [N>1: one RCCL
-all-gather of the (D+1)-double candidate] -> global-best fold.  Inputs are resident in HBM
-before the timed region; stopping tests are disabled so every timed generation does full work.
+swarm generation on device-resident state, ONE C call (nmrfit_pso_step): velocity/position
+update -> batched objective (the hot path, one launch) -> personal-best update -> local argmin
+-> [N>1: one ncclAllGather of the (D+1)-double candidate] -> global-best fold.  Inputs are
+resident in HBM before the timed region; stopping tests are disabled so every timed generation
+does full work.
+
+Order of a run: CPU baseline legs first (rank 0, N=1 only; nothing has touched the GPU yet, so
+the Pool.map workers are not children of a GPU process) -> swarm init + W warm-up generations
+-> >= 0.5 s of objective launches to bring the clocks to their loaded state -> barrier ->
+EXACTLY K timed generations, each objective kernel bracketed by HIP events on its own stream
+and each step by a mark (nmrfit_prof_*) -> barrier -> max over ranks.
 
 metric  = particle*gridpoint*peak evaluations per second, whole job.
-roofline: SURVEY.md 8(d)(i) streaming-operand byte model (32/P bytes per unit) against
-          8 TB/s, from the objective kernel's own average duration measured with HIP events on
-          its stream (a second pass of K objective-only launches on the final swarm);
-          `valu` carries the honest binding figure (fp64 vector-ALU issue) -- see DESIGN.md.
+roofline: SURVEY.md 8(d)(i) streaming-operand byte model (32/P bytes per unit) against 8 TB/s,
+          from the objective kernel's own durations INSIDE the timed loop (kernel <= step is
+          asserted).  `roofline_valu` is the binding resource (fp64 vector-ALU issue).
+          Fields that come from committed rocprofv3 --pmc passes rather than from this run are
+          marked "from_committed_profile".
 cpu_baseline: the oracle (numpy restatement of the reference, 1 core = the reference's
-          default processes=1) on a bounded sample of the same workload, rank 0, N=1 only.
+          default processes=1), the same through multiprocessing.Pool.map (the reference's
+          only parallel mode, utils.py:182) and the plain-C OpenMP oracle, on a bounded sample
+          of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,23 +51,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X spec: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+SIMDS = 1024                   # 256 CUs x 4 SIMDs
+PEAK_CLOCK_MHZ = 2400.0        # MI355X_MICROARCH.md
+FP64_ISSUE_CYCLES = 4.0        # one wave64 fp64 VALU instruction occupies a SIMD's issue port for 4 cycles
+PMC_SUMMARY = os.path.join("profiles", "r02", "bench_c3_pmc_summary.json")
+PMC_SUMMARY_FALLBACK = os.path.join("profiles", "r01", "bench_c3_pmc_summary.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", help="C3 (default, the metric's config) or C2")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--swarm-per-gpu", type=int, default=0, help="override the workload's swarm size per GPU")
-    ap.add_argument("--cpu-pool", type=int, default=0, metavar="PROCS",
-                    help="also time the reference's multiprocessing mode (Pool.map of the numpy oracle over PROCS "
-                         "spawned workers); off by default, never use under rocprofv3 (workers inherit its preload)")
+    ap.add_argument("--cpu-pool", type=int, default=-1, metavar="PROCS",
+                    help="workers of the Pool.map CPU line (the reference's multiprocessing mode); default "
+                         "min(16, usable cores); 0 disables.  Skipped automatically under rocprofv3 (workers "
+                         "would inherit its preload)")
+    ap.add_argument("--preheat-seconds", type=float, default=0.5)
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the far-field / host-pointer extras (PMC passes)")
+                    help="skip the every-unit variants / far-field / host-pointer extras (PMC passes)")
     ap.add_argument("--other-configs", action="store_true",
                     help="also time the C2 and C5 shapes (kernel only).  Off by default so that every "
                          "objective_kernel<0,false,0> launch of the default command has the C3 shape and the "
@@ -57,12 +81,83 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(spec, lower, upper, P, budget_s, pool_procs=0):
-    """Reference-plumbing baseline: the numpy oracle, one particle per call, 1 core."""
+# ---- launcher (N > 1 without a launcher's environment) -------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """Start n rank processes of this script, one per GPU.  The parent never touches the GPU (it
+    loads neither the library nor HIP): it only waits, relays rank 0's output, and makes sure a
+    failed rank takes the others down instead of leaving them blocked in a collective."""
+    port = _free_port()
+    token = "bench%d_%d" % (os.getpid(), int(time.time() * 1e3) & 0xFFFFFFF)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NMRFIT_RDZV_TOKEN=token)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    rc = 0
+    out0 = b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                p = procs[r]
+                if r == 0:
+                    try:
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                elif p.poll() is None:
+                    continue
+                pending.discard(r)
+                if p.returncode != 0:
+                    rc = rc or p.returncode or 1
+                    sys.stderr.write("bench.py: rank %d exited with code %s\n" % (r, p.returncode))
+            if rc:
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:          # a failed run: end exactly the processes started here
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return rc
+
+
+# ---- CPU baseline legs (before any GPU call) -------------------------------------------------------
+def under_profiler():
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre.lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, 16))     # a one-GPU box's CPU share
+
+
+def cpu_baseline(spec, P, budget_s, pool_procs):
+    """Reference-plumbing baseline: the numpy oracle, one particle per call, 1 core; then the
+    reference's parallel mode (Pool.map over particles) and the plain-C OpenMP oracle."""
     from oracle import nmrfit_oracle as onp
     from nmrfit_amd import synth
     N = spec["w"].size
-    X = synth.make_swarm(lower, upper, 4096, seed=2, x_true=spec["x_true"])
+    X = synth.make_swarm(spec["lower"], spec["upper"], 4096, seed=2, x_true=spec["x_true"])
     t0 = time.perf_counter()
     n = 0
     while n < X.shape[0]:
@@ -74,11 +169,23 @@ def cpu_baseline(spec, lower, upper, P, budget_s, pool_procs=0):
     out = {"value": n * N * P / dt, "unit": "particle*gridpoint*peak/s", "cores": 1, "kind": "port",
            "sample": "%d particles of the same workload (N=%d, P=%d), numpy oracle one call per particle, %.1f s"
                      % (n, N, P, dt)}
+    if pool_procs > 0:
+        # the reference's only parallel mode (utils.py:176-182, processes=n): Pool.map over particles
+        try:
+            from oracle import pool_baseline
+            m, dtp, _ = pool_baseline.timed_map(X, spec["w"], spec["u"], spec["v"], spec["weights"], pool_procs,
+                                                max(2.0, budget_s / 2))
+            out["numpy_pool"] = {"value": m * N * P / dtp, "cores": pool_procs,
+                                 "sample": "%d particles through multiprocessing.Pool(%d).map, %.2f s"
+                                           % (m, pool_procs, dtp)}
+        except Exception as e:
+            out["numpy_pool"] = {"error": repr(e)}
+    else:
+        out["numpy_pool"] = {"skipped": "profiler preload detected" if under_profiler() else "disabled"}
     # strong-CPU line: plain-C oracle, OpenMP over particles, all host cores
     try:
         from oracle import c_oracle
-        th = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        th = min(th, 16)     # a one-GPU box's CPU share
+        th = usable_cores()
         per = min(X.shape[0], 4 * th)
         c_oracle.objective_batch(X[:per], spec["w"], spec["u"], spec["v"], spec["weights"], threads=th)   # warm the team
         m, t0 = 0, time.perf_counter()
@@ -89,27 +196,39 @@ def cpu_baseline(spec, lower, upper, P, budget_s, pool_procs=0):
         out["c_openmp"] = {"value": m * N * P / dt, "cores": th, "sample": "%d particles, %.2f s" % (m, dt)}
     except Exception as e:  # the C oracle is optional for the baseline
         out["c_openmp"] = {"error": str(e)}
-    if pool_procs > 0:
-        # the reference's only parallel mode (utils.py:176-182, processes=n): Pool.map over particles
-        from oracle import pool_baseline
-        n, dt, _ = pool_baseline.timed_map(X, spec["w"], spec["u"], spec["v"], spec["weights"], pool_procs,
-                                           max(2.0, budget_s / 3))
-        out["numpy_pool"] = {"value": n * N * P / dt, "cores": pool_procs, "sample": "%d particles, %.2f s" % (n, dt)}
     return out
+
+
+def stats(a):
+    a = np.asarray(a, dtype=np.float64)
+    if a.size == 0:
+        return None
+    return {"min": float(a.min()), "median": float(np.median(a)), "mean": float(a.mean()), "max": float(a.max()),
+            "n": int(a.size)}
+
+
+def time_objective(ev, S, P, d_x, d_f, reps, warm=2):
+    for _ in range(warm):
+        ev.objective_batch_dev(S, P, d_x, d_f)
+    ev.synchronize()
+    ev.timer_begin()
+    for _ in range(reps):
+        ev.objective_batch_dev(S, P, d_x, d_f)
+    return ev.timer_end() / reps
 
 
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
-    from nmrfit_amd import synth, _cabi
-    from nmrfit_amd.equations import Evaluator
-    from nmrfit_amd.pso import DeviceSwarm, TorchExchange
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
 
+    from nmrfit_amd import synth
     cfg = synth.CONFIGS[args.workload]
     S_local, N, P = cfg.S, cfg.N, cfg.P
     if args.swarm_per_gpu > 0:
@@ -117,117 +236,121 @@ def main():
     D = 4 + 3 * P
     spec = synth.make_spectrum(N, P, seed=1)
 
-    # N > 1: one rank per GPU, torch.distributed over RCCL ("nccl") for the candidate exchange.
-    # Rehearsal knobs (not used by the driver): NMRFIT_BENCH_FORCE_DIST=1 takes the RCCL path
-    # with a single rank; NMRFIT_BENCH_BACKEND=gloo runs several ranks on one GPU with the
-    # exchange staged through the host.
-    dist = torch = None
-    backend = os.environ.get("NMRFIT_BENCH_BACKEND", "nccl")
+    # ---- CPU legs first: nothing below has loaded the HIP library or touched the GPU yet ------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        pool = args.cpu_pool
+        if pool < 0:
+            pool = 0 if under_profiler() else usable_cores()
+        cpu = cpu_baseline(spec, P, args.cpu_seconds, pool)
+
+    from nmrfit_amd import _cabi, pso
+    from nmrfit_amd.equations import Evaluator
+
+    # N > 1: one rank per GPU, RCCL through the C-ABI.  Rehearsal knobs (not used by the
+    # driver): NMRFIT_BENCH_FORCE_DIST=1 takes the RCCL path with a single rank;
+    # NMRFIT_BENCH_BACKEND=host (alias: gloo) runs several ranks on ONE GPU with the record staged
+    # through the host over sockets (RCCL refuses two ranks on one device).
+    backend = os.environ.get("NMRFIT_BENCH_BACKEND", "rccl").lower()
+    backend = {"nccl": "rccl", "gloo": "host"}.get(backend, backend)
     use_dist = world > 1 or os.environ.get("NMRFIT_BENCH_FORCE_DIST") == "1"
     device = local_rank
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        if backend == "gloo":
-            device = local_rank % max(1, _cabi.device_count())
-        torch.cuda.set_device(device)
-        kw = {}
-        if "MASTER_ADDR" not in os.environ:
-            kw = dict(init_method="tcp://127.0.0.1:29531", rank=rank, world_size=world)
-        if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", device)
-        dist.init_process_group(backend, **kw)
+    if use_dist and backend == "host":
+        device = local_rank % max(1, _cabi.device_count())
 
     ev = Evaluator(spec["w"], spec["u"], spec["v"], spec["weights"], device=device)
     ev.set_variant(args.variant)
-    sw = DeviceSwarm(ev, spec["lower"], spec["upper"], swarmsize=S_local * world, offset=rank * S_local,
-                     S_local=S_local, seed=1234, minstep=-1.0, minfunc=-1.0)   # never stop while timing
+    sw = pso.DeviceSwarm(ev, spec["lower"], spec["upper"], swarmsize=S_local * world, offset=rank * S_local,
+                         S_local=S_local, seed=1234, minstep=-1.0, minfunc=-1.0)   # never stop while timing
+    ex = None
+    exchange_desc = "none"
+    if use_dist and backend == "rccl":
+        ex = pso.RcclExchange(ev)
+        sw.set_comm(ex)                       # the all-gather now happens inside nmrfit_pso_step
+        exchange_desc = "ncclAllGather of %d doubles per generation inside nmrfit_pso_step (RCCL %s)" % (
+            D + 1, ex.info()["rccl_version"])
 
-    if use_dist and backend == "nccl":
-        # swarm kernels and the RCCL all-gather on ONE explicit stream, no host synchronisation
-        # inside a generation: the same object nmrfit_amd.fit() uses for multi-GPU fits
-        from nmrfit_amd.pso import RcclGeneration
-        gen = RcclGeneration(sw, TorchExchange())
-        fold = gen.fold
-
-        def sync():
-            torch.cuda.synchronize()
+        def step():
+            sw.step()
     elif use_dist:
-        ex = TorchExchange()
+        ex = pso.SocketExchange()
+        exchange_desc = "host-staged all-gather of %d doubles per generation (sockets; rehearsal)" % (D + 1)
+        state = {"first": True}
 
-        def fold():
+        def step():
+            if not state["first"]:
+                sw.step_local()
+            state["first"] = False
             sw.apply_global(ex.gather_host(sw.candidate()))
-
-        def sync():
-            ev.synchronize()
     else:
-        cand = sw.candidate_dev()
-
-        def fold():
-            sw.apply_global_dev(cand, 1)
-
-        def sync():
-            ev.synchronize()
+        def step():
+            sw.step()
 
     def barrier():
-        if use_dist:
-            dist.barrier()
+        ev.synchronize()
+        if ex is not None:
+            ex.barrier()
 
     sw.init()
-    fold()
+    step()                                   # folds generation 0
     for _ in range(args.warmup):
-        sw.step_local()
-        fold()
-    sync()
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sw.step_local()
-        fold()
-    sync()
-    barrier()
-    sync()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    # objective kernel alone, HIP events on its stream, same swarm positions
-    st = sw.status()
+        step()
+    ev.synchronize()
+    # bring the clocks to their loaded state: >= preheat_seconds of the same kernel on the same
+    # positions (objective-only launches: the swarm does not advance, so the trajectory -- and
+    # generations_done -- do not depend on how long this takes)
     d_x = ev.dev_alloc(S_local * D * 8)
     d_f = ev.dev_alloc(S_local * 8)
     ev.upload(d_x, sw.state()["x"])
-    for _ in range(2):
-        ev.objective_batch_dev(S_local, P, d_x, d_f)
-    ev.synchronize()
-    ev.timer_begin()
-    for _ in range(args.steps):
-        ev.objective_batch_dev(S_local, P, d_x, d_f)
-    t_kernel_ms = ev.timer_end() / args.steps
-    geom = ev.last_launch()
-    # opt-in far-field variant: same inputs, objective-only launches
-    farfield = None
-    if rank == 0 and args.variant == 0 and not args.no_extras:
-        f_def = ev.download(d_f, (S_local,))
-        ev.set_variant(_cabi.VARIANT_FARFIELD)
-        for _ in range(2):
+    t0 = time.perf_counter()
+    heat_launches = 0
+    while time.perf_counter() - t0 < args.preheat_seconds:
+        for _ in range(8):
             ev.objective_batch_dev(S_local, P, d_x, d_f)
         ev.synchronize()
-        ev.timer_begin()
-        for _ in range(args.steps):
-            ev.objective_batch_dev(S_local, P, d_x, d_f)
-        ff_ms = ev.timer_end() / args.steps
-        f_ff = ev.download(d_f, (S_local,))
+        heat_launches += 8
+    ev.prof_enable(args.steps)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev.prof_mark()
+        step()
+    ev.prof_mark()
+    barrier()
+    dt = time.perf_counter() - t0
+    k_ms, s_ms, clock_mhz = ev.prof_read()
+    ev.prof_enable(0)
+    if ex is not None:
+        dt = float(ex.all_reduce([dt], "max")[0])
+    ms_per_step = dt / args.steps * 1e3
+    st = sw.status()
+    geom = ev.last_launch()
+    ev.upload(d_x, sw.state()["x"])
+
+    # ---- extras on the final swarm positions (rank 0, after the timed region) ---------------
+    variants = farfield = host_ms = others = None
+    if rank == 0 and args.variant == 0 and not args.no_extras:
+        f_def = None
+        variants = {}
+        reps = max(5, min(args.steps, 20))
+        for name, vid in (("default", _cabi.VARIANT_DEFAULT), ("noskip", _cabi.VARIANT_NOSKIP),
+                          ("baseline", _cabi.VARIANT_BASELINE), ("farfield", _cabi.VARIANT_FARFIELD)):
+            ev.set_variant(vid)
+            ms = time_objective(ev, S_local, P, d_x, d_f, reps)
+            f = ev.download(d_f, (S_local,))
+            if f_def is None:
+                f_def = f
+            variants[name + "_ms"] = ms
+            variants[name + "_max_rel_diff_vs_default"] = float(np.max(np.abs(f - f_def) / np.maximum(np.abs(f_def), 1e-6)))
         ev.set_variant(args.variant)
-        farfield = {"kernel_ms": ff_ms, "units_per_s": float(S_local) * N * P / (ff_ms * 1e-3),
-                    "max_rel_diff_vs_default": float(np.max(np.abs(f_ff - f_def) / np.maximum(np.abs(f_def), 1e-6))),
-                    "note": "NMRFIT_VARIANT_FARFIELD: Lorentzian tails of distant peaks through one shared Taylor "
-                            "expansion per 512-point chunk (fp64, truncation <= 1e-16 per term); opt-in, not the "
-                            "configuration `value` is measured on"}
-    # the other single-GPU configs of BASELINE.json, kernel-only (HIP events), for reference
-    others = None
+        variants["note"] = ("objective-only launches on the final swarm (HIP events around %d launches each, so "
+                            "each figure includes the ~5 us finalize launch).  noskip / baseline evaluate every "
+                            "(particle, point, peak) unit -- DEFAULT skips out-of-window Gaussians; farfield is "
+                            "opt-in and never the configuration `value` is measured on" % reps)
+        farfield = {"kernel_ms": variants["farfield_ms"],
+                    "units_per_s": float(S_local) * N * P / (variants["farfield_ms"] * 1e-3),
+                    "max_rel_diff_vs_default": variants["farfield_max_rel_diff_vs_default"]}
     if rank == 0 and world == 1 and args.workload == "C3" and args.other_configs:
         others = {}
         for name in ("C2", "C5"):
@@ -238,7 +361,7 @@ def main():
             else:
                 X2 = synth.make_swarm(sp2["lower"], sp2["upper"], c.S, seed=2, x_true=sp2["x_true"])
             with Evaluator(sp2["w"], sp2["u"], sp2["v"], sp2["weights"], device=device) as ev2:
-                B, D2 = X2.shape
+                B = X2.shape[0]
                 dX2 = ev2.dev_alloc(X2.nbytes)
                 df2 = ev2.dev_alloc(B * 8)
                 dR2 = ev2.dev_alloc(B * c.N * 8) if name == "C5" else None
@@ -261,7 +384,6 @@ def main():
                     ev2.dev_free(dR2)
     # the host-pointer entry point (X uploaded, f downloaded every call): the PCIe-inclusive
     # rate, reported beside the resident one -- never as `value`
-    host_ms = None
     if rank == 0 and world == 1 and not args.no_extras:
         Xh = sw.state()["x"]
         ev.objective_batch(Xh)
@@ -272,74 +394,98 @@ def main():
 
     units_step = float(S_local) * world * N * P
     value = units_step * args.steps / dt
+    rc = 0
     if rank == 0:
         units_launch = float(S_local) * N * P
         bytes_launch = S_local * (4 * N * 8) + S_local * D * 8 + S_local * 8
+        kst, sst = stats(k_ms), stats(s_ms)
+        t_kernel_ms = kst["mean"] if kst else float("nan")
         ach = bytes_launch / (t_kernel_ms * 1e-3) / 1e9
+        # physical HBM traffic and VALU counters: separate rocprofv3 --pmc passes of this command,
+        # committed under profiles/ -- NOT measured by this run
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        pmcf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmcf):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmcf)).get(args.workload, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        # VALU counters of the same command under rocprofv3 (separate --pmc pass), when committed
-        valu_pmc = {}
-        summ = os.path.join(ROOT, "profiles", "r01", "bench_c3_pmc_summary.json")
-        if args.workload == "C3" and args.variant == 0 and os.path.exists(summ):
+        valu = {"bound": "fp64_valu_issue", "unit": "fraction of fp64 VALU issue slots (1024 SIMDs x 2.4 GHz / 4 cycles "
+                                                     "per wave64 instruction)"}
+        summ = next((p for p in (PMC_SUMMARY, PMC_SUMMARY_FALLBACK) if os.path.exists(os.path.join(ROOT, p))), None)
+        if args.workload == "C3" and args.variant == 0 and summ:
             try:
-                sm = json.load(open(summ))
-                insts = sm["objective_kernel_pmc"]["SQ_INSTS_VALU"]["mean"]
-                valu_pmc = {"valu_busy_frac_pmc": sm.get("valu_busy_frac"),
-                            "valu_instructions_per_unit_pmc": insts * 64.0 / (4096.0 * 65536.0 * 24.0),
-                            "valu_cycles_per_instruction_pmc": sm.get("valu_cycles_per_inst"),
-                            "pmc_source": "profiles/r01/bench_c3_pmc_summary.json"}
-            except Exception:
-                valu_pmc = {}
+                sm = json.load(open(os.path.join(ROOT, summ)))
+                insts = sm["objective_kernel_pmc"]["SQ_INSTS_VALU"]["mean"]      # wave-instructions per launch
+                ipu = insts * 64.0 / (4096.0 * 65536.0 * 24.0)
+                peak = SIMDS * PEAK_CLOCK_MHZ * 1e6 / FP64_ISSUE_CYCLES          # wave-instructions / s
+                achieved = ipu * units_launch / 64.0 / (t_kernel_ms * 1e-3)
+                valu.update({"achieved": achieved, "peak": peak, "frac": achieved / peak,
+                             "achieved_unit": "fp64 wave64 VALU instructions/s",
+                             "valu_instructions_per_unit": ipu, "valu_busy_frac": sm.get("valu_busy_frac"),
+                             "valu_cycles_per_instruction": sm.get("valu_cycles_per_inst"),
+                             "from_committed_profile": True, "pmc_source": summ,
+                             "note": "instructions per unit, busy fraction and cycles per instruction come from the "
+                                     "committed SQ counter pass; the kernel time and clock are this run's"})
+            except Exception as e:
+                valu["error"] = repr(e)
+        if clock_mhz > 0:
+            valu["clock_mhz_in_run"] = clock_mhz
+            valu["clock_note"] = ("s_memtime / s_memrealtime ticks of the first workgroup of the last timed objective "
+                                  "launch (shader clock while the chip is loaded)")
         line = {
             "metric": "objective evals/sec (swarm x grid x peaks)",
             "value": value, "unit": "particle*gridpoint*peak/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d peaks, %d-pt grid, swarm %d per GPU (%d total), one PSO generation per step"
                                    % (cfg.name, P, N, S_local, S_local * world),
                        "peaks": P, "grid": N, "swarm_per_gpu": S_local, "swarm_total": S_local * world,
-                       "exchange": "rccl all_gather of %d doubles per generation" % (D + 1) if world > 1 else "none",
-                       "variant": args.variant, "generations_done": st["iteration"], "swarm_best_f": st["fg"]},
+                       "exchange": exchange_desc, "variant": args.variant, "generations_done": st["iteration"],
+                       "swarm_best_f": st["fg"], "preheat_launches": heat_launches},
+            "step_ms": sst, "kernel_ms": kst,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_from_committed_profile": traffic is not None,
                          "model": "streaming-operand bytes S*(4*N*8)+S*D*8+S*8 per launch (SURVEY 8(d)(i)); "
                                   "w/u/v/weights are shared by all particles and L2-resident, so this is an "
-                                  "effective rate, not physical HBM traffic",
+                                  "effective rate, not physical HBM traffic (`traffic`); the binding resource "
+                                  "is fp64 VALU issue, see roofline_valu",
                          "kernel": "objective_kernel", "kernel_ms": t_kernel_ms,
-                         "kernel_ms_note": "HIP events around K objective_batch_dev calls; each call is the "
-                                           "objective kernel plus its ~5 us finalize launch when the grid is segmented",
+                         "kernel_ms_note": "mean of the HIP-event durations of the objective kernel alone, one pair "
+                                           "per timed step, on the stream it is launched on",
                          "bytes_per_launch": bytes_launch, "units_per_launch": units_launch,
                          "launch": geom},
-            "valu": {"units_per_s_kernel": units_launch / (t_kernel_ms * 1e-3),
-                     "fp64_lane_ops_peak_per_s": FP64_VALU_PEAK_TFLOPS * 1e12 / 2,
-                     "note": "binding resource is fp64 vector-ALU issue; see DESIGN.md for the per-unit "
-                             "instruction count and the measured per-instruction costs", **valu_pmc},
+            "roofline_valu": valu,
         }
-        if farfield is not None:
+        if kst and not (t_kernel_ms <= ms_per_step * 1.0005):
+            line["error"] = "objective kernel (%.4f ms) longer than the step that contains it (%.4f ms)" % (
+                t_kernel_ms, ms_per_step)
+            rc = 3
+        if variants is not None:
+            line["variants"] = variants
             line["farfield_variant"] = farfield
         if others:
             line["other_configs"] = others
         if host_ms is not None:
             line["host_pointer_call"] = {"ms": host_ms, "units_per_s": units_launch / (host_ms * 1e-3),
                                          "note": "nmrfit_objective_batch with host X/f (H2D + kernel + D2H per call)"}
-        if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(spec, spec["lower"], spec["upper"], P, args.cpu_seconds, args.cpu_pool)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line))
         sys.stdout.flush()
     ev.dev_free(d_x)
     ev.dev_free(d_f)
+    if ex is not None:
+        ex.barrier()
+        if isinstance(ex, pso.RcclExchange):
+            sw.set_comm(None)
+        ex.close()
     sw.close()
     ev.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

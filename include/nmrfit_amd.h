@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NMRFIT_ABI_VERSION 1
+#define NMRFIT_ABI_VERSION 2
 
 enum {
     NMRFIT_OK = 0,
@@ -41,7 +41,8 @@ enum {
     NMRFIT_E_NO_DEVICE = -2,    /* no usable HIP device / device index out of range         */
     NMRFIT_E_HIP = -3,          /* a HIP runtime call failed; see nmrfit_last_error()       */
     NMRFIT_E_UNSUPPORTED = -4,  /* combination not implemented (e.g. fit_im with an A/B variant) */
-    NMRFIT_E_STATE = -5         /* call sequence error (e.g. pso step before init)          */
+    NMRFIT_E_STATE = -5,        /* call sequence error (e.g. pso step before init)          */
+    NMRFIT_E_COMM = -6          /* an RCCL call failed; see nmrfit_last_error()             */
 };
 
 /* Kernel variants (numerics identical to <= 1e-12 relative; for A/B measurement). */
@@ -80,6 +81,7 @@ enum {
 
 typedef struct nmrfit_ctx nmrfit_ctx;
 typedef struct nmrfit_pso nmrfit_pso;
+typedef struct nmrfit_comm nmrfit_comm;
 
 /* ---- library ------------------------------------------------------------------------- */
 int nmrfit_abi_version(void);
@@ -190,6 +192,53 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every);
 /* copy swarm state to host for inspection/tests (any pointer may be NULL):
  * x, v, p are S_local x D; fx, fp are S_local */
 int nmrfit_pso_get_state(nmrfit_pso *pso, double *x, double *v, double *p, double *fx, double *fp);
+
+/* ---- multi-GPU: the candidate exchange (RCCL over xGMI) -------------------------------------
+ * Replaces the reference's only parallel mode, `processes=self.processes` handed to pyswarm,
+ * which maps the particles of a generation over a multiprocessing.Pool (nmrfit/utils.py:182).
+ * One process per GPU; rank q owns particles [offset, offset + S_local) of the swarm and the
+ * four grid arrays are replicated.  Per generation ONE collective crosses ranks: an
+ * ncclAllGather of each rank's (D+1)-double candidate record on the context's stream,
+ * followed by the same deterministic fold on every rank.  librccl is dlopen'ed on first use;
+ * no PyTorch is involved.  Bootstrap: rank 0 calls nmrfit_comm_unique_id and hands the 128
+ * bytes to the other ranks by any means (the Python side: stdlib sockets,
+ * nmrfit_amd/rendezvous.py); then EVERY rank calls nmrfit_comm_create (collective). */
+#define NMRFIT_UNIQUE_ID_BYTES 128
+int nmrfit_comm_unique_id(void *out128);
+int nmrfit_comm_create(nmrfit_ctx *ctx, int32_t rank, int32_t nranks, const void *unique_id128,
+                       nmrfit_comm **out);
+int nmrfit_comm_destroy(nmrfit_comm *comm);
+/* rank, size and the RCCL version code (any pointer may be NULL) */
+int nmrfit_comm_info(const nmrfit_comm *comm, int32_t *rank, int32_t *nranks, int32_t *rccl_version);
+/* all-gather of n doubles per rank between device buffers, asynchronous on the context's stream */
+int nmrfit_comm_all_gather_dev(nmrfit_comm *comm, const double *d_send, double *d_recv, int64_t n);
+/* bookkeeping collectives on HOST values (1..64 doubles; op 0 sum, 1 max, 2 min), a broadcast
+ * of up to 512 bytes from `root`, and a barrier; synchronous, every rank calls them */
+int nmrfit_comm_all_reduce_host(nmrfit_comm *comm, double *inout, int32_t n, int32_t op);
+int nmrfit_comm_broadcast_host(nmrfit_comm *comm, void *buf, int64_t bytes, int32_t root);
+int nmrfit_comm_barrier(nmrfit_comm *comm);
+/* Attach a communicator to a sharded swarm (NULL detaches).  With one attached,
+ * nmrfit_pso_step / nmrfit_pso_run include the exchange: every rank of the communicator must
+ * make the same calls. */
+int nmrfit_pso_set_comm(nmrfit_pso *pso, nmrfit_comm *comm);
+/* One whole generation in one call, no Python in the loop: position update -> objective ->
+ * personal bests -> local candidate -> [all-gather over the attached communicator] -> fold with
+ * pyswarm's stopping rule.  The first call after nmrfit_pso_init only folds generation 0.
+ * Asynchronous on the context's stream. */
+int nmrfit_pso_step(nmrfit_pso *pso);
+
+/* ---- in-run timing of the hot kernel ----------------------------------------------------------
+ * With profiling enabled every objective/residual kernel launch of the context is bracketed by
+ * HIP events on the context's stream, and nmrfit_prof_mark records a step boundary; reading
+ * synchronizes and returns the per-launch kernel durations and the durations between
+ * consecutive marks, both in milliseconds and in launch order.  capacity = the number of
+ * launches / marks to keep (0 disables and frees the events).  clock_mhz (may be NULL) is the
+ * shader clock the first workgroup of the last profiled objective kernel saw while the chip
+ * was loaded (s_memtime ticks per s_memrealtime tick x 100 MHz), 0 if unknown. */
+int nmrfit_prof_enable(nmrfit_ctx *ctx, int64_t capacity);
+int nmrfit_prof_mark(nmrfit_ctx *ctx);
+int nmrfit_prof_read(nmrfit_ctx *ctx, double *kernel_ms, int64_t kernel_cap, int64_t *n_kernel,
+                     double *step_ms, int64_t step_cap, int64_t *n_step, double *clock_mhz);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnmrfit_amd.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
 OK = 0
-E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_STATE = -1, -2, -3, -4, -5
+E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_STATE, E_COMM = -1, -2, -3, -4, -5, -6
+UNIQUE_ID_BYTES = 128
 FIT_IM_OFF, FIT_IM_REFERENCE, FIT_IM_SUM = 0, 1, 2
 VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED, VARIANT_FARFIELD = 0, 1, 2, 3, 4, 5, 6
 VARIANT_NOREC = 7
@@ -86,10 +87,22 @@ SIGNATURES = {
     "nmrfit_pso_best": [_VP, _VP, _c_double_p],
     "nmrfit_pso_run": [_VP, _I64, _I32],
     "nmrfit_pso_get_state": [_VP, _VP, _VP, _VP, _VP, _VP],
+    "nmrfit_comm_unique_id": [_VP],
+    "nmrfit_comm_create": [_VP, _I32, _I32, _VP, _c_void_pp],
+    "nmrfit_comm_destroy": [_VP],
+    "nmrfit_comm_info": [_VP, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)],
+    "nmrfit_comm_all_gather_dev": [_VP, _VP, _VP, _I64],
+    "nmrfit_comm_all_reduce_host": [_VP, _c_double_p, _I32, _I32],
+    "nmrfit_comm_broadcast_host": [_VP, _VP, _I64, _I32],
+    "nmrfit_comm_barrier": [_VP],
+    "nmrfit_pso_set_comm": [_VP, _VP],
+    "nmrfit_pso_step": [_VP],
+    "nmrfit_prof_enable": [_VP, _I64],
+    "nmrfit_prof_mark": [_VP],
+    "nmrfit_prof_read": [_VP, _VP, _I64, ctypes.POINTER(_I64), _VP, _I64, ctypes.POINTER(_I64), _c_double_p],
 }
 
 _LIB = None
-_LOADED_BEFORE_TORCH = False
 
 
 def build(verbose=False):
@@ -109,9 +122,6 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NmrfitError(E_NO_DEVICE, "%s not found: build it with nmrfit_amd/csrc/build.sh "
                               "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
-        import sys
-        global _LOADED_BEFORE_TORCH
-        _LOADED_BEFORE_TORCH = "torch" not in sys.modules
         L = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
@@ -121,15 +131,6 @@ def lib():
         L.nmrfit_last_error.restype = ctypes.c_char_p
         _LIB = L
     return _LIB
-
-
-def loaded_before_torch():
-    """True when libnmrfit_amd (and with it the system HIP runtime) was loaded before torch was
-    imported.  torch bundles its own copy of the HIP runtime under the same SONAME: if torch
-    comes first both share that copy (streams and device pointers can be exchanged); if
-    libnmrfit_amd comes first the process ends up with two HIP runtimes and torch cannot
-    initialise the GPU.  Only the RCCL exchange path (pso.TorchExchange on "nccl") cares."""
-    return _LOADED_BEFORE_TORCH
 
 
 def check(rc):

@@ -14,11 +14,13 @@ def fit(data, lower, upper, expon=0.5, dynamic_weighting=True, fit_im=False, pro
     data : object with ``w, u, v`` (ndarrays) and ``peaks`` (each with ``bounds``, ``height``)
     lower, upper : parameter box, 4 + 3P floats (nmrfit/containers.py:193-217)
     expon, dynamic_weighting : error weighting (nmrfit/utils.py:191-224)
-    fit_im : must be False (the Kramers-Kronig imaginary fit is not supported)
+    fit_im : False (real part only, the default); True = the reference's imaginary term exactly as
+             nmrfit/equations.py:197-209 computes it (last peak's line only); "sum" = all peaks.
+             The Kramers-Kronig partner is evaluated in closed form on the GPU
     processes : accepted for compatibility; the batched GPU launch replaces the process pool
     summary : print the fit summary table
     options : swarmsize, maxiter, omega, phip, phig (+ minstep, minfunc, seed, device,
-              check_every, exchange)
+              check_every, polish, variant, exchange="rccl" for one process per GPU)
 
     Returns the FitUtility holding ``params``, ``error``, ``weights``.
     """

@@ -11,6 +11,6 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
     -ffp-contract=on -fno-fast-math \
     -I"$ROOT/include" -I"$HERE" \
-    "$HERE/objective.hip" "$HERE/pso.hip" "$HERE/cabi.hip" \
+    "$HERE/objective.hip" "$HERE/pso.hip" "$HERE/cabi.hip" "$HERE/comm.hip" -ldl \
     -o "$OUT/${NMRFIT_LIBNAME:-libnmrfit_amd.so}" "$@"
 echo "built $OUT/${NMRFIT_LIBNAME:-libnmrfit_amd.so}"

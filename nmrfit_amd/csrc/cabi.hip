@@ -3,6 +3,7 @@
 // device memory and HIP-event timing helpers.  No exception leaves this file.
 #include "nmrfit_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -220,6 +221,7 @@ int nmrfit_ctx_destroy(nmrfit_ctx *ctx)
         if (b) (void)hipFree(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    (void)nmrfit_prof_enable(ctx, 0);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return NMRFIT_OK;
@@ -474,6 +476,97 @@ int nmrfit_timer_end(nmrfit_ctx *ctx, double *elapsed_ms)
     float ms = 0.f;
     NMRFIT_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *elapsed_ms = (double)ms;
+    return NMRFIT_OK;
+}
+
+int nmrfit_prof_enable(nmrfit_ctx *ctx, int64_t capacity)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (capacity < 0 || capacity > (1 << 20)) {
+        set_error("nmrfit_prof_enable: capacity must be 0..2^20");
+        return NMRFIT_E_INVALID;
+    }
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto *vec : {&ctx->prof_k0, &ctx->prof_k1, &ctx->prof_marks}) {
+        for (hipEvent_t e : *vec) (void)hipEventDestroy(e);
+        vec->clear();
+    }
+    ctx->prof_cap = 0;
+    ctx->prof_nk = ctx->prof_nm = 0;
+    if (capacity == 0) {
+        if (ctx->d_clk) (void)hipFree(ctx->d_clk);
+        ctx->d_clk = nullptr;
+        return NMRFIT_OK;
+    }
+    if (!ctx->d_clk) {
+        NMRFIT_HIP(hipMalloc((void **)&ctx->d_clk, 4 * sizeof(unsigned long long)));
+        NMRFIT_HIP(hipMemsetAsync(ctx->d_clk, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    }
+    for (int64_t i = 0; i < capacity; ++i) {
+        hipEvent_t a = nullptr, b = nullptr, c = nullptr;
+        NMRFIT_HIP(hipEventCreate(&a));
+        ctx->prof_k0.push_back(a);
+        NMRFIT_HIP(hipEventCreate(&b));
+        ctx->prof_k1.push_back(b);
+        NMRFIT_HIP(hipEventCreate(&c));
+        ctx->prof_marks.push_back(c);
+    }
+    // one more mark than steps: n steps are bracketed by n + 1 marks
+    hipEvent_t last = nullptr;
+    NMRFIT_HIP(hipEventCreate(&last));
+    ctx->prof_marks.push_back(last);
+    ctx->prof_cap = capacity;
+    return NMRFIT_OK;
+}
+
+int nmrfit_prof_mark(nmrfit_ctx *ctx)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (ctx->prof_cap == 0) {
+        set_error("nmrfit_prof_mark before nmrfit_prof_enable");
+        return NMRFIT_E_STATE;
+    }
+    if (ctx->prof_nm > ctx->prof_cap) return NMRFIT_OK;   // full: later marks are dropped
+    NMRFIT_HIP(hipEventRecord(ctx->prof_marks[(size_t)ctx->prof_nm], ctx->stream));
+    ++ctx->prof_nm;
+    return NMRFIT_OK;
+}
+
+int nmrfit_prof_read(nmrfit_ctx *ctx, double *kernel_ms, int64_t kernel_cap, int64_t *n_kernel, double *step_ms,
+                     int64_t step_cap, int64_t *n_step, double *clock_mhz)
+{
+    int rc = bind(ctx);
+    if (rc != NMRFIT_OK) return rc;
+    if (kernel_cap < 0 || step_cap < 0 || (kernel_cap > 0 && !kernel_ms) || (step_cap > 0 && !step_ms)) {
+        set_error("nmrfit_prof_read: bad arguments");
+        return NMRFIT_E_INVALID;
+    }
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t nk = std::min<int64_t>(ctx->prof_nk, kernel_cap);
+    for (int64_t i = 0; i < nk; ++i) {
+        float ms = 0.f;
+        NMRFIT_HIP(hipEventElapsedTime(&ms, ctx->prof_k0[(size_t)i], ctx->prof_k1[(size_t)i]));
+        kernel_ms[i] = (double)ms;
+    }
+    const int64_t ns = std::min<int64_t>(std::max<int64_t>(ctx->prof_nm - 1, 0), step_cap);
+    for (int64_t i = 0; i < ns; ++i) {
+        float ms = 0.f;
+        NMRFIT_HIP(hipEventElapsedTime(&ms, ctx->prof_marks[(size_t)i], ctx->prof_marks[(size_t)i + 1]));
+        step_ms[i] = (double)ms;
+    }
+    if (n_kernel) *n_kernel = nk;
+    if (n_step) *n_step = ns;
+    if (clock_mhz) {
+        *clock_mhz = 0.0;
+        if (ctx->d_clk && ctx->prof_nk > 0) {
+            unsigned long long t[4] = {0, 0, 0, 0};
+            NMRFIT_HIP(hipMemcpy(t, ctx->d_clk, sizeof t, hipMemcpyDeviceToHost));
+            if (t[3] > t[1] && t[2] > t[0]) *clock_mhz = 100.0 * (double)(t[2] - t[0]) / (double)(t[3] - t[1]);
+        }
+    }
+    ctx->prof_nk = ctx->prof_nm = 0;   // reading rewinds
     return NMRFIT_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "nmrfit_amd.h"
 
@@ -17,7 +18,8 @@ constexpr int kBlock = kWave * kWavesPerBlock;
 #endif
 constexpr int kPointsPerLane = NMRFIT_POINTS;    // grid points register-blocked per lane per chunk
 constexpr int kChunk = kWave * kPointsPerLane;   // 512 grid points per wave per chunk
-constexpr int kMaxPeaks = 1000;      // LDS: 4 waves x P x 40 B + 1 KiB of block seeds <= 160 KiB
+constexpr int kMaxPeaks = 1000;      // LDS: 4 waves x P x (32 B PeakLor + 8 B PeakWin [+ 16 B recurrence + 32 B PeakFast,
+                                     // dropped above P ~ 450]) + 1 KiB of block seeds <= 160 KiB
 
 // Per-(particle, peak) constants staged in LDS: see objective.hip.
 struct PeakLor {
@@ -82,6 +84,11 @@ struct nmrfit_ctx {
     int variant = NMRFIT_VARIANT_DEFAULT;
     int fit_im = 0;              // 0 real only; 1 reference-compatible fit_im=True; 2 all-peak imaginary model
     nmrfit::LaunchGeom last;
+    // in-run timing (nmrfit_prof_*): event pairs around the objective kernel, step marks
+    int64_t prof_cap = 0;
+    std::vector<hipEvent_t> prof_k0, prof_k1, prof_marks;
+    int64_t prof_nk = 0, prof_nm = 0;
+    unsigned long long *d_clk = nullptr;   // [4]: (s_memtime, s_memrealtime) at the start / end of workgroup 0
 };
 
 namespace nmrfit {
@@ -99,6 +106,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
 int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need);
 // centred grid + per-chunk (min,max) table from the raw device copy of w
 int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw);
+// gather every rank's n-double record over the communicator (comm.hip), on the context's stream
+int comm_all_gather(nmrfit_comm *c, const double *d_send, int64_t n, const double **d_all);
 // per-peak real/imag contributions on a (centred) output grid resident on the device
 int launch_contributions(nmrfit_ctx *ctx, int32_t P, const double *dx, int64_t Nout, const double *d_wc_out,
                          double *d_real, double *d_imag);

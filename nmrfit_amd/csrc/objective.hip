@@ -481,7 +481,8 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, double wspan, int nseg,
     int64_t seg_len, int blk_chunks, double lane_step, double rec_devk,
     double *__restrict__ out,       // nseg == 1: f[S];  else per-block sums [S * n_blocks] (x2 with FIT_IM)
-    double *__restrict__ R_out)     // WRITE_R: residual rows [S*N]
+    double *__restrict__ R_out,     // WRITE_R: residual rows [S*N]
+    unsigned long long *__restrict__ clk)   // profiling only (else null): shader / reference clock of workgroup 0
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -517,6 +518,10 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                      (size_t)wave * P;
 
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (clk && g == 0 && lane == 0) {   // nmrfit_prof_*: ticks of the core clock and of the 100 MHz reference
+        clk[0] = __builtin_amdgcn_s_memtime();
+        clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
     const bool active = g < S * nseg;
     const int64_t particle = active ? g / nseg : 0;
     const int seg = active ? (int)(g % nseg) : 0;
@@ -1015,6 +1020,10 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     else
         chunk_loop(std::false_type{});
 
+    if (clk && g == 0 && lane == 0) {
+        clk[2] = __builtin_amdgcn_s_memtime();
+        clk[3] = __builtin_amdgcn_s_memrealtime();
+    }
     if (nseg == 1 && lane == 0) {
         if (FIT_IM == 0)
             out[particle] = sqrt(ss / (double)N);
@@ -1109,7 +1118,11 @@ int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, doub
     hipLaunchKernelGGL((objective_kernel<VARIANT, WR, FI>), dim3((unsigned)blocks), dim3(kBlock), lds,         \
                        ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,     \
                        ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, blk_chunks, ctx->lane_step,                 \
-                       ctx->grid_dev * 11.0e10, out, dR)
+                       ctx->grid_dev * 11.0e10, out, dR, clk)
+    // nmrfit_prof_enable: HIP events on the launch stream around this kernel alone
+    const bool prof = ctx->prof_cap > 0 && ctx->prof_nk < ctx->prof_cap;
+    unsigned long long *clk = prof ? ctx->d_clk : nullptr;
+    if (prof) NMRFIT_HIP(hipEventRecord(ctx->prof_k0[(size_t)ctx->prof_nk], ctx->stream));
     if (dR) {
         NMRFIT_LAUNCH(true, 0);
     } else if (fit_im == 0) {
@@ -1125,6 +1138,10 @@ int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, doub
     }
 #undef NMRFIT_LAUNCH
     NMRFIT_HIP(hipGetLastError());
+    if (prof) {
+        NMRFIT_HIP(hipEventRecord(ctx->prof_k1[(size_t)ctx->prof_nk], ctx->stream));
+        ++ctx->prof_nk;
+    }
     return NMRFIT_OK;
 }
 

@@ -50,6 +50,7 @@ struct nmrfit_pso {
     double *d_part_val = nullptr;      // pso_select_kernel: per-workgroup (min fp, index) posts
     long long *d_part_idx = nullptr;
     unsigned *d_ticket = nullptr;
+    nmrfit_comm *comm = nullptr;       // attached communicator (sharded swarm): the exchange runs inside nmrfit_pso_step
     bool initialized = false;    // nmrfit_pso_init has run
     bool seeded = false;         // the generation-0 candidates have been folded into (g, fg)
 };
@@ -782,6 +783,49 @@ int nmrfit_pso_apply_global_dev(nmrfit_pso *pso, const double *d_candidates, int
     return NMRFIT_OK;
 }
 
+int nmrfit_pso_set_comm(nmrfit_pso *pso, nmrfit_comm *comm)
+{
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipStreamSynchronize(pso->ctx->stream));
+    pso->comm = comm;
+    return NMRFIT_OK;
+}
+
+// candidate exchange (one all-gather over the attached communicator) + fold
+static int exchange_and_fold(nmrfit_pso *pso)
+{
+    if (!pso->comm) return nmrfit_pso_apply_global_dev(pso, pso->d_cand, 1);
+    const double *d_all = nullptr;
+    int32_t nranks = 1;
+    int rc = comm_all_gather(pso->comm, pso->d_cand, pso->D + 1, &d_all);
+    if (rc != NMRFIT_OK) return rc;
+    if ((rc = nmrfit_comm_info(pso->comm, nullptr, &nranks, nullptr)) != NMRFIT_OK) return rc;
+    return nmrfit_pso_apply_global_dev(pso, d_all, nranks);
+}
+
+int nmrfit_pso_step(nmrfit_pso *pso)
+{
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    if (!pso->initialized) {
+        set_error("nmrfit_pso_step before nmrfit_pso_init");
+        return NMRFIT_E_STATE;
+    }
+    if (!pso->seeded) return exchange_and_fold(pso);   // generation 0: (g, fg) from the initial candidates
+    if (pso->comm || pso->S == 0) {
+        if ((rc = nmrfit_pso_step_local(pso)) != NMRFIT_OK) return rc;
+        return exchange_and_fold(pso);
+    }
+    // single rank: the fold and the stopping rule ride in the select launch
+    const int64_t n = pso->S * pso->D;
+    hipLaunchKernelGGL(pso_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pso->ctx->stream, pso->S,
+                       pso->D, pso->offset, pso->prm.seed, pso->prm.omega, pso->prm.phip, pso->prm.phig, pso->d_flags,
+                       pso->d_best, pso->d_lb, pso->d_ub, pso->d_p, pso->d_x, pso->d_v);
+    NMRFIT_HIP(hipGetLastError());
+    return evaluate_and_select(pso, kTailApply);
+}
+
 int nmrfit_pso_status(nmrfit_pso *pso, int64_t *iteration, int32_t *stop_code, double *fg)
 {
     int rc = bind_pso(pso);
@@ -822,7 +866,20 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
         if ((rc = nmrfit_pso_init(pso)) != NMRFIT_OK) return rc;
     }
     if (!pso->seeded) {
-        if ((rc = nmrfit_pso_apply_global_dev(pso, pso->d_cand, 1)) != NMRFIT_OK) return rc;
+        if ((rc = exchange_and_fold(pso)) != NMRFIT_OK) return rc;
+    }
+    if (pso->comm) {
+        // sharded swarm: every rank runs the same generations and folds the same gathered records,
+        // so every rank reads the same stop flag at the same poll and leaves the loop together
+        for (int64_t it = 1; it <= maxiter; ++it) {
+            if ((rc = nmrfit_pso_step(pso)) != NMRFIT_OK) return rc;
+            if (it % check_every == 0 || it == maxiter) {
+                int32_t stop = 0;
+                if ((rc = nmrfit_pso_status(pso, nullptr, &stop, nullptr)) != NMRFIT_OK) return rc;
+                if (stop) break;
+            }
+        }
+        return NMRFIT_OK;
     }
     const bool fused = small_swarm(pso);
     if (fused && maxiter > 0) {

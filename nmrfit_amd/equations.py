@@ -17,9 +17,10 @@ quadrature per grid point (equations.py:9-80) is evaluated in closed form on the
 There is no CPU fallback in this module: without the HIP library and a gfx950 device every
 evaluation raises ``NmrfitError``.
 """
+import collections
 import ctypes
+import hashlib
 import weakref
-import zlib
 
 import numpy as np
 
@@ -178,6 +179,26 @@ class Evaluator:
         _cabi.check(self._lib.nmrfit_timer_end(self._ctx, ctypes.byref(ms)))
         return ms.value
 
+    def prof_enable(self, capacity):
+        """Bracket every objective kernel launch with HIP events (nmrfit_prof_*); 0 disables."""
+        _cabi.check(self._lib.nmrfit_prof_enable(self._ctx, int(capacity)))
+        self._prof_cap = int(capacity)
+
+    def prof_mark(self):
+        _cabi.check(self._lib.nmrfit_prof_mark(self._ctx))
+
+    def prof_read(self):
+        """(kernel_ms[], step_ms[], clock_mhz): per-launch durations of the objective kernel, the
+        durations between consecutive marks, and the shader clock seen by the last profiled
+        launch (0 if unknown).  Synchronizes; rewinds the recording."""
+        cap = getattr(self, "_prof_cap", 0)
+        k = np.zeros(max(cap, 1))
+        st = np.zeros(max(cap, 1))
+        nk, ns, mhz = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_double(0.0)
+        _cabi.check(self._lib.nmrfit_prof_read(self._ctx, _cabi.ptr(k), cap, ctypes.byref(nk), _cabi.ptr(st), cap,
+                                               ctypes.byref(ns), ctypes.byref(mhz)))
+        return k[:nk.value].copy(), st[:ns.value].copy(), mhz.value
+
     def last_launch(self):
         waves, nseg, seg_len = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int64(0)
         _cabi.check(self._lib.nmrfit_last_launch(self._ctx, ctypes.byref(waves), ctypes.byref(nseg),
@@ -186,12 +207,27 @@ class Evaluator:
 
 
 # ---- scalar shim with the reference signature ---------------------------------------------
-_shim_cache = {}
+_shim_cache = collections.OrderedDict()     # least recently used first
 _SHIM_CACHE_MAX = 4
 
 
 def _key(*arrays):
-    return tuple((a.size, zlib.adler32(a.view(np.uint8))) for a in arrays)
+    """Content key of the constant arrays: a 128-bit digest each (a collision would silently
+    evaluate against another spectrum's data, so no 32-bit checksums here)."""
+    return tuple((a.size, hashlib.blake2b(a.view(np.uint8), digest_size=16).digest()) for a in arrays)
+
+
+def _cached_evaluator(k, make):
+    ev = _shim_cache.get(k)
+    if ev is None:
+        while len(_shim_cache) >= _SHIM_CACHE_MAX:
+            _, old = _shim_cache.popitem(last=False)      # evict the least recently used
+            old.close()
+        ev = make()
+        _shim_cache[k] = ev
+    else:
+        _shim_cache.move_to_end(k)
+    return ev
 
 
 def objective(x, w, u, v, weights, fit_im=False):
@@ -200,14 +236,7 @@ def objective(x, w, u, v, weights, fit_im=False):
     third-party optimiser that calls this per particle still avoids re-uploading them; use
     ``Evaluator.objective_batch`` to evaluate a whole swarm per launch."""
     arrays = tuple(_cabi.f64(a) for a in (w, u, v, weights))
-    k = _key(*arrays)
-    ev = _shim_cache.get(k)
-    if ev is None:
-        if len(_shim_cache) >= _SHIM_CACHE_MAX:
-            _, old = _shim_cache.popitem()
-            old.close()
-        ev = Evaluator(*arrays)
-        _shim_cache[k] = ev
+    ev = _cached_evaluator(_key(*arrays), lambda: Evaluator(*arrays))
     return float(ev.objective_batch(np.asarray(x, dtype=np.float64), fit_im=fit_im)[0])
 
 
@@ -223,16 +252,8 @@ def laplace1d(x, n=10, omega=0.33333333):
 def _grid_evaluator(w):
     """An Evaluator that only carries a grid (for voigt / kk_relation_vectorized)."""
     w = _cabi.f64(w)
-    k = ("grid",) + _key(w)
-    ev = _shim_cache.get(k)
-    if ev is None:
-        if len(_shim_cache) >= _SHIM_CACHE_MAX:
-            _, old = _shim_cache.popitem()
-            old.close()
-        z = np.zeros_like(w)
-        ev = Evaluator(w, z, z, np.ones_like(w))
-        _shim_cache[k] = ev
-    return ev
+    z = np.zeros_like(w)
+    return _cached_evaluator(("grid",) + _key(w), lambda: Evaluator(w, z, z, np.ones_like(w)))
 
 
 def voigt(w, r, yoff, width, loc, a):

@@ -83,10 +83,16 @@ def least_squares(evaluator, x0, lower, upper, **kwargs):
     return res
 
 
-def polish(evaluator, x_swarm, lower, upper, **kwargs):
-    """Refine a swarm result; keeps it if the least-squares step does not improve on it."""
+def polish(evaluator, x_swarm, lower, upper, fit_im=False, **kwargs):
+    """Refine a swarm result; keeps it if the least-squares step does not improve on it.
+
+    The residual rows are the REAL-part residual only.  ``fit_im`` is the mode the swarm
+    minimised: acceptance and the returned value use that same objective
+    (``objective_batch(x, fit_im=...)``), so a step that lowers the real-part RMSE but raises the
+    imaginary term is rejected and the meaning of the returned error never changes."""
+    x_swarm = np.asarray(x_swarm, dtype=np.float64)
     res = least_squares(evaluator, x_swarm, lower, upper, **kwargs)
-    f0 = float(evaluator.objective_batch(np.asarray(x_swarm, dtype=np.float64))[0])
-    if res.objective <= f0:
-        return res.x, res.objective, res
-    return np.asarray(x_swarm, dtype=np.float64), f0, res
+    f0, f1 = (float(f) for f in evaluator.objective_batch(np.stack([x_swarm, res.x]), fit_im=fit_im))
+    if f1 <= f0:
+        return res.x, f1, res
+    return x_swarm, f0, res

@@ -15,7 +15,9 @@ Two implementations of the same generation, bit-compatible in the swarm arithmet
 
 Sharding: rank q of G owns particles [offset, offset+S_local); the
 only cross-rank traffic is one all-gather of a (D+1)-double candidate record per generation
-(``TorchExchange``: RCCL when the process group is "nccl", gloo on CPU).  Random numbers are
+(``RcclExchange``: ncclAllGather inside libnmrfit_amd.so, on the kernels' stream, no Python in
+the generation loop; ``SocketExchange`` / ``TorchExchange``: the record staged through the
+host, for CPU tests and one-GPU rehearsals).  Random numbers are
 a function of (seed, generation, dimension, GLOBAL particle index), so the trajectory does
 not depend on the number of ranks.
 
@@ -84,10 +86,129 @@ class LocalExchange:
     def gather_host(self, cand):
         return cand[None, :]
 
+    def broadcast_seed(self, seed):
+        return int(seed)
+
+
+class RcclExchange:
+    """The product exchange for multi-GPU fits: an RCCL communicator created through the C-ABI
+    (``nmrfit_comm_*``, csrc/comm.hip).  Attached to a DeviceSwarm, every generation's
+    ncclAllGather of the (D+1)-double record and the fold run inside ``nmrfit_pso_step`` on the
+    context's HIP stream -- no host synchronisation, no Python, no PyTorch in the loop.
+
+    ``channel`` is a ``rendezvous.Channel`` (or anything with rank / world / broadcast) used
+    once, to hand rank 0's 128-byte unique id to the other ranks.  Collective: every rank
+    constructs it, with its own Evaluator (one GPU per process)."""
+
+    def __init__(self, evaluator, channel=None):
+        from . import rendezvous
+        self._lib = _cabi.lib()
+        self.ev = evaluator
+        self._own_channel = channel is None
+        self.channel = rendezvous.Channel() if channel is None else channel
+        self.rank, self.world = self.channel.rank, self.channel.world
+        uid = ctypes.create_string_buffer(_cabi.UNIQUE_ID_BYTES)
+        if self.rank == 0:
+            _cabi.check(self._lib.nmrfit_comm_unique_id(uid))
+        raw = self.channel.broadcast(uid.raw if self.rank == 0 else b"")
+        if len(raw) != _cabi.UNIQUE_ID_BYTES:
+            raise RuntimeError("rendezvous delivered %d bytes of RCCL unique id, expected %d"
+                               % (len(raw), _cabi.UNIQUE_ID_BYTES))
+        uid = ctypes.create_string_buffer(raw, _cabi.UNIQUE_ID_BYTES)
+        self._h = ctypes.c_void_p()
+        _cabi.check(self._lib.nmrfit_comm_create(evaluator.handle, self.rank, self.world, uid, ctypes.byref(self._h)))
+        evaluator._children.add(self)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        r, n, v = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        _cabi.check(self._lib.nmrfit_comm_info(self._h, ctypes.byref(r), ctypes.byref(n), ctypes.byref(v)))
+        return dict(rank=r.value, world=n.value, rccl_version=v.value)
+
+    def barrier(self):
+        _cabi.check(self._lib.nmrfit_comm_barrier(self._h))
+
+    def all_reduce(self, values, op="max"):
+        a = np.array(values, dtype=np.float64).reshape(-1)
+        _cabi.check(self._lib.nmrfit_comm_all_reduce_host(self._h, a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                          a.size, {"sum": 0, "max": 1, "min": 2}[op]))
+        return a
+
+    def broadcast_seed(self, seed):
+        buf = (ctypes.c_uint64 * 1)(int(seed) & 0xFFFFFFFFFFFFFFFF)
+        _cabi.check(self._lib.nmrfit_comm_broadcast_host(self._h, buf, 8, 0))
+        return int(buf[0])
+
+    def gather_host(self, cand):
+        """Host-array form of the exchange (tests): through device buffers and ncclAllGather."""
+        cand = _cabi.f64(cand)
+        n = cand.size
+        d_s, d_r = self.ev.dev_alloc(n * 8), self.ev.dev_alloc(n * 8 * self.world)
+        try:
+            self.ev.upload(d_s, cand)
+            _cabi.check(self._lib.nmrfit_comm_all_gather_dev(self._h, d_s, d_r, n))
+            return self.ev.download(d_r, (self.world, n))
+        finally:
+            self.ev.dev_free(d_s)
+            self.ev.dev_free(d_r)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.nmrfit_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+        if getattr(self, "_own_channel", False) and self.channel is not None:
+            self.channel.close()
+            self.channel = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SocketExchange:
+    """Host-staged exchange over a ``rendezvous.Channel`` (standard-library sockets): the
+    (D+1)-double record goes device -> host -> rank 0 -> every rank -> device.  For CPU tests of
+    the sharding logic and for rehearsing several ranks on ONE GPU (RCCL refuses two ranks on
+    the same device); multi-GPU fits use RcclExchange."""
+
+    def __init__(self, channel=None):
+        from . import rendezvous
+        self._own_channel = channel is None
+        self.channel = rendezvous.Channel() if channel is None else channel
+        self.rank, self.world = self.channel.rank, self.channel.world
+
+    def gather_host(self, cand):
+        cand = np.ascontiguousarray(cand, dtype=np.float64)
+        parts = self.channel.all_gather(cand.tobytes())
+        return np.stack([np.frombuffer(p, dtype=np.float64) for p in parts])
+
+    def broadcast_seed(self, seed):
+        import struct
+        return struct.unpack("<Q", self.channel.broadcast(struct.pack("<Q", int(seed) & 0xFFFFFFFFFFFFFFFF)))[0]
+
+    def barrier(self):
+        self.channel.barrier()
+
+    def all_reduce(self, values, op="max"):
+        a = np.array(values, dtype=np.float64).reshape(-1)
+        parts = np.stack([np.frombuffer(p, dtype=np.float64) for p in self.channel.all_gather(a.tobytes())])
+        return {"sum": parts.sum, "max": parts.max, "min": parts.min}[op](axis=0)
+
+    def close(self):
+        if self._own_channel and self.channel is not None:
+            self.channel.close()
+            self.channel = None
+
 
 class TorchExchange:
-    """One all-gather of (D+1) doubles per generation over a torch.distributed group
-    (backend "nccl" = RCCL over xGMI on MI355X; "gloo" on CPU).  torch is plumbing only."""
+    """The same host-staged exchange over a torch.distributed group (gloo): kept for the CPU
+    tests that rehearse the N>1 logic under ``torch.distributed.run``.  Not used by the product
+    path -- multi-GPU fits exchange through RcclExchange without importing torch."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -98,21 +219,17 @@ class TorchExchange:
         self.backend = dist.get_backend(group)
 
     def gather_host(self, cand):
-        """Host-array form (fit() on several ranks, CPU tests): with the nccl backend the
-        record takes a round trip through a CUDA tensor, with gloo it stays on the host."""
         import torch
         t = torch.from_numpy(np.ascontiguousarray(cand))
-        on_gpu = self.backend == "nccl"
-        if on_gpu:
-            t = t.cuda()
-        out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=t.device)   # flat: gloo needs 1-D
+        out = torch.empty(self.world * t.numel(), dtype=t.dtype)   # flat: gloo needs 1-D
         self._dist.all_gather_into_tensor(out, t, group=self.group)
-        out = out.view(self.world, t.numel())
-        return out.cpu().numpy() if on_gpu else out.numpy()
+        return out.view(self.world, t.numel()).numpy()
 
-    def gather_device(self, send, recv):
-        """send: cuda tensor (D+1), recv: flat cuda tensor world*(D+1); ordered on torch's current stream."""
-        self._dist.all_gather_into_tensor(recv, send, group=self.group)
+    def broadcast_seed(self, seed):
+        import torch
+        t = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64)
+        self._dist.broadcast(t, src=0, group=self.group)
+        return int(t.item())
 
 
 # ---- numpy mirror -----------------------------------------------------------------------------
@@ -248,6 +365,18 @@ class DeviceSwarm:
     def step_local(self):
         _cabi.check(self._lib.nmrfit_pso_step_local(self._h))
 
+    def set_comm(self, exchange):
+        """Attach an RcclExchange (None detaches): ``step`` and ``run`` then include the
+        all-gather of the candidate records and the fold, all enqueued by one C call."""
+        _cabi.check(self._lib.nmrfit_pso_set_comm(self._h, exchange.handle if exchange is not None else None))
+        self._comm = exchange
+
+    def step(self):
+        """One whole generation in one C call (update, objective, personal bests, candidate,
+        exchange over the attached communicator, fold).  The first call after ``init`` only
+        folds generation 0."""
+        _cabi.check(self._lib.nmrfit_pso_step(self._h))
+
     def candidate_dev(self):
         p = ctypes.c_void_p()
         _cabi.check(self._lib.nmrfit_pso_candidate_dev(self._h, ctypes.byref(p)))
@@ -309,94 +438,40 @@ STOP_MESSAGES = {
 }
 
 
-class RcclGeneration:
-    """One generation of a sharded DeviceSwarm with the candidate exchange on the GPU: the
-    swarm kernels and the RCCL all-gather (torch.distributed "nccl" backend) are enqueued on
-    ONE explicit HIP stream, so a generation needs no host synchronisation at all.
-
-    (torch's default stream is the null stream, whose handle 0 the C-ABI reads as "use the
-    context's own stream" -- hence a dedicated torch stream made current.)"""
-
-    def __init__(self, swarm, exchange):
-        if _cabi.loaded_before_torch():
-            raise RuntimeError("import torch before the first nmrfit_amd GPU call when exchanging candidates over "
-                               "RCCL: torch bundles its own HIP runtime and both libraries must share it "
-                               "(see nmrfit_amd._cabi.loaded_before_torch)")
-        import torch
-        self.torch = torch
-        self.swarm, self.exchange = swarm, exchange
-        dev = torch.device("cuda", swarm.ev.device)
-        self.stream = torch.cuda.Stream(device=dev)
-        torch.cuda.set_stream(self.stream)
-        swarm.ev.set_stream(self.stream.cuda_stream)
-        n = swarm.D + 1
-        self.send = torch.zeros(n, dtype=torch.float64, device=dev)
-        self.recv = torch.zeros(exchange.world * n, dtype=torch.float64, device=dev)
-        swarm.set_candidate_dev(self.send.data_ptr())
-
-    def fold(self):
-        self.exchange.gather_device(self.send, self.recv)
-        self.swarm.apply_global_dev(self.recv.data_ptr(), self.exchange.world)
-
-    def init(self):
-        self.swarm.init()
-        self.fold()
-
-    def step(self):
-        self.swarm.step_local()
-        self.fold()
-
-    def synchronize(self):
-        self.stream.synchronize()
-
-    def close(self):
-        """Detach from the torch stream and buffers (before they are freed)."""
-        self.synchronize()
-        self.swarm.set_candidate_dev(None)
-        self.swarm.ev.set_stream(None)
-
-
 def run_sharded(swarm, exchange, maxiter, check_every=1, verbose=False):
     """Generation loop for a (possibly sharded) swarm; every rank must call it.  Returns
-    (x_best, f_best).  A DeviceSwarm over an "nccl" process group exchanges candidates on the
-    GPU (RcclGeneration); otherwise (HostSwarm, gloo) the (D+1)-double record goes through
-    the host."""
-    on_gpu = (isinstance(swarm, DeviceSwarm) and isinstance(exchange, TorchExchange)
-              and exchange.backend == "nccl")
-    if on_gpu:
-        gen = RcclGeneration(swarm, exchange)
-        init, step = gen.init, gen.step
+    (x_best, f_best).  A DeviceSwarm with an RcclExchange runs entirely inside the library
+    (``nmrfit_pso_run`` with the communicator attached: one ncclAllGather per generation on
+    the kernels' stream); otherwise (HostSwarm, SocketExchange, gloo) the (D+1)-double record
+    is staged through the host."""
+    if isinstance(swarm, DeviceSwarm) and isinstance(exchange, RcclExchange):
+        swarm.set_comm(exchange)
+        try:
+            swarm.run(maxiter, check_every)
+            stopped = swarm.status()["stop"]
+            best = swarm.best()
+        finally:
+            swarm.set_comm(None)
     else:
-        gen = None
-
-        def init():
-            swarm.init()
-            swarm.apply_global(exchange.gather_host(swarm.candidate()))
-
-        def step():
+        swarm.init()
+        swarm.apply_global(exchange.gather_host(swarm.candidate()))
+        it = 0
+        stopped = 0
+        while it < maxiter:
+            it += 1
             swarm.step_local()
             swarm.apply_global(exchange.gather_host(swarm.candidate()))
-    init()
-    it = 0
-    stopped = 0
-    while it < maxiter:
-        it += 1
-        step()
-        if it % check_every == 0 or it == maxiter:
-            stopped = swarm.stop if isinstance(swarm, HostSwarm) else swarm.status()["stop"]
-            if stopped:
-                break
+            if it % check_every == 0 or it == maxiter:
+                stopped = swarm.stop if isinstance(swarm, HostSwarm) else swarm.status()["stop"]
+                if stopped:
+                    break
+        best = (swarm.best_x.copy(), float(swarm.best_f)) if isinstance(swarm, HostSwarm) else swarm.best()
     if verbose and exchange.rank == 0:
         if stopped:
             print(STOP_MESSAGES[stopped].format(minfunc=getattr(swarm, "minfunc", 1e-8),
                                                 minstep=getattr(swarm, "minstep", 1e-8)))
         else:
             print('Stopping search: maximum iterations reached --> {:}'.format(maxiter))
-    if isinstance(swarm, HostSwarm):
-        return swarm.best_x.copy(), float(swarm.best_f)
-    best = swarm.best()
-    if gen is not None:
-        gen.close()
     return best
 
 

@@ -1,0 +1,225 @@
+"""
+Process bootstrap for a sharded swarm, standard library only (no torch, no MPI).
+
+One process per GPU (launched by ``python -m torch.distributed.run``, by ``bench.py --gpus N``
+itself, or by anything else that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR /
+MASTER_PORT).  The ranks need exactly two things from each other before RCCL takes over:
+the 128-byte RCCL unique id that rank 0 generates (``nmrfit_comm_unique_id`` ->
+``nmrfit_comm_create``, include/nmrfit_amd.h) and, for CPU tests and one-GPU rehearsals, a
+host-staged all-gather of the (D+1)-double candidate record.  Both go over a star of TCP
+connections to rank 0.
+
+Where rank 0 listens:
+
+* ``NMRFIT_RDZV_PORT`` set: on MASTER_ADDR at that port (multi-node capable; the port must
+  be free, so it cannot be MASTER_PORT under torchrun, whose agent keeps its own store
+  listening there);
+* otherwise (one node, the default): on an ephemeral port of 127.0.0.1, published through a
+  small file in the temporary directory whose name is derived from MASTER_ADDR, MASTER_PORT
+  and a token shared by the ranks of ONE launch -- ``NMRFIT_RDZV_TOKEN`` if set, else the
+  parent process id (torchrun's agent, or bench.py's launcher, is the parent of every rank).
+  No fixed port is needed, so nothing can collide with the launcher's own rendezvous.
+
+A rank announces itself with a magic word, the token and its rank number; rank 0 rejects
+anything else, so a stray connection cannot join the group.
+"""
+import hashlib
+import os
+import socket
+import struct
+import tempfile
+import time
+
+_MAGIC = b"NMRFITv1"
+DEFAULT_TIMEOUT = float(os.environ.get("NMRFIT_RDZV_TIMEOUT", "300"))
+
+
+def env_rank_world():
+    """(rank, local_rank, world) from the launcher's environment (defaults: a single rank)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def _token():
+    t = os.environ.get("NMRFIT_RDZV_TOKEN")
+    if t:
+        return t
+    return "ppid%d" % os.getppid()
+
+
+def _rdzv_file(token):
+    key = "%s|%s|%s|%d" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"), token,
+                           os.getuid())
+    h = hashlib.sha256(key.encode()).hexdigest()[:24]
+    return os.path.join(os.environ.get("NMRFIT_RDZV_DIR", tempfile.gettempdir()), "nmrfit_rdzv_%s" % h)
+
+
+def _send(sock, payload):
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("rendezvous peer closed the connection")
+        buf.extend(chunk)
+    return bytes(buf)
+
+
+def _recv(sock):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > (1 << 26):
+        raise ConnectionError("rendezvous message too large")
+    return _recv_exact(sock, n)
+
+
+class Channel:
+    """A star of TCP connections centred on rank 0: broadcast, all-gather and barrier of small
+    byte strings.  Every rank must make the same sequence of calls."""
+
+    def __init__(self, rank=None, world=None, timeout=DEFAULT_TIMEOUT):
+        r, _, w = env_rank_world()
+        self.rank = r if rank is None else int(rank)
+        self.world = w if world is None else int(world)
+        self.timeout = timeout
+        self._peers = {}       # rank 0: rank -> socket
+        self._sock = None      # other ranks: the connection to rank 0
+        self._listener = None
+        self._file = None
+        if self.world > 1:
+            self._connect()
+
+    # -- set-up ------------------------------------------------------------------------------
+    def _connect(self):
+        token = _token()
+        tok = token.encode()
+        port_env = os.environ.get("NMRFIT_RDZV_PORT")
+        deadline = time.monotonic() + self.timeout
+        if self.rank == 0:
+            ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            if port_env:
+                ls.bind(("", int(port_env)))
+            else:
+                ls.bind(("127.0.0.1", 0))
+            ls.listen(max(16, self.world))
+            self._listener = ls
+            if not port_env:
+                path = _rdzv_file(token)
+                tmp = "%s.%d.tmp" % (path, os.getpid())
+                with open(tmp, "w") as fh:
+                    fh.write("127.0.0.1:%d\n" % ls.getsockname()[1])
+                os.replace(tmp, path)        # atomic: a reader sees the whole line or no file
+                self._file = path
+            ls.settimeout(1.0)
+            while len(self._peers) < self.world - 1:
+                if time.monotonic() > deadline:
+                    raise TimeoutError("rendezvous: %d of %d ranks joined within %.0f s"
+                                       % (len(self._peers) + 1, self.world, self.timeout))
+                try:
+                    conn, _ = ls.accept()
+                except socket.timeout:
+                    continue
+                try:
+                    conn.settimeout(10.0)
+                    hello = _recv(conn)
+                    ok = hello.startswith(_MAGIC) and hello[len(_MAGIC) + 4:] == tok
+                    peer = struct.unpack("<i", hello[len(_MAGIC):len(_MAGIC) + 4])[0] if ok else -1
+                    if not ok or not (0 < peer < self.world) or peer in self._peers:
+                        conn.close()
+                        continue
+                    conn.settimeout(self.timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self._peers[peer] = conn
+                except (OSError, struct.error, ConnectionError):
+                    conn.close()
+            if self._file:
+                try:
+                    os.unlink(self._file)
+                except OSError:
+                    pass
+                self._file = None
+        else:
+            addr = None
+            if port_env:
+                addr = (os.environ.get("MASTER_ADDR", "127.0.0.1"), int(port_env))
+            path = _rdzv_file(token)
+            last_err = None
+            while True:
+                if time.monotonic() > deadline:
+                    raise TimeoutError("rendezvous: rank %d could not reach rank 0 within %.0f s (%s)"
+                                       % (self.rank, self.timeout, last_err))
+                target = addr
+                if target is None:
+                    try:
+                        with open(path) as fh:
+                            host, port = fh.read().strip().rsplit(":", 1)
+                        target = (host, int(port))
+                    except (OSError, ValueError) as e:
+                        last_err = e
+                        time.sleep(0.05)
+                        continue
+                try:
+                    s = socket.create_connection(target, timeout=5.0)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    _send(s, _MAGIC + struct.pack("<i", self.rank) + tok)
+                    s.settimeout(self.timeout)
+                    self._sock = s
+                    break
+                except OSError as e:
+                    last_err = e
+                    time.sleep(0.1)
+        self.barrier()     # everyone is connected (and a rejected rank finds out here)
+
+    # -- collectives over the star ---------------------------------------------------------------
+    def all_gather(self, payload):
+        """list of every rank's byte string, in rank order, on every rank."""
+        payload = bytes(payload)
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [None] * (self.world - 1)
+            for r, s in self._peers.items():
+                parts[r] = _recv(s)
+            blob = b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+            for s in self._peers.values():
+                _send(s, blob)
+            return parts
+        _send(self._sock, payload)
+        blob = _recv(self._sock)
+        parts, off = [], 0
+        for _ in range(self.world):
+            (n,) = struct.unpack_from("<Q", blob, off)
+            parts.append(blob[off + 8:off + 8 + n])
+            off += 8 + n
+        return parts
+
+    def broadcast(self, payload, root=0):
+        """root's byte string on every rank (the others pass anything, e.g. b"")."""
+        return self.all_gather(payload if self.rank == root else b"")[root]
+
+    def barrier(self):
+        self.all_gather(b"")
+
+    def close(self):
+        for s in list(self._peers.values()) + [self._sock, self._listener]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self._peers, self._sock, self._listener = {}, None, None
+        if self._file:
+            try:
+                os.unlink(self._file)
+            except OSError:
+                pass
+            self._file = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -10,8 +10,10 @@ Kept verbatim from the reference interface:
   after fit(): weights, params, error.
   options: swarmsize (204), maxiter (2000), omega (-0.2134), phip (-0.3344), phig (2.3259)
            (utils.py:177-181).  Extra opt-in keys: minstep, minfunc (pyswarm's 1e-8 defaults,
-           which the reference does not forward), seed, device, check_every, exchange, polish,
-           variant (kernel variant by name or number, e.g. "farfield").
+           which the reference does not forward), seed, device, check_every, polish,
+           variant (kernel variant by name or number, e.g. "farfield"), exchange ("rccl" for a
+           multi-GPU fit, one process per GPU: the swarm axis is sharded and the global best is
+           exchanged by one RCCL all-gather per generation inside libnmrfit_amd.so).
 
 ``processes`` is accepted and ignored: the reference's only use of it is to spread the
 per-particle objective calls (and the Kramers-Kronig quadratures of generate_result) over a
@@ -108,21 +110,41 @@ class FitUtility:
         seed = opt.get('seed')
         if seed is None:     # pyswarm draws from numpy's unseeded global RNG: do the equivalent
             seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
-        exchange = opt.get('exchange')       # a pso.TorchExchange for multi-GPU fits
+        # Multi-GPU fits (one process per GPU, every rank makes the same fit() call):
+        # options['exchange'] = "rccl" builds the RCCL communicator from the launcher's
+        # environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; nmrfit_amd.rendezvous), or pass a
+        # ready pso.RcclExchange / SocketExchange / TorchExchange.
+        exchange = opt.get('exchange')
+        device = opt.get('device')
+        own_exchange = False
+        if isinstance(exchange, str):
+            if exchange.lower() != "rccl":
+                raise ValueError("options['exchange'] must be \"rccl\" or an exchange object")
+            from . import rendezvous
+            if device is None:
+                device = rendezvous.env_rank_world()[1]
+        if device is None:
+            device = 0
 
-        ev = equations.Evaluator(self.data.w, self.data.u, self.data.v, self.weights, device=opt.get('device', 0))
+        ev = equations.Evaluator(self.data.w, self.data.u, self.data.v, self.weights, device=device)
         try:
+            if isinstance(exchange, str):
+                exchange = pso.RcclExchange(ev)
+                own_exchange = True
             ev.set_fit_im(self.fit_im)     # True: the reference's imaginary term (equations.py:197-209)
             if 'variant' in opt:           # opt-in kernel variant, e.g. "farfield" 
                 ev.set_variant(_cabi.variant_id(opt['variant']))
-            if exchange is None or exchange.world == 1:
+            if exchange is None or (exchange.world == 1 and not isinstance(exchange, pso.RcclExchange)):
                 xopt, fopt = pso.pso(ev, self.lower, self.upper, swarmsize=swarmsize, maxiter=maxiter, seed=seed,
                                      check_every=opt.get('check_every', 16), verbose=True, **kw)
             else:
+                # every rank must run the same swarm: rank 0's seed wins (an unseeded fit would
+                # otherwise draw a different seed on every rank)
+                seed = exchange.broadcast_seed(seed)
                 off, n = pso.shard(swarmsize, exchange.rank, exchange.world)
                 sw = pso.DeviceSwarm(ev, self.lower, self.upper, swarmsize, offset=off, S_local=n, seed=seed, **kw)
                 try:
-                    xopt, fopt = pso.run_sharded(sw, exchange, maxiter, check_every=opt.get('check_every', 1),
+                    xopt, fopt = pso.run_sharded(sw, exchange, maxiter, check_every=opt.get('check_every', 16),
                                                  verbose=True)
                 finally:
                     sw.close()
@@ -130,8 +152,10 @@ class FitUtility:
                 # opt-in extension (no reference counterpart): trust-region least squares on the
                 # batched residual kernel, started from the swarm's answer
                 from . import lsq
-                xopt, fopt, _ = lsq.polish(ev, xopt, self.lower, self.upper)
+                xopt, fopt, _ = lsq.polish(ev, xopt, self.lower, self.upper, fit_im=self.fit_im)
         finally:
+            if own_exchange:
+                exchange.close()
             ev.close()
 
         self.params = xopt

@@ -1,9 +1,13 @@
 """
-GPU tier (iv), end to end through bench.py: the one-rank path, the RCCL path (torch
-"nccl" backend, candidate all-gather and swarm kernels ordered on one HIP stream) forced with a
-single rank, and two ranks sharing the one GPU of the test box over gloo.  All three must report
-the same swarm best bit for bit: sharding and the exchange path do not change the trajectory.
-The 8-GPU RCCL run itself belongs to the driver; this covers its code path as far as one GPU can.
+GPU tier (iv), end to end through bench.py: the one-rank path, the RCCL path (a communicator
+created through the C-ABI, ncclAllGather inside nmrfit_pso_step) forced with a single rank, the
+self-launching form (`python bench.py --gpus N`, no launcher) and the torchrun form, both with
+several ranks sharing the one GPU of the test box (the candidate record staged through the host
+over sockets: RCCL itself refuses two ranks on one device).  All must report the same swarm best
+bit for bit: sharding and the exchange path do not change the trajectory.  The 8-GPU RCCL run
+itself belongs to the driver; this covers its code path as far as one GPU can (a GPU box allows
+at most 6 processes on its card, so the C4 rehearsal runs 4 ranks x 4096 particles and the
+8-shard identity is tested in one process, tests/test_gpu_pso.py).
 """
 import json
 import os
@@ -17,11 +21,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(cmd, env_extra):
+def _run(cmd, env_extra, timeout=900):
     env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                         timeout=600)
+                         timeout=timeout)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -37,19 +43,43 @@ def _free_port():
 
 
 def test_bench_paths_agree():
-    common = ["--steps", "5", "--warmup", "2", "--cpu-seconds", "0", "--workload", "C2"]
+    common = ["--steps", "5", "--warmup", "2", "--cpu-seconds", "0", "--workload", "C2", "--preheat-seconds", "0.1"]
     plain = _run([sys.executable, "bench.py", "--swarm-per-gpu", "512"] + common, {})
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "roofline_valu", "step_ms", "kernel_ms"):
         assert key in plain, key
     assert plain["dtype"] == "f64" and plain["vs_baseline"] is None and plain["n_gpus"] == 1
     r = plain["roofline"]
     assert r["bound"] == "hbm" and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    # the kernel is timed inside the steps that contain it
+    assert plain["kernel_ms"]["n"] == 5 and plain["step_ms"]["n"] == 5
+    assert plain["kernel_ms"]["mean"] <= plain["ms_per_step"]
+    assert plain["kernel_ms"]["max"] <= plain["step_ms"]["max"] * 1.001
+    assert 500.0 < plain["roofline_valu"]["clock_mhz_in_run"] < 3000.0
+    assert "error" not in plain
     rccl = _run([sys.executable, "bench.py", "--swarm-per-gpu", "512"] + common, {"NMRFIT_BENCH_FORCE_DIST": "1"})
     assert rccl["config"]["swarm_best_f"] == plain["config"]["swarm_best_f"]
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
-                "--swarm-per-gpu", "256"] + common, {"NMRFIT_BENCH_BACKEND": "gloo"})
+    assert "ncclAllGather" in rccl["config"]["exchange"]
+    # self-launching form: no launcher, no WORLD_SIZE in the environment
+    two = _run([sys.executable, "bench.py", "--gpus", "2", "--swarm-per-gpu", "256"] + common,
+               {"NMRFIT_BENCH_BACKEND": "host"})
     assert two["n_gpus"] == 2 and two["config"]["swarm_total"] == 512
     assert two["config"]["swarm_best_f"] == plain["config"]["swarm_best_f"]
     assert two["config"]["generations_done"] == plain["config"]["generations_done"] == 7
+    # the driver's form: torch.distributed.run as the launcher (torch is not imported by the ranks)
+    three = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                  "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
+                  "--swarm-per-gpu", "256"] + common, {"NMRFIT_BENCH_BACKEND": "host"})
+    assert three["config"]["swarm_best_f"] == plain["config"]["swarm_best_f"]
+
+
+def test_c4_rehearsal_four_ranks_on_one_gpu():
+    """C4's per-GPU shape (4096 particles x 65536 points x 24 peaks per rank) with 4 ranks on one
+    device through the self-launcher, against the one-rank 16384-particle run: same swarm best."""
+    common = ["--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-extras", "--preheat-seconds", "0.1"]
+    four = _run([sys.executable, "bench.py", "--gpus", "4", "--swarm-per-gpu", "4096"] + common,
+                {"NMRFIT_BENCH_BACKEND": "host"})
+    one = _run([sys.executable, "bench.py", "--swarm-per-gpu", "16384"] + common, {})
+    assert four["n_gpus"] == 4 and four["config"]["swarm_total"] == 16384 == one["config"]["swarm_total"]
+    assert four["config"]["swarm_best_f"] == one["config"]["swarm_best_f"]
+    assert four["config"]["generations_done"] == one["config"]["generations_done"] == 4

@@ -161,70 +161,134 @@ def test_fit_api_end_to_end(problem, capsys):
         nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im="nonsense", summary=False)
 
 
-_RCCL_SCRIPT = r"""
-import socket, sys
-import torch                      # before any nmrfit_amd GPU call: one shared HIP runtime
-import torch.distributed as dist
-import numpy as np
-sys.path.insert(0, %r)
-import nmrfit_amd
-from nmrfit_amd import pso, synth
-from nmrfit_amd.equations import Evaluator
-s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% port, rank=0, world_size=1,
-                        device_id=torch.device("cuda", 0))
-sp = synth.make_spectrum(2048, 3, seed=5)
-ev = Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"])
-ex = pso.TorchExchange()
-assert ex.backend == "nccl" and ex.world == 1
-a = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 300, seed=9)
-xa, fa = pso.run_sharded(a, ex, 120, check_every=7)
-st = a.status(); a.close()
-b = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 300, seed=9)
-b.run(120, check_every=7)
-xb, fb = b.best()
-assert b.status() == st, (b.status(), st)
-b.close()
-assert (xa == xb).all() and fa == fb
-f = ev.objective_batch(xa)        # the context is back on its own stream and still usable
-assert abs(f[0] - fa) <= 1e-12 * fa
-data = synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"])
-r1 = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False,
-                    options={"swarmsize": 100, "maxiter": 40, "seed": 5, "exchange": pso.TorchExchange()})
-r2 = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False,
-                    options={"swarmsize": 100, "maxiter": 40, "seed": 5})
-assert (r1.params == r2.params).all() and r1.error == r2.error
-ev.close()
-dist.destroy_process_group()
-print("RCCL_OK")
-"""
+def test_native_rccl_single_rank(problem):
+    """The product exchange on real hardware as far as one GPU allows: a one-rank RCCL
+    communicator created through the C-ABI (nmrfit_comm_*: dlopen'ed librccl, no torch).  The
+    bookkeeping collectives work, a swarm with the communicator attached runs whole generations
+    in one C call (ncclAllGather + fold on the kernels' stream) and reproduces the plain device
+    loop bit for bit, and nmrfit_amd.fit(options={"exchange": "rccl"}) takes that same route."""
+    import sys
+    import nmrfit_amd
+    sp, ev = problem
+    ex = pso.RcclExchange(ev)
+    info = ex.info()
+    assert info["rank"] == 0 and info["world"] == 1 and info["rccl_version"] > 0
+    ex.barrier()
+    np.testing.assert_array_equal(ex.all_reduce([1.5, -2.0, 7.0], "max"), [1.5, -2.0, 7.0])
+    np.testing.assert_array_equal(ex.all_reduce([1.5, -2.0], "sum"), [1.5, -2.0])
+    assert ex.broadcast_seed(0xFEDCBA9876543210) == 0xFEDCBA9876543210
+    rec = np.arange(14.0)
+    np.testing.assert_array_equal(ex.gather_host(rec), rec[None, :])
+    a = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 300, seed=9)
+    xa, fa = pso.run_sharded(a, ex, 120, check_every=7)
+    st = a.status()
+    a.close()
+    b = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 300, seed=9)
+    b.run(120, check_every=7)
+    xb, fb = b.best()
+    assert b.status() == st, (b.status(), st)
+    b.close()
+    np.testing.assert_array_equal(xa, xb)
+    assert fa == fb
+    # step by step (what bench.py does), against the host-staged fold
+    c = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 700, seed=3, minfunc=-1.0, minstep=-1.0)
+    d = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 700, seed=3, minfunc=-1.0, minstep=-1.0)
+    c.set_comm(ex)
+    c.init()
+    d.init()
+    for _ in range(6):
+        c.step()
+    d.apply_global(d.candidate()[None, :])
+    for _ in range(5):
+        d.step_local()
+        d.apply_global(d.candidate()[None, :])
+    assert c.status() == d.status() and c.status()["iteration"] == 5
+    np.testing.assert_array_equal(c.state()["x"], d.state()["x"])
+    c.set_comm(None)
+    c.close()
+    d.close()
+    ex.close()
+    data = synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"])
+    r1 = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False,
+                        options={"swarmsize": 100, "maxiter": 40, "seed": 5, "exchange": "rccl"})
+    r2 = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False,
+                        options={"swarmsize": 100, "maxiter": 40, "seed": 5})
+    np.testing.assert_array_equal(r1.params, r2.params)
+    assert r1.error == r2.error
+    assert "torch" not in sys.modules or True     # (other tests of this process may import torch)
 
 
-def test_run_sharded_over_rccl_single_rank():
-    """pso.run_sharded with a torch "nccl" group (one rank): the candidate all-gather runs on the
-    GPU on the same stream as the swarm kernels (RcclGeneration) and the result equals the plain
-    device loop; nmrfit_amd.fit(options={"exchange": ...}) takes the same route.  Runs in its own
-    process because torch must be imported before libnmrfit_amd is loaded (shared HIP runtime)."""
+def test_no_torch_in_the_product_path():
+    """A fresh interpreter that fits with the RCCL exchange never imports torch."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT % root], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                         text=True, timeout=600)
-    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stderr[-3000:]
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import nmrfit_amd\n"
+        "from nmrfit_amd import synth\n"
+        "sp = synth.make_spectrum(2048, 3, seed=5)\n"
+        "data = synth.SynthData(sp['w'], sp['u'], sp['v'], sp['peaks'])\n"
+        "r = nmrfit_amd.fit(data, list(sp['lower']), list(sp['upper']), summary=False,\n"
+        "                   options={'swarmsize': 64, 'maxiter': 10, 'seed': 5, 'exchange': 'rccl'})\n"
+        "assert 'torch' not in sys.modules, 'torch was imported'\n"
+        "print('NO_TORCH_OK', r.error)\n" % root)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0 and "NO_TORCH_OK" in out.stdout, out.stderr[-3000:]
 
 
-def test_rccl_needs_torch_first(problem):
-    """In THIS process libnmrfit_amd was loaded first: the RCCL generation must refuse loudly
-    instead of letting torch fail to find the GPU."""
-    sp, ev = problem
-    if not _cabi.loaded_before_torch():
-        pytest.skip("torch was imported before the library in this process")
-    sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 16, seed=1)
-    with pytest.raises(RuntimeError, match="import torch before"):
-        pso.RcclGeneration(sw, pso.LocalExchange())
-    sw.close()
+def test_c4_shape_eight_shards_equal_one_swarm():
+    """BASELINE config C4 as far as one GPU allows: eight DeviceSwarm shards (4096 particles
+    each, offsets q*4096 of a 32768-particle swarm, N = 65536, P = 24) on ONE device against
+    the single 32768-particle swarm.  After 3 generations every shard holds the same (g, fg)
+    as the single swarm, the shards' positions tile it bit for bit, and each shard's objective
+    values equal the matching slice of one objective_batch over the whole swarm."""
+    from nmrfit_amd import equations
+    c4 = synth.CONFIGS["C4"]
+    sp = synth.make_spectrum(c4.N, c4.P, seed=1)
+    G, S = 8, c4.S
+    per = S // G
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        kw = dict(seed=1234, minfunc=-1.0, minstep=-1.0)
+        one = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, **kw)
+        shards = [pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, offset=q * per, S_local=per, **kw) for q in range(G)]
+        one.init()
+        one.apply_global(one.candidate()[None, :])
+        for s in shards:
+            s.init()
+        cands = np.stack([s.candidate() for s in shards])
+        for s in shards:
+            s.apply_global(cands)
+        for _ in range(3):
+            one.step_local()
+            one.apply_global(one.candidate()[None, :])
+            for s in shards:
+                s.step_local()
+            cands = np.stack([s.candidate() for s in shards])
+            for s in shards:
+                s.apply_global(cands)
+        st1 = one.state()
+        f_all = ev.objective_batch(st1["x"])
+        np.testing.assert_array_equal(f_all, st1["fx"])          # swarm launch == plain batched launch
+        b1 = one.best()
+        for q, s in enumerate(shards):
+            st = s.state()
+            sl = slice(q * per, (q + 1) * per)
+            for k in ("x", "v", "p", "fx", "fp"):
+                np.testing.assert_array_equal(st[k], st1[k][sl], err_msg="shard %d %s" % (q, k))
+            np.testing.assert_array_equal(st["fx"], f_all[sl])
+            b = s.best()
+            np.testing.assert_array_equal(b[0], b1[0])
+            assert b[1] == b1[1]
+            assert s.status() == one.status()
+            s.close()
+        assert one.status()["iteration"] == 3
+        one.close()
 
 
 def test_closing_the_evaluator_closes_its_swarms():

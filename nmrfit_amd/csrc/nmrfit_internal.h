@@ -101,8 +101,12 @@ struct ObjectiveDeferred {
     int fit_im = 0;
 };
 // Enqueue the objective (R_out == nullptr) or residual launch on ctx->stream.
+// `fused` (swarm generations, pso.hip): advance every particle by the swarm's update rule in the
+// kernel's prologue and evaluate the NEW positions (dX is then unused).
+struct PsoFused;
+constexpr int64_t kFusedMaxD = 400;   // 4 waves x D doubles of LDS for the updated rows (12.5 KiB at the limit)
 int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR,
-                     ObjectiveDeferred *defer = nullptr);
+                     ObjectiveDeferred *defer = nullptr, const PsoFused *fused = nullptr);
 int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need);
 // centred grid + per-chunk (min,max) table from the raw device copy of w
 int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw);

@@ -36,6 +36,7 @@
 //     kernel adds the per-block sums in grid order (deterministic, no atomics, and the same
 //     order whatever the segmentation: f does not depend on launch geometry or on sharding).
 #include "nmrfit_internal.h"
+#include "pso_update.h"
 
 #define NMRFIT_DAWSON_QUAL __device__ const
 #include "dawson_coeffs.h"
@@ -482,7 +483,8 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     int64_t seg_len, int blk_chunks, double lane_step, double rec_devk,
     double *__restrict__ out,       // nseg == 1: f[S];  else per-block sums [S * n_blocks] (x2 with FIT_IM)
     double *__restrict__ R_out,     // WRITE_R: residual rows [S*N]
-    unsigned long long *__restrict__ clk)   // profiling only (else null): shader / reference clock of workgroup 0
+    unsigned long long *__restrict__ clk,   // profiling only (else null): shader / reference clock of workgroup 0
+    const PsoFused upd)             // swarm generations: advance the particle first (x_in != null), X is then unused
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -526,12 +528,12 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     const int64_t particle = active ? g / nseg : 0;
     const int seg = active ? (int)(g % nseg) : 0;
     const int64_t D = 4 + 3 * (int64_t)P;
-    const double *x = X + particle * D;
-
-    const double p0 = x[0], p1 = x[1], r = x[2], yoff = x[3];   // equations.py:177
-
-    // stage this particle's per-peak constants in the wave's LDS slices
+    double p0, p1, r, yoff;
+    // stage this particle's per-peak constants in the wave's LDS slices (x: the particle's row,
+    // in global memory or -- fused swarm update -- in this wave's LDS copy)
     bool fast_bad = false, rec_bad = false;
+    auto stage_peaks = [&](const double *x) {
+    p0 = x[0], p1 = x[1], r = x[2], yoff = x[3];   // equations.py:177
     for (int kb0 = 0; kb0 < P; kb0 += kWave) {   // every lane iterates (the group sums below shuffle)
         const int k = kb0 + lane;
         const bool have = k < P;
@@ -585,6 +587,40 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
             if (have && !ok) rec_bad = true;
             if (have) grec[k] = make_double2(d, ok ? exp2_neg(-2.0 * d * d) : 0.0);
         }
+    }
+    };
+    bool fused = false;
+    if constexpr (!WRITE_R) fused = upd.x_in != nullptr;
+    if (fused) {
+        // Swarm generation: the velocity / position update of this particle happens HERE, in the
+        // prologue of the kernel that evaluates it (one launch fewer per generation).  Every wave of
+        // the particle computes the same new row into its own LDS slice; the wave of segment 0 also
+        // writes it (and the velocity) to the swarm's other state buffer -- never the one being
+        // read, so the segments of a particle cannot race.  After a stop every launch is a no-op:
+        // the row is carried over unchanged and the kernel returns.
+        double *xrow = reinterpret_cast<double *>(lds_raw + upd.xrow_off) + (size_t)wave * D;
+        const bool stopped = upd.flags[1] != 0;
+        const uint32_t gen = (uint32_t)(upd.flags[0] + 1);
+        for (int64_t d = lane; d < D; d += kWave) {
+            const int64_t idx = particle * D + d;
+            double xn = upd.x_in[idx], vn = upd.v_in[idx];
+            if (!stopped) {
+                double rp, rg;
+                uniform2(upd.seed, gen, (uint32_t)d, (uint64_t)(upd.offset + particle), &rp, &rg);
+                xn = update_value(xn, vn, upd.p[idx], upd.best[2 + d], upd.lb[d], upd.ub[d], rp, rg, upd.omega,
+                                  upd.phip, upd.phig, &vn);
+            }
+            xrow[d] = xn;
+            if (active && seg == 0) {
+                upd.x_out[idx] = xn;
+                upd.v_out[idx] = vn;
+            }
+        }
+        if (stopped) return;   // the same for every wave of the grid
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
+        stage_peaks(xrow);
+    } else {
+        stage_peaks(X + particle * D);
     }
     // wave-uniform: every group of this particle may take the two-operation pair form
     const bool fast_all = kFast && (__ballot(fast_bad) == 0ull);
@@ -1112,13 +1148,14 @@ __global__ void centre_kernel(const double *__restrict__ w, int64_t N, double w0
 
 template <int VARIANT>
 int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *out, double *dR,
-                   int nseg, int64_t seg_len, int blk_chunks, int64_t blocks, size_t lds, int fit_im)
+                   int nseg, int64_t seg_len, int blk_chunks, int64_t blocks, size_t lds, int fit_im,
+                   const PsoFused &upd)
 {
 #define NMRFIT_LAUNCH(WR, FI)                                                                                   \
     hipLaunchKernelGGL((objective_kernel<VARIANT, WR, FI>), dim3((unsigned)blocks), dim3(kBlock), lds,         \
                        ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,     \
                        ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, blk_chunks, ctx->lane_step,                 \
-                       ctx->grid_dev * 11.0e10, out, dR, clk)
+                       ctx->grid_dev * 11.0e10, out, dR, clk, upd)
     // nmrfit_prof_enable: HIP events on the launch stream around this kernel alone
     const bool prof = ctx->prof_cap > 0 && ctx->prof_nk < ctx->prof_cap;
     unsigned long long *clk = prof ? ctx->d_clk : nullptr;
@@ -1162,7 +1199,7 @@ int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw)
 }
 
 int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR,
-                     ObjectiveDeferred *defer)
+                     ObjectiveDeferred *defer, const PsoFused *fused)
 {
     if (defer) *defer = ObjectiveDeferred{};
     const int fit_im = dR ? 0 : ctx->fit_im;
@@ -1212,10 +1249,22 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
                                 ? (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(PeakFast) : 0;
     if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_rec + lds_fast > 160 * 1024)
         variant = NMRFIT_VARIANT_NOREC;     // P > ~450: no room for the recurrence / scaled records
-    const size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
-                       (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : 0) +
-                       ((variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_DEFAULT) ? lds_rec : 0) +
-                       (variant == NMRFIT_VARIANT_DEFAULT ? lds_fast : 0);
+    size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
+                 (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : 0) +
+                 ((variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_DEFAULT) ? lds_rec : 0) +
+                 (variant == NMRFIT_VARIANT_DEFAULT ? lds_fast : 0);
+    // fused swarm update: one copy of the particle's updated row per wave, after everything else
+    PsoFused upd{};
+    if (fused && fused->x_in) {
+        if (dR || (4 + 3 * (int64_t)P) > kFusedMaxD) {
+            set_error("fused swarm update: objective launches with D <= kFusedMaxD only");
+            return NMRFIT_E_INVALID;
+        }
+        upd = *fused;
+        lds = (lds + 15) & ~(size_t)15;
+        upd.xrow_off = (unsigned)lds;
+        lds += (size_t)kWavesPerBlock * (size_t)(4 + 3 * (int64_t)P) * sizeof(double);
+    }
     double *out = df;
     if (nseg > 1) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));
@@ -1225,28 +1274,28 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     int rc;
     switch (variant) {
         case NMRFIT_VARIANT_BASELINE:
-            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
             break;
         case NMRFIT_VARIANT_NOSKIP:
-            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
             break;
         case NMRFIT_VARIANT_SINGLE:
-            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
             break;
         case NMRFIT_VARIANT_QUAD:
-            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
             break;
         case NMRFIT_VARIANT_FARFIELD:
-            rc = launch_variant<NMRFIT_VARIANT_FARFIELD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_FARFIELD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
             break;
         case NMRFIT_VARIANT_NOREC:
-            rc = launch_variant<NMRFIT_VARIANT_NOREC>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_NOREC>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
             break;
         case NMRFIT_VARIANT_STAGED:
-            rc = launch_variant<NMRFIT_VARIANT_STAGED>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_STAGED>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
             break;
         default:
-            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im);
+            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
             break;
     }
     if (rc != NMRFIT_OK) return rc;

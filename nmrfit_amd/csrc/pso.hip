@@ -28,6 +28,7 @@
 //       (a device-scope fence per workgroup would cost more than the launch)     -> 4 launches
 // Multi-rank generations run apply as its own launch after the all-gather.
 #include "nmrfit_internal.h"
+#include "pso_update.h"
 
 #include <algorithm>
 #include <cmath>
@@ -42,6 +43,8 @@ struct nmrfit_pso {
     nmrfit_pso_params prm{};
     double *d_lb = nullptr, *d_ub = nullptr;
     double *d_x = nullptr, *d_v = nullptr, *d_p = nullptr;
+    double *d_x2 = nullptr, *d_v2 = nullptr;   // the other half of the x / v ping-pong (fused update: the objective
+                                               // kernel reads one pair and writes the other, then they swap)
     double *d_fx = nullptr, *d_fp = nullptr;
     double *d_cand = nullptr;          // (D+1): f_best, x_best (own buffer or caller's)
     double *d_cand_own = nullptr;
@@ -57,40 +60,6 @@ struct nmrfit_pso {
 
 namespace nmrfit {
 namespace {
-
-struct U4 {
-    uint32_t x, y, z, w;
-};
-
-__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
-        U4 n;
-        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
-        n.y = (uint32_t)p1;
-        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
-        n.w = (uint32_t)p0;
-        c = n;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return c;
-}
-
-// two uniforms in [0,1) with 53 random bits each
-__device__ __forceinline__ void uniform2(uint64_t seed, uint32_t gen, uint32_t dim, uint64_t particle, double *a,
-                                         double *b)
-{
-    U4 c{gen, dim, (uint32_t)particle, (uint32_t)(particle >> 32)};
-    const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const uint64_t ua = ((uint64_t)o.y << 32) | o.x;
-    const uint64_t ub = ((uint64_t)o.w << 32) | o.z;
-    *a = (double)(ua >> 11) * 0x1.0p-53;
-    *b = (double)(ub >> 11) * 0x1.0p-53;
-}
 
 // The swarm arithmetic is written without fused multiply-add so that it is bit-identical to
 // the numpy mirror in nmrfit_amd/pso.py (IEEE mul/add in numpy's evaluation order).
@@ -124,18 +93,9 @@ __device__ __forceinline__ void update_element(int64_t idx, int64_t D, int64_t o
 {
     const int64_t i = idx / D;
     const int d = (int)(idx - i * D);
-    double rp, rg;
+    double rp, rg, vn;
     uniform2(seed, gen, (uint32_t)d, (uint64_t)(offset + i), &rp, &rg);
-    const double g = best[2 + d];
-    const double xo = x[idx];
-    const double a = omega * v[idx];
-    const double b = (phip * rp) * (p[idx] - xo);
-    const double c = (phig * rg) * (g - xo);
-    const double vn = (a + b) + c;
-    double xn = xo + vn;
-    const double lo = lb[d], hi = ub[d];
-    if (xn < lo) xn = lo;
-    if (xn > hi) xn = hi;
+    const double xn = update_value(x[idx], v[idx], p[idx], best[2 + d], lb[d], ub[d], rp, rg, omega, phip, phig, &vn);
     v[idx] = vn;
     x[idx] = xn;
 }
@@ -566,45 +526,82 @@ int launch_tail(nmrfit_pso *pso, const TailArgs &a)
     return NMRFIT_OK;
 }
 
-// objective + personal bests + local candidate.  `more` adds phases to the fused tail of a
-// small swarm (kTailApply / kTailUpdate, used by nmrfit_pso_run); ignored for large swarms.
-int evaluate_and_select(nmrfit_pso *pso, int more = 0, int is_init = 0)
+// The position update rides in the objective kernel's prologue (objective.hip) unless the
+// parameter vector is too long for its LDS copy or NMRFIT_NO_FUSED_UPDATE is set (A/B knob).
+bool fuse_update(const nmrfit_pso *pso)
+{
+    static const bool off = getenv("NMRFIT_NO_FUSED_UPDATE") != nullptr;
+    return !off && pso->S > 0 && pso->D <= kFusedMaxD;
+}
+
+int launch_update(nmrfit_pso *pso)
+{
+    const int64_t n = pso->S * pso->D;
+    if (n == 0) return NMRFIT_OK;
+    hipLaunchKernelGGL(pso_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pso->ctx->stream, pso->S,
+                       pso->D, pso->offset, pso->prm.seed, pso->prm.omega, pso->prm.phip, pso->prm.phig, pso->d_flags,
+                       pso->d_best, pso->d_lb, pso->d_ub, pso->d_p, pso->d_x, pso->d_v);
+    NMRFIT_HIP(hipGetLastError());
+    return NMRFIT_OK;
+}
+
+// [position update +] objective + personal bests + local candidate [+ fold].
+//   advance: move the swarm one generation first (fused into the objective launch when possible)
+//   more:    kTailApply folds this rank's own candidate in the same launch (single-rank runs)
+int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init = 0)
 {
     nmrfit_ctx *ctx = pso->ctx;
     const int64_t S = pso->S, D = pso->D;
-    if (small_swarm(pso)) {
-        ObjectiveDeferred def;
-        int rc = launch_objective(ctx, S, pso->P, pso->d_x, pso->d_fx, nullptr, &def);
-        if (rc != NMRFIT_OK) return rc;
-        TailArgs a = tail_args(pso, def, (def.needed ? kTailFinalize : 0) | kTailPbest | kTailArgmin | more);
-        a.is_init = is_init;
-        return launch_tail(pso, a);
-    }
-    if (S > 0) {
-        ObjectiveDeferred def;
-        int rc = launch_objective(ctx, S, pso->P, pso->d_x, pso->d_fx, nullptr, &def);
-        if (rc != NMRFIT_OK) return rc;
-        TailArgs a = tail_args(pso, def, (def.needed ? kTailFinalize : 0) | kTailPbest | kTailArgmin | (more & kTailApply));
-        a.is_init = is_init;
-        // S <= 512: one launch, the last-ticket workgroup finishes; larger: posts, then a
-        // single-workgroup launch (a fence per workgroup would cost more than the launch)
-        const int64_t nb64 = (S + kSelectWaves - 1) / kSelectWaves;
-        const unsigned nb = (unsigned)std::min<int64_t>(nb64, kSelectMaxPosts);
-        const bool ticket = nb <= (unsigned)kSelectTicketBlocks;
-        hipLaunchKernelGGL(pso_select_kernel, dim3(nb), dim3(kWave * kSelectWaves), 0, ctx->stream, a, pso->d_part_val,
-                           pso->d_part_idx, ticket ? pso->d_ticket : nullptr);
+    if (S == 0) {
+        // an empty shard still posts its (+inf, zeros) candidate
+        hipLaunchKernelGGL(pso_argmin_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, D, pso->d_flags, pso->d_fp,
+                           pso->d_p, pso->d_cand);
         NMRFIT_HIP(hipGetLastError());
-        if (!ticket) {
-            hipLaunchKernelGGL(pso_select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, pso->d_part_val,
-                               pso->d_part_idx, nb);
-            NMRFIT_HIP(hipGetLastError());
-        }
         return NMRFIT_OK;
     }
-    // an empty shard still posts its (+inf, zeros) candidate
-    hipLaunchKernelGGL(pso_argmin_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, D, pso->d_flags, pso->d_fp, pso->d_p,
-                       pso->d_cand);
+    ObjectiveDeferred def;
+    int rc;
+    if (advance && fuse_update(pso)) {
+        PsoFused f;
+        f.x_in = pso->d_x;
+        f.v_in = pso->d_v;
+        f.x_out = pso->d_x2;
+        f.v_out = pso->d_v2;
+        f.p = pso->d_p;
+        f.best = pso->d_best;
+        f.lb = pso->d_lb;
+        f.ub = pso->d_ub;
+        f.flags = pso->d_flags;
+        f.seed = pso->prm.seed;
+        f.offset = pso->offset;
+        f.omega = pso->prm.omega;
+        f.phip = pso->prm.phip;
+        f.phig = pso->prm.phig;
+        rc = launch_objective(ctx, S, pso->P, pso->d_x2, pso->d_fx, nullptr, &def, &f);
+        if (rc != NMRFIT_OK) return rc;
+        std::swap(pso->d_x, pso->d_x2);   // d_x / d_v: the state the kernel has just written
+        std::swap(pso->d_v, pso->d_v2);
+    } else {
+        if (advance && (rc = launch_update(pso)) != NMRFIT_OK) return rc;
+        rc = launch_objective(ctx, S, pso->P, pso->d_x, pso->d_fx, nullptr, &def);
+        if (rc != NMRFIT_OK) return rc;
+    }
+    TailArgs a = tail_args(pso, def, (def.needed ? kTailFinalize : 0) | kTailPbest | kTailArgmin | (more & kTailApply));
+    a.is_init = is_init;
+    if (small_swarm(pso)) return launch_tail(pso, a);
+    // S <= 512: one launch, the last-ticket workgroup finishes; larger: posts, then a
+    // single-workgroup launch (a fence per workgroup would cost more than the launch)
+    const int64_t nb64 = (S + kSelectWaves - 1) / kSelectWaves;
+    const unsigned nb = (unsigned)std::min<int64_t>(nb64, kSelectMaxPosts);
+    const bool ticket = nb <= (unsigned)kSelectTicketBlocks;
+    hipLaunchKernelGGL(pso_select_kernel, dim3(nb), dim3(kWave * kSelectWaves), 0, ctx->stream, a, pso->d_part_val,
+                       pso->d_part_idx, ticket ? pso->d_ticket : nullptr);
     NMRFIT_HIP(hipGetLastError());
+    if (!ticket) {
+        hipLaunchKernelGGL(pso_select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, pso->d_part_val,
+                           pso->d_part_idx, nb);
+        NMRFIT_HIP(hipGetLastError());
+    }
     return NMRFIT_OK;
 }
 
@@ -663,6 +660,8 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
     PSO_HIP(hipMalloc((void **)&pso->d_ub, (size_t)D * sizeof(double)));
     PSO_HIP(hipMalloc((void **)&pso->d_x, sd));
     PSO_HIP(hipMalloc((void **)&pso->d_v, sd));
+    PSO_HIP(hipMalloc((void **)&pso->d_x2, sd));
+    PSO_HIP(hipMalloc((void **)&pso->d_v2, sd));
     PSO_HIP(hipMalloc((void **)&pso->d_p, sd));
     PSO_HIP(hipMalloc((void **)&pso->d_fx, s1));
     PSO_HIP(hipMalloc((void **)&pso->d_fp, s1));
@@ -694,7 +693,7 @@ int nmrfit_pso_destroy(nmrfit_pso *pso)
         (void)hipSetDevice(pso->ctx->device);
         (void)hipStreamSynchronize(pso->ctx->stream);
     }
-    void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_p, pso->d_fx, pso->d_fp, pso->d_cand_own, pso->d_flags, pso->d_best,
+    void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_x2, pso->d_v2, pso->d_p, pso->d_fx, pso->d_fp, pso->d_cand_own, pso->d_flags, pso->d_best,
                     pso->d_part_val, pso->d_part_idx, pso->d_ticket};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -714,7 +713,7 @@ int nmrfit_pso_init(nmrfit_pso *pso)
                            pso->offset, pso->prm.seed, pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_p, pso->d_fp);
         NMRFIT_HIP(hipGetLastError());
     }
-    rc = evaluate_and_select(pso);
+    rc = evaluate_and_select(pso, /*advance=*/false);
     if (rc != NMRFIT_OK) return rc;
     pso->initialized = true;
     pso->seeded = false;
@@ -729,15 +728,7 @@ int nmrfit_pso_step_local(nmrfit_pso *pso)
         set_error("nmrfit_pso_step_local before nmrfit_pso_init");
         return NMRFIT_E_STATE;
     }
-    nmrfit_ctx *ctx = pso->ctx;
-    const int64_t n = pso->S * pso->D;
-    if (n > 0) {
-        hipLaunchKernelGGL(pso_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pso->S,
-                           pso->D, pso->offset, pso->prm.seed, pso->prm.omega, pso->prm.phip, pso->prm.phig,
-                           pso->d_flags, pso->d_best, pso->d_lb, pso->d_ub, pso->d_p, pso->d_x, pso->d_v);
-        NMRFIT_HIP(hipGetLastError());
-    }
-    return evaluate_and_select(pso);
+    return evaluate_and_select(pso, /*advance=*/true);
 }
 
 int nmrfit_pso_candidate_dev(nmrfit_pso *pso, double **dptr)
@@ -818,12 +809,7 @@ int nmrfit_pso_step(nmrfit_pso *pso)
         return exchange_and_fold(pso);
     }
     // single rank: the fold and the stopping rule ride in the select launch
-    const int64_t n = pso->S * pso->D;
-    hipLaunchKernelGGL(pso_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pso->ctx->stream, pso->S,
-                       pso->D, pso->offset, pso->prm.seed, pso->prm.omega, pso->prm.phip, pso->prm.phig, pso->d_flags,
-                       pso->d_best, pso->d_lb, pso->d_ub, pso->d_p, pso->d_x, pso->d_v);
-    NMRFIT_HIP(hipGetLastError());
-    return evaluate_and_select(pso, kTailApply);
+    return evaluate_and_select(pso, /*advance=*/true, kTailApply);
 }
 
 int nmrfit_pso_status(nmrfit_pso *pso, int64_t *iteration, int32_t *stop_code, double *fg)
@@ -881,36 +867,10 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
         }
         return NMRFIT_OK;
     }
-    const bool fused = small_swarm(pso);
-    if (fused && maxiter > 0) {
-        // generation 1's positions; from here on a generation is two launches: the objective
-        // and one single-workgroup tail that also folds the candidate, applies the stopping
-        // rule and prepares the next generation's positions
-        const int64_t n = pso->S * pso->D;
-        hipLaunchKernelGGL(pso_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pso->ctx->stream, pso->S,
-                           pso->D, pso->offset, pso->prm.seed, pso->prm.omega, pso->prm.phip, pso->prm.phig,
-                           pso->d_flags, pso->d_best, pso->d_lb, pso->d_ub, pso->d_p, pso->d_x, pso->d_v);
-        NMRFIT_HIP(hipGetLastError());
-    }
+    // single rank: a generation is the objective launch (which also advances the swarm) and the
+    // select launch (which also folds the candidate and applies the stopping rule)
     for (int64_t it = 1; it <= maxiter; ++it) {
-        if (fused) {
-            // no position update after the last generation: the state then is what the
-            // unfused sequence leaves behind
-            rc = evaluate_and_select(pso, kTailApply | (it < maxiter ? kTailUpdate : 0));
-            if (rc != NMRFIT_OK) return rc;
-        } else if (pso->S > 0) {
-            // three launches: positions, objective, select (+ fold and stopping rule)
-            const int64_t n = pso->S * pso->D;
-            hipLaunchKernelGGL(pso_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pso->ctx->stream,
-                               pso->S, pso->D, pso->offset, pso->prm.seed, pso->prm.omega, pso->prm.phip,
-                               pso->prm.phig, pso->d_flags, pso->d_best, pso->d_lb, pso->d_ub, pso->d_p, pso->d_x,
-                               pso->d_v);
-            NMRFIT_HIP(hipGetLastError());
-            if ((rc = evaluate_and_select(pso, kTailApply)) != NMRFIT_OK) return rc;
-        } else {
-            if ((rc = nmrfit_pso_step_local(pso)) != NMRFIT_OK) return rc;
-            if ((rc = nmrfit_pso_apply_global_dev(pso, pso->d_cand, 1)) != NMRFIT_OK) return rc;
-        }
+        if ((rc = nmrfit_pso_step(pso)) != NMRFIT_OK) return rc;
         if (it % check_every == 0 || it == maxiter) {
             int32_t stop = 0;
             if ((rc = nmrfit_pso_status(pso, nullptr, &stop, nullptr)) != NMRFIT_OK) return rc;

@@ -1,0 +1,81 @@
+// pso_update.h -- the swarm's random numbers and its velocity / position rule, shared by the
+// stand-alone swarm kernels (pso.hip) and the objective kernel's fused prologue (objective.hip).
+//
+// pyswarm (github.com/tisimst/pyswarm, pso.py; called from nmrfit/utils.py:176-182):
+//     v = omega*v + phip*rp*(p - x) + phig*rg*(g - x);   x = x + v;   clip to [lb, ub]
+// with rp, rg ~ U[0,1).  Here the uniforms are Philox4x32-10 keyed by the seed with counter
+// (generation, dimension, GLOBAL particle index), and the arithmetic is written without fused
+// multiply-add so that it is bit-identical to the numpy mirror in nmrfit_amd/pso.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nmrfit {
+
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// two uniforms in [0,1) with 53 random bits each
+__device__ __forceinline__ void uniform2(uint64_t seed, uint32_t gen, uint32_t dim, uint64_t particle, double *a,
+                                         double *b)
+{
+    U4 c{gen, dim, (uint32_t)particle, (uint32_t)(particle >> 32)};
+    const U4 o = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint64_t ua = ((uint64_t)o.y << 32) | o.x;
+    const uint64_t ub = ((uint64_t)o.w << 32) | o.z;
+    *a = (double)(ua >> 11) * 0x1.0p-53;
+    *b = (double)(ub >> 11) * 0x1.0p-53;
+}
+
+// one element of the update: returns the new position, *vn the new velocity
+__device__ __forceinline__ double update_value(double xo, double vo, double po, double g, double lo, double hi,
+                                               double rp, double rg, double omega, double phip, double phig,
+                                               double *vn_out)
+{
+#pragma clang fp contract(off)
+    const double a = omega * vo;
+    const double b = (phip * rp) * (po - xo);
+    const double c = (phig * rg) * (g - xo);
+    const double vn = (a + b) + c;
+    double xn = xo + vn;
+    if (xn < lo) xn = lo;
+    if (xn > hi) xn = hi;
+    *vn_out = vn;
+    return xn;
+}
+
+// What the objective kernel needs to advance a particle before evaluating it (the position
+// update fused into its prologue: one launch fewer per generation).  x_in == nullptr: not fused.
+struct PsoFused {
+    const double *x_in = nullptr, *v_in = nullptr;   // state before the update   [S x D]
+    double *x_out = nullptr, *v_out = nullptr;        // state after it (ping-pong: never the same buffers)
+    const double *p = nullptr;                        // personal bests            [S x D]
+    const double *best = nullptr;                     // [0] fg, [1] best_f, [2..2+D) g
+    const double *lb = nullptr, *ub = nullptr;
+    const long long *flags = nullptr;                 // [0] completed generations, [1] stop code
+    uint64_t seed = 0;
+    int64_t offset = 0;                               // global index of this shard's first particle
+    double omega = 0.0, phip = 0.0, phig = 0.0;
+    unsigned xrow_off = 0;                            // byte offset of the per-wave x rows in dynamic LDS
+};
+
+}  // namespace nmrfit

@@ -7,12 +7,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nmrfit_amd import synth, pso
 from nmrfit_amd.equations import Evaluator
 
-for (S, N, P) in [(50, 4096, 6), (204, 4096, 6), (204, 16384, 12), (1024, 4096, 6), (204, 65536, 24)]:
+SHAPES = [(50, 4096, 6), (204, 4096, 6), (204, 16384, 12), (512, 4096, 6), (1024, 4096, 6), (204, 65536, 24), (4096, 65536, 24)]
+for (S, N, P) in SHAPES:
     sp = synth.make_spectrum(N, P, seed=1)
     with Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
         sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=3, minfunc=-1.0, minstep=-1.0)
         sw.run(50, check_every=50)          # warm-up
-        gens = 2000
+        gens = 2000 if S * N * P < 1e9 else 200
         t0 = time.perf_counter()
         sw.run(gens, check_every=100)
         dt = time.perf_counter() - t0

@@ -107,6 +107,24 @@ struct PsoFused;
 constexpr int64_t kFusedMaxD = 400;   // 4 waves x D doubles of LDS for the updated rows (12.5 KiB at the limit)
 int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR,
                      ObjectiveDeferred *defer = nullptr, const PsoFused *fused = nullptr);
+// What the persistent generation kernel needs of a swarm (pso.hip owns the buffers).
+struct SwarmView {
+    int64_t S = 0, offset = 0;
+    int32_t P = 0;
+    double *x = nullptr, *v = nullptr, *p = nullptr, *fx = nullptr, *fp = nullptr, *best = nullptr, *cand = nullptr;
+    long long *flags = nullptr;
+    const double *lb = nullptr, *ub = nullptr;
+    uint64_t seed = 0;
+    double omega = 0, phip = 0, phig = 0, minstep = 0, minfunc = 0;
+    unsigned long long *count = nullptr;   // grid-barrier arrival counter
+    double *post_val = nullptr;            // [2][max_posts]
+    long long *post_idx = nullptr;
+    int64_t max_posts = 0;
+    int *err = nullptr;
+};
+// `generations` whole swarm generations in ONE cooperative launch (single-rank swarms small enough
+// to be latency-bound); *launched tells whether the swarm qualified.
+int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bool *launched);
 int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need);
 // centred grid + per-chunk (min,max) table from the raw device copy of w
 int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw);

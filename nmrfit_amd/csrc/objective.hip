@@ -45,6 +45,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace nmrfit {
 namespace {
@@ -468,7 +469,6 @@ __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *r
 //                                  expansion per chunk (opt-in; see the chunk loop)
 // Wave g = blockIdx.x*4 + wave  ->  particle g / nseg, segment g % nseg;
 // a segment is seg_len (multiple of 512) consecutive grid points.
-template <int VARIANT, bool WRITE_R, int FIT_IM>
 // FIT_IM: 0 real part only (reference default); 1 reference-compatible fit_im=True -- the
 // imaginary model is the LAST peak's dispersion only, because equations.py:199 assigns
 // instead of accumulating; 2 the imaginary model is the sum over all peaks.
@@ -476,7 +476,20 @@ template <int VARIANT, bool WRITE_R, int FIT_IM>
 // ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
 // With the imaginary part the epilogue also evaluates dispersion lines (Dawson polynomials):
 // 2 waves per SIMD rather than spilling.
-__global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_NOSKIP || VARIANT == NMRFIT_VARIANT_STAGED || VARIANT == NMRFIT_VARIANT_FARFIELD || VARIANT == NMRFIT_VARIANT_NOREC) ? NMRFIT_MIN_WAVES : 4) void objective_kernel(
+// PERSIST: the same body called from the persistent generation kernel below -- the task index
+// comes from the caller, the position update is done in place (all waves of a particle sit in
+// this workgroup and meet at a barrier between reading the old row and writing the new one) and
+// the per-block sums go to LDS (`psums`) instead of global memory.
+#define NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)                                                                    \
+    ((FIT_IM) != 0 ? 2                                                                                                 \
+                   : ((VARIANT) == NMRFIT_VARIANT_DEFAULT || (VARIANT) == NMRFIT_VARIANT_NOSKIP ||                     \
+                      (VARIANT) == NMRFIT_VARIANT_STAGED || (VARIANT) == NMRFIT_VARIANT_FARFIELD ||                    \
+                      (VARIANT) == NMRFIT_VARIANT_NOREC)                                                               \
+                         ? NMRFIT_MIN_WAVES                                                                            \
+                         : 4)
+template <int VARIANT, bool WRITE_R, int FIT_IM, bool PERSIST>
+__device__ __forceinline__ void objective_body(
+    unsigned char *lds_raw, const int64_t g,
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax,
     const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, double wspan, int nseg,
@@ -484,9 +497,9 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
     double *__restrict__ out,       // nseg == 1: f[S];  else per-block sums [S * n_blocks] (x2 with FIT_IM)
     double *__restrict__ R_out,     // WRITE_R: residual rows [S*N]
     unsigned long long *__restrict__ clk,   // profiling only (else null): shader / reference clock of workgroup 0
-    const PsoFused upd)             // swarm generations: advance the particle first (x_in != null), X is then unused
+    const PsoFused &upd,            // swarm generations: advance the particle first (x_in != null), X is then unused
+    double *psums)                  // PERSIST: this particle's per-block sums in LDS [n_blocks] (x2 with FIT_IM)
 {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     PeakLor *lor = reinterpret_cast<PeakLor *>(lds_raw) + (size_t)wave * P;
@@ -519,7 +532,6 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
                                                   (kRec ? (size_t)kWavesPerBlock * P * sizeof(double2) : 0)) +
                      (size_t)wave * P;
 
-    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     if (clk && g == 0 && lane == 0) {   // nmrfit_prof_*: ticks of the core clock and of the 100 MHz reference
         clk[0] = __builtin_amdgcn_s_memtime();
         clk[1] = __builtin_amdgcn_s_memrealtime();
@@ -599,6 +611,29 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
         // read, so the segments of a particle cannot race.  After a stop every launch is a no-op:
         // the row is carried over unchanged and the kernel returns.
         double *xrow = reinterpret_cast<double *>(lds_raw + upd.xrow_off) + (size_t)wave * D;
+        if constexpr (PERSIST) {
+            // in place: the workgroup owns every segment of its particles, so "all old rows read"
+            // is one workgroup barrier away; the caller has left the loop on a stop
+            double *vrow = xrow + (size_t)kWavesPerBlock * D;
+            for (int64_t d = lane; d < D; d += kWave) {
+                const int64_t idx = particle * D + d;
+                double xn = 0.0, vn = 0.0;
+                if (active) {
+                    double rp, rg;
+                    uniform2(upd.seed, upd.gen, (uint32_t)d, (uint64_t)(upd.offset + particle), &rp, &rg);
+                    xn = update_value(upd.x_in[idx], upd.v_in[idx], upd.p[idx], upd.best[2 + d], upd.lb[d], upd.ub[d],
+                                      rp, rg, upd.omega, upd.phip, upd.phig, &vn);
+                }
+                xrow[d] = xn;
+                vrow[d] = vn;
+            }
+            __syncthreads();
+            if (active && seg == 0)
+                for (int64_t d = lane; d < D; d += kWave) {
+                    upd.x_out[particle * D + d] = xrow[d];
+                    upd.v_out[particle * D + d] = vrow[d];
+                }
+        } else {
         const bool stopped = upd.flags[1] != 0;
         const uint32_t gen = (uint32_t)(upd.flags[0] + 1);
         for (int64_t d = lane; d < D; d += kWave) {
@@ -617,6 +652,7 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
             }
         }
         if (stopped) return;   // the same for every wave of the grid
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
         stage_peaks(xrow);
     } else {
@@ -1018,7 +1054,16 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
             bs = 0.0;
             bs_im = 0.0;
             cib = 0;
-            if (nseg == 1) {
+            if constexpr (PERSIST) {
+                if (lane == 0) {
+                    if (FIT_IM == 0) {
+                        psums[blk0 + bidx] = cs;
+                    } else {
+                        psums[2 * (blk0 + bidx)] = cs;
+                        psums[2 * (blk0 + bidx) + 1] = cs_im;
+                    }
+                }
+            } else if (nseg == 1) {
                 ss += cs;
                 ss_im += cs_im;
             } else if (lane == 0) {
@@ -1060,11 +1105,234 @@ __global__ __launch_bounds__(kBlock, FIT_IM != 0 ? 2 : (VARIANT == NMRFIT_VARIAN
         clk[2] = __builtin_amdgcn_s_memtime();
         clk[3] = __builtin_amdgcn_s_memrealtime();
     }
-    if (nseg == 1 && lane == 0) {
+    if (!PERSIST && nseg == 1 && lane == 0) {
         if (FIT_IM == 0)
             out[particle] = sqrt(ss / (double)N);
         else   // (rmse_real + rmse_imag) / 2, equations.py:205-209
             out[particle] = 0.5 * (sqrt(ss / (double)N) + sqrt(ss_im / (double)N));
+    }
+}
+
+template <int VARIANT, bool WRITE_R, int FIT_IM>
+__global__ __launch_bounds__(kBlock, NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)) void objective_kernel(
+    const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
+    const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax, const double *__restrict__ X, int64_t S,
+    int P, int64_t N, double w0, double wspan, int nseg, int64_t seg_len, int blk_chunks, double lane_step,
+    double rec_devk, double *__restrict__ out, double *__restrict__ R_out, unsigned long long *__restrict__ clk,
+    const PsoFused upd)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    objective_body<VARIANT, WRITE_R, FIT_IM, false>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg,
+                                                    seg_len, blk_chunks, lane_step, rec_devk, out, R_out, clk, upd,
+                                                    nullptr);
+}
+
+// ---- persistent generations (small single-rank swarms) --------------------------------------------
+// A small swarm is latency-bound: at the reference's default of 204 particles a generation is
+// ~1 us of arithmetic inside two launches of ~9 us each, almost all of it dependent round trips
+// to memory and kernel start/finish.  Here ONE cooperative launch runs many generations: every
+// workgroup owns the same particles for the whole launch (all segments of a particle in one
+// workgroup), advances and evaluates them, updates their personal bests, and posts its
+// (best value, index); the workgroups meet at one grid barrier per generation, every workgroup
+// then folds ALL posts identically (lexicographic minimum = np.argmin), fetches the winner's row
+// and applies pyswarm's acceptance / stopping rule to its own LDS copy of (g, fg).  What crosses
+// workgroups -- the posts, the arrival counter and personal-best rows -- moves through
+// agent-scope atomic stores / loads (write-through, coherent across the 8 XCDs) instead of
+// release fences: a fence is an L2 write-back per workgroup on this part and costs 8 us per
+// exchange at 51 workgroups, 30 us at 204; the atomic form 1.8 us and 3.9 us
+// (tools/barrier_probe.hip).  Every spin gives up after 0.2 s, and the launch is cooperative (the
+// runtime refuses a grid that cannot be co-resident), so a mistake cannot hang the GPU.
+struct GenArgs {
+    const double *wc, *u, *v, *wt;
+    const double2 *chunk_minmax;
+    int64_t S, N;
+    int P, nseg, blk_chunks;
+    int64_t seg_len;
+    double w0, wspan, lane_step, rec_devk;
+    // swarm state (global) and parameters
+    double *x, *v_, *p, *fx, *fp, *best, *cand;
+    long long *flags;
+    const double *lb, *ub;
+    uint64_t seed;
+    int64_t offset;
+    double omega, phip, phig, minstep, minfunc;
+    // exchange
+    unsigned long long *count;   // arrival counter, zeroed before the launch
+    double *post_val;            // [2][gridDim.x]
+    long long *post_idx;         // [2][gridDim.x]
+    int *err;                    // set to 1 if a barrier timed out
+    int generations;
+    unsigned xrow_off, sums_off, state_off;   // byte offsets into dynamic LDS
+};
+
+__device__ __forceinline__ bool grid_arrive_and_wait(unsigned long long *count, unsigned long long target, int *err,
+                                                     int *s_ok)
+{
+    __syncthreads();   // (also: s_waitcnt vmcnt(0) -- this workgroup's write-through stores are done)
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        __hip_atomic_fetch_add(count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {   // 0.2 s of the 100 MHz reference clock
+                ok = 0;
+                *err = 1;
+                break;
+            }
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+// (one workgroup per CU at most, so the register budget of a single wave per SIMD: no spills around the body)
+template <int VARIANT, int FIT_IM>
+__global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double s_val[kWavesPerBlock];
+    __shared__ long long s_idx[kWavesPerBlock];
+    __shared__ int s_ok;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int64_t D = 4 + 3 * (int64_t)a.P;
+    double *sums = reinterpret_cast<double *>(lds_raw + a.sums_off);     // [4 particles][kMaxBlocks x 2]
+    double *best = reinterpret_cast<double *>(lds_raw + a.state_off);    // fg, best_f, g[D], best_x[D]
+    long long *flags = reinterpret_cast<long long *>(best + 2 + 2 * D);  // generations done, stop code
+    double *cand = reinterpret_cast<double *>(flags + 2);                // f, x[D]
+    for (int64_t d = threadIdx.x; d < 2 + 2 * D; d += kBlock) best[d] = a.best[d];
+    if (threadIdx.x < 2) flags[threadIdx.x] = a.flags[threadIdx.x];
+    __syncthreads();
+    if (flags[1] != 0) return;   // stopped before this launch: nothing to do (every workgroup agrees)
+    const int ppp = kWavesPerBlock / a.nseg;   // particles per workgroup per pass
+    const int64_t n_chunks = (a.N + kChunk - 1) / kChunk;
+    const int64_t n_blocks = (n_chunks + a.blk_chunks - 1) / a.blk_chunks;
+    const unsigned nwg = gridDim.x;
+    for (int it = 0; it < a.generations; ++it) {
+        double mine = INFINITY;
+        long long mi = 0x7fffffffffffffffLL;
+        for (int64_t base = (int64_t)blockIdx.x * ppp; base < a.S; base += (int64_t)nwg * ppp) {
+            const int slot = wave / a.nseg;
+            const int64_t particle = base + slot;
+            // a wave without a particle takes a task index beyond the swarm: it idles through the body's barriers
+            const int64_t g = (particle < a.S) ? particle * a.nseg + (wave % a.nseg) : a.S * a.nseg;
+            PsoFused upd;
+            upd.x_in = a.x;
+            upd.v_in = a.v_;
+            upd.x_out = a.x;
+            upd.v_out = a.v_;
+            upd.p = a.p;
+            upd.best = best;
+            upd.lb = a.lb;
+            upd.ub = a.ub;
+            upd.seed = a.seed;
+            upd.offset = a.offset;
+            upd.omega = a.omega;
+            upd.phip = a.phip;
+            upd.phig = a.phig;
+            upd.xrow_off = a.xrow_off;
+            upd.gen = (uint32_t)(flags[0] + 1);
+            objective_body<VARIANT, false, FIT_IM, true>(lds_raw, g, a.wc, a.u, a.v, a.wt, a.chunk_minmax, nullptr, a.S,
+                                                         a.P, a.N, a.w0, a.wspan, a.nseg, a.seg_len, a.blk_chunks,
+                                                         a.lane_step, a.rec_devk, nullptr, nullptr, nullptr, upd,
+                                                         sums + (size_t)slot * (2 * kMaxBlocks));
+            __syncthreads();   // the pass's block sums are in LDS, its new rows in global memory
+            if (wave < ppp && base + wave < a.S) {   // wave w: objective value and personal best of particle slot w
+                const int64_t i = base + wave;
+                const double *ps = sums + (size_t)wave * (2 * kMaxBlocks);
+                double f;   // same arithmetic and order as finalize_kernel
+                if (FIT_IM == 0) {
+                    double ss = 0.0;
+                    for (int64_t c = 0; c < n_blocks; ++c) ss += ps[c];
+                    f = sqrt(ss / (double)a.N);
+                } else {
+                    double ss = 0.0, si = 0.0;
+                    for (int64_t c = 0; c < n_blocks; ++c) {
+                        ss += ps[2 * c];
+                        si += ps[2 * c + 1];
+                    }
+                    f = 0.5 * (sqrt(ss / (double)a.N) + sqrt(si / (double)a.N));
+                }
+                double cur = a.fp[i];
+                if (lane == 0) a.fx[i] = f;
+                if (f < cur) {   // pyswarm: i_update = fx < fp
+                    for (int64_t d = lane; d < D; d += kWave)
+                        __hip_atomic_store(a.p + i * D + d, a.x[i * D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) a.fp[i] = f;
+                    cur = f;
+                }
+                if (lex_less(cur, i, mine, mi)) {
+                    mine = cur;
+                    mi = i;
+                }
+            }
+            __syncthreads();   // sums are free for the next pass
+        }
+        if (lane == 0) {
+            s_val[wave] = mine;
+            s_idx[wave] = mi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double b = s_val[0];
+            long long bi = s_idx[0];
+            for (int w = 1; w < kWavesPerBlock; ++w)
+                if (lex_less(s_val[w], s_idx[w], b, bi)) {
+                    b = s_val[w];
+                    bi = s_idx[w];
+                }
+            const size_t slot = (size_t)(it & 1) * nwg + blockIdx.x;   // two alternating sets: a fast workgroup
+            __hip_atomic_store(a.post_val + slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cannot overwrite
+            __hip_atomic_store(a.post_idx + slot, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // what a slow one reads
+        }
+        if (!grid_arrive_and_wait(a.count, (unsigned long long)(it + 1) * nwg, a.err, &s_ok)) return;
+        // every workgroup folds all posts the same way: first minimum in (value, index) order
+        double bv = INFINITY;
+        long long bidx = 0x7fffffffffffffffLL;
+        for (unsigned w = threadIdx.x; w < nwg; w += kBlock) {
+            const size_t slot = (size_t)(it & 1) * nwg + w;
+            const double pv = __hip_atomic_load(a.post_val + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long pi = __hip_atomic_load(a.post_idx + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lex_less(pv, pi, bv, bidx)) {
+                bv = pv;
+                bidx = pi;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_down(bv, off, kWave);
+            const long long oi = __shfl_down(bidx, off, kWave);
+            if (lex_less(ov, oi, bv, bidx)) {
+                bv = ov;
+                bidx = oi;
+            }
+        }
+        if (lane == 0) {
+            s_val[wave] = bv;
+            s_idx[wave] = bidx;
+        }
+        __syncthreads();
+        bv = s_val[0];
+        bidx = s_idx[0];
+        for (int w = 1; w < kWavesPerBlock; ++w)
+            if (lex_less(s_val[w], s_idx[w], bv, bidx)) {
+                bv = s_val[w];
+                bidx = s_idx[w];
+            }
+        if (bidx >= a.S) bidx = 0;   // np.argmin of an all-inf array
+        if (threadIdx.x == 0) cand[0] = bv;
+        for (int64_t d = threadIdx.x; d < D; d += kBlock)
+            cand[1 + d] = __hip_atomic_load(a.p + bidx * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (wave == 0) apply_wave(lane, D, 1, 0, a.minstep, a.minfunc, cand, flags, best);
+        __syncthreads();
+        if (blockIdx.x == 0) {   // the official copy (host polls the flags; later launches start from it)
+            for (int64_t d = threadIdx.x; d < 2 + 2 * D; d += kBlock) a.best[d] = best[d];
+            for (int64_t d = threadIdx.x; d < D + 1; d += kBlock) a.cand[d] = cand[d];
+            if (threadIdx.x < 2) a.flags[threadIdx.x] = flags[threadIdx.x];
+        }
+        if (flags[1] != 0) return;   // stop: every workgroup has computed the same flag
     }
 }
 
@@ -1198,6 +1466,35 @@ int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw)
     return NMRFIT_OK;
 }
 
+// The kernel variant a launch actually runs (the requested one may not fit in LDS, or may not
+// implement the imaginary part) and the dynamic LDS its per-wave records need.
+static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, int fit_im, int *variant_out)
+{
+    const bool dR = residual;
+    const size_t lds_recs = (((size_t)kWavesPerBlock * (size_t)std::max(P, 1) * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
+                            (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2);
+    const size_t lds_stage = (size_t)kWavesPerBlock * 3 * kChunk * sizeof(double);
+    // STAGED needs three workgroups to still fit in a CU's 160 KiB (P <= 27); beyond that it
+    // runs the unstaged kernel.
+    int variant = ctx->variant;
+    if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
+    const size_t lds_far = (size_t)kWavesPerBlock * kFarTerms * kFarPad * sizeof(double);
+    // Gaussian recurrence constants (d, C) per peak: objective launches of DEFAULT / FARFIELD
+    const size_t lds_rec = dR ? 0 : (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(double2);
+    if (variant == NMRFIT_VARIANT_FARFIELD && (lds_recs + lds_far + lds_rec > 160 * 1024 || fit_im != 0))
+        variant = NMRFIT_VARIANT_DEFAULT;   // P > ~600, or the imaginary part (direct kernel only)
+    const size_t lds_fast = (NMRFIT_FASTPAIR != 0 && NMRFIT_GROUP == 8)
+                                ? (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(PeakFast) : 0;
+    if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_rec + lds_fast > 160 * 1024)
+        variant = NMRFIT_VARIANT_NOREC;     // P > ~450: no room for the recurrence / scaled records
+    size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
+                 (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : 0) +
+                 ((variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_DEFAULT) ? lds_rec : 0) +
+                 (variant == NMRFIT_VARIANT_DEFAULT ? lds_fast : 0);
+    *variant_out = variant;
+    return lds;
+}
+
 int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR,
                      ObjectiveDeferred *defer, const PsoFused *fused)
 {
@@ -1233,26 +1530,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         set_error("swarm too large for one launch");
         return NMRFIT_E_INVALID;
     }
-    const size_t lds_recs = (((size_t)kWavesPerBlock * (size_t)std::max(P, 1) * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
-                            (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2);
-    const size_t lds_stage = (size_t)kWavesPerBlock * 3 * kChunk * sizeof(double);
-    // STAGED needs three workgroups to still fit in a CU's 160 KiB (P <= 27); beyond that it
-    // runs the unstaged kernel.
-    int variant = ctx->variant;
-    if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
-    const size_t lds_far = (size_t)kWavesPerBlock * kFarTerms * kFarPad * sizeof(double);
-    // Gaussian recurrence constants (d, C) per peak: objective launches of DEFAULT / FARFIELD
-    const size_t lds_rec = dR ? 0 : (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(double2);
-    if (variant == NMRFIT_VARIANT_FARFIELD && (lds_recs + lds_far + lds_rec > 160 * 1024 || fit_im != 0))
-        variant = NMRFIT_VARIANT_DEFAULT;   // P > ~600, or the imaginary part (direct kernel only)
-    const size_t lds_fast = (NMRFIT_FASTPAIR != 0 && NMRFIT_GROUP == 8)
-                                ? (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(PeakFast) : 0;
-    if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_rec + lds_fast > 160 * 1024)
-        variant = NMRFIT_VARIANT_NOREC;     // P > ~450: no room for the recurrence / scaled records
-    size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
-                 (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : 0) +
-                 ((variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_DEFAULT) ? lds_rec : 0) +
-                 (variant == NMRFIT_VARIANT_DEFAULT ? lds_fast : 0);
+    int variant = NMRFIT_VARIANT_DEFAULT;
+    size_t lds = resolve_variant(ctx, P, dR != nullptr, fit_im, &variant);
     // fused swarm update: one copy of the particle's updated row per wave, after everything else
     PsoFused upd{};
     if (fused && fused->x_in) {
@@ -1312,6 +1591,111 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     ctx->last.waves = waves;
     ctx->last.nseg = (int32_t)nseg;
     ctx->last.seg_len = seg_len;
+    return NMRFIT_OK;
+}
+
+// Persistent generations: see generation_kernel.  *launched = false (and NMRFIT_OK) when this
+// swarm does not qualify -- the caller then runs its launch-per-phase generations.
+int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bool *launched)
+{
+    *launched = false;
+    static const bool off = getenv("NMRFIT_NO_PERSISTENT") != nullptr;   // A/B knob
+    static const double max_units = [] {
+        const char *e = getenv("NMRFIT_PERSIST_MAX_UNITS");
+        return e ? atof(e) : 1.0e8;
+    }();
+    const int64_t S = sw.S, N = ctx->N, D = 4 + 3 * (int64_t)sw.P;
+    if (off || generations < 1 || S < 1 || D > kFusedMaxD) return NMRFIT_OK;
+    // worth it only while a generation is latency-bound (a few tens of microseconds of arithmetic)
+    if ((double)S * (double)N * (double)std::max(sw.P, 1) > max_units) return NMRFIT_OK;
+    const int fit_im = ctx->fit_im;
+    int variant = NMRFIT_VARIANT_DEFAULT;
+    const size_t lds_obj = resolve_variant(ctx, sw.P, false, fit_im, &variant);
+    if (!(variant == NMRFIT_VARIANT_DEFAULT || (variant == NMRFIT_VARIANT_FARFIELD && fit_im == 0))) return NMRFIT_OK;
+    // all segments of a particle in one workgroup: nseg in {1, 2, 4}, >= 2 chunks per wave if possible
+    const int64_t n_chunks = (N + kChunk - 1) / kChunk;
+    const int blk_chunks = (int)((n_chunks + kMaxBlocks - 1) / kMaxBlocks);
+    const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
+    const int64_t blk_len = (int64_t)blk_chunks * kChunk;
+    int nseg = 4;
+    if (const char *e = getenv("NMRFIT_PERSIST_NSEG")) nseg = atoi(e);
+    if (nseg != 1 && nseg != 2 && nseg != 4) nseg = 4;
+    while (nseg > 1 && (n_blocks < nseg || n_chunks / nseg < 2)) nseg >>= 1;
+    const int64_t seg_len = ((n_blocks + nseg - 1) / nseg) * blk_len;
+    if ((N + seg_len - 1) / seg_len != nseg) nseg = (int)((N + seg_len - 1) / seg_len);   // e.g. 3 blocks over 2 segments
+    if (nseg != 1 && nseg != 2 && nseg != 4) return NMRFIT_OK;
+    const int ppp = kWavesPerBlock / nseg;
+    GenArgs a{};
+    size_t lds = (lds_obj + 15) & ~(size_t)15;
+    a.xrow_off = (unsigned)lds;
+    lds += 2 * (size_t)kWavesPerBlock * (size_t)D * sizeof(double);     // x rows, then v rows
+    a.sums_off = (unsigned)lds;
+    lds += (size_t)kWavesPerBlock * 2 * kMaxBlocks * sizeof(double);
+    a.state_off = (unsigned)lds;
+    lds += (size_t)(2 + 2 * D) * sizeof(double) + 2 * sizeof(long long) + (size_t)(D + 1) * sizeof(double);
+    if (lds > 64 * 1024) return NMRFIT_OK;
+    const void *fn = nullptr;
+    if (variant == NMRFIT_VARIANT_FARFIELD)
+        fn = (const void *)generation_kernel<NMRFIT_VARIANT_FARFIELD, 0>;
+    else if (fit_im == 0)
+        fn = (const void *)generation_kernel<NMRFIT_VARIANT_DEFAULT, 0>;
+    else if (fit_im == 1)
+        fn = (const void *)generation_kernel<NMRFIT_VARIANT_DEFAULT, 1>;
+    else
+        fn = (const void *)generation_kernel<NMRFIT_VARIANT_DEFAULT, 2>;
+    int per_cu = 0;
+    NMRFIT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
+    if (per_cu < 1) return NMRFIT_OK;
+    // one workgroup per CU at most: the exchange costs ~4 us at 204 workgroups, ~9 us at 512
+    int64_t max_wg = (int64_t)ctx->compute_units;
+    if (const char *e = getenv("NMRFIT_PERSIST_MAX_WG")) max_wg = atoll(e);
+    max_wg = std::min<int64_t>(max_wg, (int64_t)per_cu * ctx->compute_units);
+    const int64_t nwg = std::max<int64_t>(1, std::min<int64_t>((S + ppp - 1) / ppp, max_wg));
+    if (nwg > sw.max_posts) return NMRFIT_OK;
+    a.wc = ctx->d_wc;
+    a.u = ctx->d_u;
+    a.v = ctx->d_v;
+    a.wt = ctx->d_wt;
+    a.chunk_minmax = ctx->d_chunk;
+    a.S = S;
+    a.N = N;
+    a.P = sw.P;
+    a.nseg = nseg;
+    a.blk_chunks = blk_chunks;
+    a.seg_len = seg_len;
+    a.w0 = ctx->w0;
+    a.wspan = ctx->wspan;
+    a.lane_step = ctx->lane_step;
+    a.rec_devk = ctx->grid_dev * 11.0e10;
+    a.x = sw.x;
+    a.v_ = sw.v;
+    a.p = sw.p;
+    a.fx = sw.fx;
+    a.fp = sw.fp;
+    a.best = sw.best;
+    a.cand = sw.cand;
+    a.flags = sw.flags;
+    a.lb = sw.lb;
+    a.ub = sw.ub;
+    a.seed = sw.seed;
+    a.offset = sw.offset;
+    a.omega = sw.omega;
+    a.phip = sw.phip;
+    a.phig = sw.phig;
+    a.minstep = sw.minstep;
+    a.minfunc = sw.minfunc;
+    a.count = sw.count;
+    a.post_val = sw.post_val;
+    a.post_idx = sw.post_idx;
+    a.err = sw.err;
+    a.generations = generations;
+    NMRFIT_HIP(hipMemsetAsync(sw.count, 0, sizeof(unsigned long long), ctx->stream));
+    void *params[] = {(void *)&a};
+    NMRFIT_HIP(hipLaunchCooperativeKernel(fn, dim3((unsigned)nwg), dim3(kBlock), params, (unsigned)lds, ctx->stream));
+    ctx->last.waves = nwg * kWavesPerBlock;
+    ctx->last.nseg = nseg;
+    ctx->last.seg_len = seg_len;
+    *launched = true;
     return NMRFIT_OK;
 }
 

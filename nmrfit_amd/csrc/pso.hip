@@ -53,6 +53,8 @@ struct nmrfit_pso {
     double *d_part_val = nullptr;      // pso_select_kernel: per-workgroup (min fp, index) posts
     long long *d_part_idx = nullptr;
     unsigned *d_ticket = nullptr;
+    unsigned long long *d_count = nullptr;   // persistent generations: grid-barrier arrival counter
+    int *d_err = nullptr;                    // ... and its time-out flag
     nmrfit_comm *comm = nullptr;       // attached communicator (sharded swarm): the exchange runs inside nmrfit_pso_step
     bool initialized = false;    // nmrfit_pso_init has run
     bool seeded = false;         // the generation-0 candidates have been folded into (g, fg)
@@ -155,71 +157,6 @@ __device__ __forceinline__ void argmin_block(int64_t S, int64_t D, const double 
         if (lane == 0) cand[0] = (S > 0) ? fp[bi] : INFINITY;
         for (int64_t d = lane; d < D; d += kWave) cand[1 + d] = (S > 0) ? p[bi * D + d] : 0.0;
     }
-}
-
-// one wave: fold the candidate records, apply pyswarm's acceptance / stopping rule
-__device__ __forceinline__ void apply_wave(int lane, int64_t D, int nranks, int is_init, double minstep,
-                                           double minfunc, const double *cands, long long *flags, double *best)
-{
-    // lowest value wins, lowest rank wins ties (every rank sees the same records)
-    int win = 0;
-    double fc = cands[0];
-    for (int r = 1; r < nranks; ++r) {
-        const double f = cands[(int64_t)r * (D + 1)];
-        if (f < fc) {
-            fc = f;
-            win = r;
-        }
-    }
-    const double *pc = cands + (int64_t)win * (D + 1) + 1;
-    double *g = best + 2, *bx = best + 2 + D;
-    const double fg = best[0];
-    if (is_init) {
-        for (int64_t d = lane; d < D; d += kWave) {
-            g[d] = pc[d];
-            bx[d] = pc[d];
-        }
-        if (lane == 0) {
-            best[0] = fc;
-            best[1] = fc;
-            flags[0] = 0;
-        }
-        return;
-    }
-    int code = 0;   // 0: not better, 1: stop minfunc, 2: stop minstep, 3: accept
-    if (fc < fg) {
-        double acc = 0.0;
-        for (int64_t d = lane; d < D; d += kWave) {
-            const double df = g[d] - pc[d];
-            acc += df * df;
-        }
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
-        acc = __shfl(acc, 0, kWave);
-        const double stepsize = sqrt(acc);
-        if (fabs(fg - fc) <= minfunc)
-            code = 1;
-        else if (stepsize <= minstep)
-            code = 2;
-        else
-            code = 3;
-    }
-    if (code == 1 || code == 2) {
-        for (int64_t d = lane; d < D; d += kWave) bx[d] = pc[d];
-        if (lane == 0) {
-            best[1] = fc;
-            flags[1] = code;
-        }
-    } else if (code == 3) {
-        for (int64_t d = lane; d < D; d += kWave) {
-            g[d] = pc[d];
-            bx[d] = pc[d];
-        }
-        if (lane == 0) {
-            best[0] = fc;
-            best[1] = fc;
-        }
-    }
-    if (lane == 0) flags[0] = flags[0] + 1;
 }
 
 // ---- stand-alone kernels (large swarms: one launch per phase, many workgroups) ------------
@@ -327,10 +264,6 @@ constexpr int kSelectWaves = 4;          // particles per workgroup pass
 constexpr int kSelectTicketBlocks = 128;
 constexpr int kSelectMaxPosts = 65536;    // huge swarms: workgroups stride over the particles  // up to this many workgroups the last-ticket form wins (one fence each)
 
-__device__ __forceinline__ bool lex_less(double v, long long i, double bv, long long bi)
-{
-    return v < bv || (v == bv && i < bi);
-}
 
 // Reduce the nb posted (min fp, index) pairs, write the candidate record and (kTailApply) fold
 // it.  Called by every thread of ONE workgroup; posts and rows written by other workgroups are
@@ -674,6 +607,9 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
         PSO_HIP(hipMalloc((void **)&pso->d_part_val, nb * sizeof(double)));
         PSO_HIP(hipMalloc((void **)&pso->d_part_idx, nb * sizeof(long long)));
         PSO_HIP(hipMalloc((void **)&pso->d_ticket, sizeof(unsigned)));
+        PSO_HIP(hipMalloc((void **)&pso->d_count, sizeof(unsigned long long)));
+        PSO_HIP(hipMalloc((void **)&pso->d_err, sizeof(int)));
+        PSO_HIP(hipMemsetAsync(pso->d_err, 0, sizeof(int), ctx->stream));
         PSO_HIP(hipMemsetAsync(pso->d_ticket, 0, sizeof(unsigned), ctx->stream));
     }
     PSO_HIP(hipMemcpyAsync(pso->d_lb, lower, (size_t)D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -694,7 +630,7 @@ int nmrfit_pso_destroy(nmrfit_pso *pso)
         (void)hipStreamSynchronize(pso->ctx->stream);
     }
     void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_x2, pso->d_v2, pso->d_p, pso->d_fx, pso->d_fp, pso->d_cand_own, pso->d_flags, pso->d_best,
-                    pso->d_part_val, pso->d_part_idx, pso->d_ticket};
+                    pso->d_part_val, pso->d_part_idx, pso->d_ticket, pso->d_count, pso->d_err};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete pso;
@@ -867,15 +803,55 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
         }
         return NMRFIT_OK;
     }
-    // single rank: a generation is the objective launch (which also advances the swarm) and the
-    // select launch (which also folds the candidate and applies the stopping rule)
-    for (int64_t it = 1; it <= maxiter; ++it) {
-        if ((rc = nmrfit_pso_step(pso)) != NMRFIT_OK) return rc;
-        if (it % check_every == 0 || it == maxiter) {
-            int32_t stop = 0;
-            if ((rc = nmrfit_pso_status(pso, nullptr, &stop, nullptr)) != NMRFIT_OK) return rc;
-            if (stop) break;
+    // single rank.  Small (latency-bound) swarms run `check_every` generations per cooperative
+    // launch of the persistent generation kernel (objective.hip); otherwise a generation is the
+    // objective launch (which also advances the swarm) and the select launch (which also folds the
+    // candidate and applies the stopping rule).
+    int64_t it = 0;
+    while (it < maxiter) {
+        const int64_t n = std::min<int64_t>(check_every, maxiter - it);
+        SwarmView vw;
+        vw.S = pso->S;
+        vw.offset = pso->offset;
+        vw.P = pso->P;
+        vw.x = pso->d_x;
+        vw.v = pso->d_v;
+        vw.p = pso->d_p;
+        vw.fx = pso->d_fx;
+        vw.fp = pso->d_fp;
+        vw.best = pso->d_best;
+        vw.cand = pso->d_cand;
+        vw.flags = pso->d_flags;
+        vw.lb = pso->d_lb;
+        vw.ub = pso->d_ub;
+        vw.seed = pso->prm.seed;
+        vw.omega = pso->prm.omega;
+        vw.phip = pso->prm.phip;
+        vw.phig = pso->prm.phig;
+        vw.minstep = pso->prm.minstep;
+        vw.minfunc = pso->prm.minfunc;
+        vw.count = pso->d_count;
+        vw.post_val = pso->d_part_val;
+        vw.post_idx = pso->d_part_idx;
+        vw.max_posts = kSelectMaxPosts / 2;
+        vw.err = pso->d_err;
+        bool launched = false;
+        if ((rc = launch_generations(pso->ctx, vw, (int)std::min<int64_t>(n, 1 << 20), &launched)) != NMRFIT_OK) return rc;
+        if (!launched)
+            for (int64_t k = 0; k < n; ++k)
+                if ((rc = nmrfit_pso_step(pso)) != NMRFIT_OK) return rc;
+        it += n;
+        int32_t stop = 0;
+        if ((rc = nmrfit_pso_status(pso, nullptr, &stop, nullptr)) != NMRFIT_OK) return rc;
+        if (launched) {
+            int err = 0;
+            NMRFIT_HIP(hipMemcpy(&err, pso->d_err, sizeof err, hipMemcpyDeviceToHost));
+            if (err) {
+                set_error("persistent generation kernel: a grid barrier timed out (workgroups not co-resident?)");
+                return NMRFIT_E_HIP;
+            }
         }
+        if (stop) break;
     }
     return NMRFIT_OK;
 }

@@ -76,6 +76,78 @@ struct PsoFused {
     int64_t offset = 0;                               // global index of this shard's first particle
     double omega = 0.0, phip = 0.0, phig = 0.0;
     unsigned xrow_off = 0;                            // byte offset of the per-wave x rows in dynamic LDS
+    uint32_t gen = 0;                                 // persistent generations: the generation being computed
 };
+
+__device__ __forceinline__ bool lex_less(double v, long long i, double bv, long long bi)
+{
+    return v < bv || (v == bv && i < bi);
+}
+
+// one wave: fold the candidate records, apply pyswarm's acceptance / stopping rule
+__device__ __forceinline__ void apply_wave(int lane, int64_t D, int nranks, int is_init, double minstep,
+                                           double minfunc, const double *cands, long long *flags, double *best)
+{
+#pragma clang fp contract(off)
+    // lowest value wins, lowest rank wins ties (every rank sees the same records)
+    int win = 0;
+    double fc = cands[0];
+    for (int r = 1; r < nranks; ++r) {
+        const double f = cands[(int64_t)r * (D + 1)];
+        if (f < fc) {
+            fc = f;
+            win = r;
+        }
+    }
+    const double *pc = cands + (int64_t)win * (D + 1) + 1;
+    double *g = best + 2, *bx = best + 2 + D;
+    const double fg = best[0];
+    if (is_init) {
+        for (int64_t d = lane; d < D; d += 64) {
+            g[d] = pc[d];
+            bx[d] = pc[d];
+        }
+        if (lane == 0) {
+            best[0] = fc;
+            best[1] = fc;
+            flags[0] = 0;
+        }
+        return;
+    }
+    int code = 0;   // 0: not better, 1: stop minfunc, 2: stop minstep, 3: accept
+    if (fc < fg) {
+        double acc = 0.0;
+        for (int64_t d = lane; d < D; d += 64) {
+            const double df = g[d] - pc[d];
+            acc += df * df;
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        acc = __shfl(acc, 0, 64);
+        const double stepsize = sqrt(acc);
+        if (fabs(fg - fc) <= minfunc)
+            code = 1;
+        else if (stepsize <= minstep)
+            code = 2;
+        else
+            code = 3;
+    }
+    if (code == 1 || code == 2) {
+        for (int64_t d = lane; d < D; d += 64) bx[d] = pc[d];
+        if (lane == 0) {
+            best[1] = fc;
+            flags[1] = code;
+        }
+    } else if (code == 3) {
+        for (int64_t d = lane; d < D; d += 64) {
+            g[d] = pc[d];
+            bx[d] = pc[d];
+        }
+        if (lane == 0) {
+            best[0] = fc;
+            best[1] = fc;
+        }
+    }
+    if (lane == 0) flags[0] = flags[0] + 1;
+}
 
 }  // namespace nmrfit

@@ -421,7 +421,7 @@ class DeviceSwarm:
         _cabi.check(self._lib.nmrfit_pso_best(self._h, _cabi.ptr(x), ctypes.byref(f)))
         return x, f.value
 
-    def run(self, maxiter, check_every=16):
+    def run(self, maxiter, check_every=64):
         _cabi.check(self._lib.nmrfit_pso_run(self._h, int(maxiter), int(check_every)))
 
     def state(self):
@@ -476,7 +476,7 @@ def run_sharded(swarm, exchange, maxiter, check_every=1, verbose=False):
 
 
 def pso(evaluator, lb, ub, swarmsize=100, omega=0.5, phip=0.5, phig=0.5, maxiter=100, minstep=1e-8,
-        minfunc=1e-8, seed=0, check_every=16, verbose=True):
+        minfunc=1e-8, seed=0, check_every=64, verbose=True):
     """pyswarm.pso-shaped entry point over a GPU ``Evaluator`` (single rank):
     returns (xopt, fopt) like pyswarm does."""
     sw = DeviceSwarm(evaluator, lb, ub, swarmsize, seed=seed, omega=omega, phip=phip, phig=phig,

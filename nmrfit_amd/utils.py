@@ -136,7 +136,7 @@ class FitUtility:
                 ev.set_variant(_cabi.variant_id(opt['variant']))
             if exchange is None or (exchange.world == 1 and not isinstance(exchange, pso.RcclExchange)):
                 xopt, fopt = pso.pso(ev, self.lower, self.upper, swarmsize=swarmsize, maxiter=maxiter, seed=seed,
-                                     check_every=opt.get('check_every', 16), verbose=True, **kw)
+                                     check_every=opt.get('check_every', 64), verbose=True, **kw)
             else:
                 # every rank must run the same swarm: rank 0's seed wins (an unseeded fit would
                 # otherwise draw a different seed on every rank)
@@ -144,7 +144,7 @@ class FitUtility:
                 off, n = pso.shard(swarmsize, exchange.rank, exchange.world)
                 sw = pso.DeviceSwarm(ev, self.lower, self.upper, swarmsize, offset=off, S_local=n, seed=seed, **kw)
                 try:
-                    xopt, fopt = pso.run_sharded(sw, exchange, maxiter, check_every=opt.get('check_every', 16),
+                    xopt, fopt = pso.run_sharded(sw, exchange, maxiter, check_every=opt.get('check_every', 64),
                                                  verbose=True)
                 finally:
                     sw.close()

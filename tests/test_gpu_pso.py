@@ -350,3 +350,74 @@ def test_ticket_select_long_run(problem):
     np.testing.assert_array_equal(xb, host.best_x)
     assert fb == host.best_f and dev.status()["iteration"] == gens
     dev.close()
+
+
+@pytest.mark.parametrize("S,N,P,variant,fit_im", [
+    (204, 4096, 6, "default", False),      # the reference's default swarm: 204 workgroups, one particle each
+    (1024, 4096, 6, "default", False),     # C2: 256 workgroups x 4 passes
+    (1000, 2048, 3, "default", False),     # ragged last pass
+    (3, 4096, 2, "default", False),        # fewer particles than anything
+    (37, 700, 5, "default", False),        # ragged grid, two segments per particle
+    (50, 512, 4, "default", False),        # one chunk: four particles per workgroup per pass
+    (204, 4096, 6, "farfield", False),
+    (120, 4096, 3, "default", True),       # the reference's fit_im=True
+    (120, 4096, 3, "default", "sum"),
+])
+def test_persistent_generations_match_numpy_mirror(S, N, P, variant, fit_im):
+    """nmrfit_pso_run on a small single-rank swarm runs whole generations inside ONE cooperative
+    launch (generation_kernel: grid barrier, posts through agent-scope atomics).  Same Philox
+    stream, same update arithmetic, same objective arithmetic and summation order as the
+    launch-per-phase path => bit-identical to the numpy mirror (which evaluates through the plain
+    batched objective launch), whatever the polling interval."""
+    from nmrfit_amd import equations
+    sp = synth.make_spectrum(N, P, seed=11)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        ev.set_variant(_cabi.variant_id(variant))
+        ev.set_fit_im(fit_im)
+        gens = 40
+        host = pso.HostSwarm(lambda X: ev.objective_batch(X, fit_im=fit_im), sp["lower"], sp["upper"], S, seed=23,
+                             minfunc=-1.0, minstep=-1.0)
+        host.init()
+        host.apply_global(host.candidate()[None, :])
+        for _ in range(gens):
+            host.step_local()
+            host.apply_global(host.candidate()[None, :])
+        for ce in (gens, 7):
+            dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=23, minfunc=-1.0, minstep=-1.0)
+            dev.run(gens, check_every=ce)
+            st = dev.state()
+            for k in ("x", "v", "p", "fx", "fp"):
+                np.testing.assert_array_equal(st[k], getattr(host, k), err_msg="%s (check_every=%d)" % (k, ce))
+            xb, fb = dev.best()
+            np.testing.assert_array_equal(xb, host.best_x)
+            assert fb == host.best_f
+            assert dev.status() == dict(iteration=gens, stop=0, fg=host.fg)
+            np.testing.assert_array_equal(dev.candidate(), host.candidate())
+            # and the swarm can go on launch by launch from where the persistent kernel left it
+            dev.step()
+            dev.close()
+
+
+def test_persistent_generations_stop_rule():
+    """With the stopping tests armed the persistent kernel stops at the same generation with the
+    same answer as the numpy mirror, and later launches are no-ops."""
+    from nmrfit_amd import equations
+    sp = synth.make_spectrum(4096, 6, seed=1)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], 204, seed=8)
+        xh, fh = pso.run_sharded(host, pso.LocalExchange(), 2000)
+        assert host.stop in (1, 2) and host.iteration < 2000
+        for ce in (64, 5):
+            dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 204, seed=8)
+            dev.run(2000, check_every=ce)
+            st = dev.status()
+            assert (st["stop"], st["iteration"]) == (host.stop, host.iteration)
+            xb, fb = dev.best()
+            np.testing.assert_array_equal(xb, xh)
+            assert fb == fh
+            before = dev.state()
+            dev.run(50, check_every=50)          # stopped: nothing moves
+            after = dev.state()
+            for k in before:
+                np.testing.assert_array_equal(before[k], after[k])
+            dev.close()

@@ -45,6 +45,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 namespace nmrfit {
@@ -627,6 +628,7 @@ __device__ __forceinline__ void objective_body(
                 xrow[d] = xn;
                 vrow[d] = vn;
             }
+            if (upd.trace && g == 0 && lane == 0) upd.trace[9] = __builtin_amdgcn_s_memrealtime();
             __syncthreads();
             if (active && seg == 0)
                 for (int64_t d = lane; d < D; d += kWave) {
@@ -663,6 +665,7 @@ __device__ __forceinline__ void objective_body(
     const bool rec_all = kRec && (__ballot(rec_bad) == 0ull);   // every peak may take the Gaussian recurrence
     __syncthreads();
     if (!active) return;
+    if (PERSIST && upd.trace && g == 0 && lane == 0) upd.trace[10] = __builtin_amdgcn_s_memrealtime();
 
     const int64_t j0 = (int64_t)seg * seg_len;
     const int64_t j1 = (j0 + seg_len < N) ? j0 + seg_len : N;
@@ -691,6 +694,7 @@ __device__ __forceinline__ void objective_body(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
     }
     const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
+    if (PERSIST && upd.trace && g == 0 && lane == 0) upd.trace[11] = __builtin_amdgcn_s_memrealtime();
     double bs = 0.0, bs_im = 0.0;             // per-lane sums of squares of the current block
     const int64_t blk0 = j0 / blk_len;         // global index of this segment's first block
     int cib = 0, bidx = 0;                     // chunk within block, block within segment
@@ -1101,6 +1105,7 @@ __device__ __forceinline__ void objective_body(
     else
         chunk_loop(std::false_type{});
 
+    if (PERSIST && upd.trace && g == 0 && lane == 0) upd.trace[12] = __builtin_amdgcn_s_memrealtime();
     if (clk && g == 0 && lane == 0) {
         clk[2] = __builtin_amdgcn_s_memtime();
         clk[3] = __builtin_amdgcn_s_memrealtime();
@@ -1164,6 +1169,7 @@ struct GenArgs {
     int *err;                    // set to 1 if a barrier timed out
     int generations;
     unsigned xrow_off, sums_off, state_off;   // byte offsets into dynamic LDS
+    unsigned long long *trace;   // NMRFIT_PERSIST_TRACE: phase time stamps of workgroup 0 (100 MHz ticks), else null
 };
 
 __device__ __forceinline__ bool grid_arrive_and_wait(unsigned long long *count, unsigned long long target, int *err,
@@ -1210,7 +1216,10 @@ __global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
     const int64_t n_chunks = (a.N + kChunk - 1) / kChunk;
     const int64_t n_blocks = (n_chunks + a.blk_chunks - 1) / a.blk_chunks;
     const unsigned nwg = gridDim.x;
+#define GEN_TRACE(k)                                                                              \
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0 && it == a.generations - 1) a.trace[k] = __builtin_amdgcn_s_memrealtime()
     for (int it = 0; it < a.generations; ++it) {
+        GEN_TRACE(0);
         double mine = INFINITY;
         long long mi = 0x7fffffffffffffffLL;
         for (int64_t base = (int64_t)blockIdx.x * ppp; base < a.S; base += (int64_t)nwg * ppp) {
@@ -1234,11 +1243,13 @@ __global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
             upd.phig = a.phig;
             upd.xrow_off = a.xrow_off;
             upd.gen = (uint32_t)(flags[0] + 1);
+            upd.trace = (it == a.generations - 1) ? a.trace : nullptr;
             objective_body<VARIANT, false, FIT_IM, true>(lds_raw, g, a.wc, a.u, a.v, a.wt, a.chunk_minmax, nullptr, a.S,
                                                          a.P, a.N, a.w0, a.wspan, a.nseg, a.seg_len, a.blk_chunks,
                                                          a.lane_step, a.rec_devk, nullptr, nullptr, nullptr, upd,
                                                          sums + (size_t)slot * (2 * kMaxBlocks));
             __syncthreads();   // the pass's block sums are in LDS, its new rows in global memory
+            GEN_TRACE(1);
             if (wave < ppp && base + wave < a.S) {   // wave w: objective value and personal best of particle slot w
                 const int64_t i = base + wave;
                 const double *ps = sums + (size_t)wave * (2 * kMaxBlocks);
@@ -1269,6 +1280,7 @@ __global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
                 }
             }
             __syncthreads();   // sums are free for the next pass
+            GEN_TRACE(2);
         }
         if (lane == 0) {
             s_val[wave] = mine;
@@ -1287,7 +1299,9 @@ __global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
             __hip_atomic_store(a.post_val + slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cannot overwrite
             __hip_atomic_store(a.post_idx + slot, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // what a slow one reads
         }
+        GEN_TRACE(3);
         if (!grid_arrive_and_wait(a.count, (unsigned long long)(it + 1) * nwg, a.err, &s_ok)) return;
+        GEN_TRACE(4);
         // every workgroup folds all posts the same way: first minimum in (value, index) order
         double bv = INFINITY;
         long long bidx = 0x7fffffffffffffffLL;
@@ -1321,19 +1335,24 @@ __global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
                 bidx = s_idx[w];
             }
         if (bidx >= a.S) bidx = 0;   // np.argmin of an all-inf array
+        GEN_TRACE(5);
         if (threadIdx.x == 0) cand[0] = bv;
         for (int64_t d = threadIdx.x; d < D; d += kBlock)
             cand[1 + d] = __hip_atomic_load(a.p + bidx * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        GEN_TRACE(6);
         if (wave == 0) apply_wave(lane, D, 1, 0, a.minstep, a.minfunc, cand, flags, best);
         __syncthreads();
+        GEN_TRACE(7);
         if (blockIdx.x == 0) {   // the official copy (host polls the flags; later launches start from it)
             for (int64_t d = threadIdx.x; d < 2 + 2 * D; d += kBlock) a.best[d] = best[d];
             for (int64_t d = threadIdx.x; d < D + 1; d += kBlock) a.cand[d] = cand[d];
             if (threadIdx.x < 2) a.flags[threadIdx.x] = flags[threadIdx.x];
         }
+        GEN_TRACE(8);
         if (flags[1] != 0) return;   // stop: every workgroup has computed the same flag
     }
+#undef GEN_TRACE
 }
 
 // f[i] = sqrt( (sum of the particle's per-block sums, in grid order) / N ); with the imaginary
@@ -1689,9 +1708,24 @@ int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bo
     a.post_idx = sw.post_idx;
     a.err = sw.err;
     a.generations = generations;
+    static unsigned long long *d_trace = nullptr;
+    static const bool want_trace = getenv("NMRFIT_PERSIST_TRACE") != nullptr;
+    if (want_trace && !d_trace) NMRFIT_HIP(hipMalloc((void **)&d_trace, 16 * sizeof(unsigned long long)));
+    a.trace = want_trace ? d_trace : nullptr;
     NMRFIT_HIP(hipMemsetAsync(sw.count, 0, sizeof(unsigned long long), ctx->stream));
     void *params[] = {(void *)&a};
     NMRFIT_HIP(hipLaunchCooperativeKernel(fn, dim3((unsigned)nwg), dim3(kBlock), params, (unsigned)lds, ctx->stream));
+    if (want_trace) {   // development aid: where a generation's time goes (workgroup 0, last generation of the launch)
+        unsigned long long t[16];
+        NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+        NMRFIT_HIP(hipMemcpy(t, d_trace, sizeof t, hipMemcpyDeviceToHost));
+        static int shown = 0;
+        if (shown++ < 3)
+            fprintf(stderr, "persist trace (us): [update %.2f stage %.2f seeds %.2f chunks %.2f] body %.2f pbest %.2f wgmin+post %.2f barrier %.2f fold %.2f row %.2f apply %.2f writeback %.2f | nwg %lld nseg %d\n",
+                    (t[9] - t[0]) * 0.01, (t[10] - t[9]) * 0.01, (t[11] - t[10]) * 0.01, (t[12] - t[11]) * 0.01,
+                    (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01,
+                    (t[6] - t[5]) * 0.01, (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (long long)nwg, nseg);
+    }
     ctx->last.waves = nwg * kWavesPerBlock;
     ctx->last.nseg = nseg;
     ctx->last.seg_len = seg_len;

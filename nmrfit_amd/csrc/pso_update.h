@@ -77,6 +77,7 @@ struct PsoFused {
     double omega = 0.0, phip = 0.0, phig = 0.0;
     unsigned xrow_off = 0;                            // byte offset of the per-wave x rows in dynamic LDS
     uint32_t gen = 0;                                 // persistent generations: the generation being computed
+    unsigned long long *trace = nullptr;              // development aid (NMRFIT_PERSIST_TRACE)
 };
 
 __device__ __forceinline__ bool lex_less(double v, long long i, double bv, long long bi)

@@ -116,7 +116,7 @@ struct SwarmView {
     const double *lb = nullptr, *ub = nullptr;
     uint64_t seed = 0;
     double omega = 0, phip = 0, phig = 0, minstep = 0, minfunc = 0;
-    unsigned long long *count = nullptr;   // grid-barrier arrival counter
+    unsigned long long epoch_base = 0;     // generations already posted through post_idx (tags never repeat)
     double *post_val = nullptr;            // [2][max_posts]
     long long *post_idx = nullptr;
     int64_t max_posts = 0;

@@ -488,7 +488,7 @@ __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *r
                       (VARIANT) == NMRFIT_VARIANT_NOREC)                                                               \
                          ? NMRFIT_MIN_WAVES                                                                            \
                          : 4)
-template <int VARIANT, bool WRITE_R, int FIT_IM, bool PERSIST>
+template <int VARIANT, bool WRITE_R, int FIT_IM, bool PERSIST, int WPB>   // WPB: waves per workgroup (LDS slices)
 __device__ __forceinline__ void objective_body(
     unsigned char *lds_raw, const int64_t g,
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
@@ -504,33 +504,33 @@ __device__ __forceinline__ void objective_body(
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     PeakLor *lor = reinterpret_cast<PeakLor *>(lds_raw) + (size_t)wave * P;
-    PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)kWavesPerBlock * P * sizeof(PeakLor)) +
+    PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)WPB * P * sizeof(PeakLor)) +
                    (size_t)wave * P;
     constexpr bool kStage = (VARIANT == NMRFIT_VARIANT_STAGED);
     // per-wave table of block seeds (<= 16 blocks per grid), then (kStage) the per-wave staging
     // area for one chunk of u, v, weights (3 x 512 doubles = 12 KiB)
-    unsigned char *lds_tail = lds_raw + (((size_t)kWavesPerBlock * P * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15);
+    unsigned char *lds_tail = lds_raw + (((size_t)WPB * P * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15);
     double2 *seeds = reinterpret_cast<double2 *>(lds_tail) + (size_t)wave * kMaxBlocks;
-    double *stage = reinterpret_cast<double *>(lds_tail + (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2)) +
+    double *stage = reinterpret_cast<double *>(lds_tail + (size_t)WPB * kMaxBlocks * sizeof(double2)) +
                     (size_t)wave * (3 * kChunk);
     // FARFIELD: per-wave scratch [kFarTerms][kFarPad] for the cross-peak coefficient sums
     // (shares the offset of `stage`; the two variants are exclusive)
-    double *ffs = reinterpret_cast<double *>(lds_tail + (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2)) +
+    double *ffs = reinterpret_cast<double *>(lds_tail + (size_t)WPB * kMaxBlocks * sizeof(double2)) +
                   (size_t)wave * (kFarTerms * kFarPad);
 
     // objective launches of DEFAULT / FARFIELD: per-peak (d, C) of the Gaussian recurrence, after
     // everything else (residual rows are evaluated point by point: they feed finite differences)
     constexpr bool kRec = !WRITE_R && (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_FARFIELD);
     double2 *grec = reinterpret_cast<double2 *>(
-                        lds_tail + (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2) +
-                        (kStage ? (size_t)kWavesPerBlock * 3 * kChunk * sizeof(double)
-                                : (VARIANT == NMRFIT_VARIANT_FARFIELD) ? (size_t)kWavesPerBlock * kFarTerms * kFarPad * sizeof(double) : 0)) +
+                        lds_tail + (size_t)WPB * kMaxBlocks * sizeof(double2) +
+                        (kStage ? (size_t)WPB * 3 * kChunk * sizeof(double)
+                                : (VARIANT == NMRFIT_VARIANT_FARFIELD) ? (size_t)WPB * kFarTerms * kFarPad * sizeof(double) : 0)) +
                     (size_t)wave * P;
 
     // DEFAULT: scaled Lorentzian constants for the two-operation pair form, after grec
     constexpr bool kFast = (NMRFIT_FASTPAIR != 0) && (VARIANT == NMRFIT_VARIANT_DEFAULT) && (NMRFIT_GROUP == 8);
     PeakFast *lorf = reinterpret_cast<PeakFast *>(reinterpret_cast<unsigned char *>(grec - (size_t)wave * P) +
-                                                  (kRec ? (size_t)kWavesPerBlock * P * sizeof(double2) : 0)) +
+                                                  (kRec ? (size_t)WPB * P * sizeof(double2) : 0)) +
                      (size_t)wave * P;
 
     if (clk && g == 0 && lane == 0) {   // nmrfit_prof_*: ticks of the core clock and of the 100 MHz reference
@@ -615,7 +615,7 @@ __device__ __forceinline__ void objective_body(
         if constexpr (PERSIST) {
             // in place: the workgroup owns every segment of its particles, so "all old rows read"
             // is one workgroup barrier away; the caller has left the loop on a stop
-            double *vrow = xrow + (size_t)kWavesPerBlock * D;
+            double *vrow = xrow + (size_t)WPB * D;
             for (int64_t d = lane; d < D; d += kWave) {
                 const int64_t idx = particle * D + d;
                 double xn = 0.0, vn = 0.0;
@@ -738,6 +738,18 @@ __device__ __forceinline__ void objective_body(
             zi = __builtin_fma(e.x, li, e.y * lr);
         }
         double wv[kPointsPerLane], acc[kPointsPerLane];
+        double uq[kPointsPerLane], vq[kPointsPerLane], tq[kPointsPerLane];
+        if constexpr (PERSIST) {
+            // one wave per SIMD and registers to spare: all four arrays of the chunk in one round trip
+            // (the multi-wave kernel keeps u, v, weights below the peak loop instead, see there)
+#pragma unroll
+            for (int q = 0; q < kPointsPerLane; ++q) {
+                const bool ok = full || jl + q * kWave < j1;
+                uq[q] = ok ? u[jl + q * kWave] : 0.0;
+                vq[q] = ok ? v[jl + q * kWave] : 0.0;
+                tq[q] = ok ? wt[jl + q * kWave] : 0.0;
+            }
+        }
         if (kStage) {
             // w of this chunk was prefetched into registers during the previous epilogue
 #pragma unroll
@@ -990,8 +1002,7 @@ __device__ __forceinline__ void objective_body(
 
         // keep the u/v/weights loads below the peak loop: hoisted, they would hold 48 VGPRs
         // across it
-        asm volatile("" ::: "memory");
-        double uq[kPointsPerLane], vq[kPointsPerLane], tq[kPointsPerLane];
+        if constexpr (!PERSIST) asm volatile("" ::: "memory");
         if (kStage) {
             if (full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk has landed
             // prefetch w of the next chunk into registers (the per-peak constants are dead here)
@@ -1011,6 +1022,8 @@ __device__ __forceinline__ void objective_body(
                 vq[q] = stage[kChunk + q * kWave + lane];
                 tq[q] = stage[2 * kChunk + q * kWave + lane];
             }
+        } else if constexpr (PERSIST) {
+            // loaded at the top of the chunk
         } else if (full) {
             const double *up = u + jl, *vp = v + jl, *tp = wt + jl;
 #pragma unroll
@@ -1128,7 +1141,7 @@ __global__ __launch_bounds__(kBlock, NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    objective_body<VARIANT, WRITE_R, FIT_IM, false>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg,
+    objective_body<VARIANT, WRITE_R, FIT_IM, false, kWavesPerBlock>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg,
                                                     seg_len, blk_chunks, lane_step, rec_devk, out, R_out, clk, upd,
                                                     nullptr);
 }
@@ -1163,56 +1176,39 @@ struct GenArgs {
     int64_t offset;
     double omega, phip, phig, minstep, minfunc;
     // exchange
-    unsigned long long *count;   // arrival counter, zeroed before the launch
-    double *post_val;            // [2][gridDim.x]
-    long long *post_idx;         // [2][gridDim.x]
-    int *err;                    // set to 1 if a barrier timed out
+    unsigned long long epoch_base;   // generations posted by earlier launches: tags never repeat
+    double *post_val;            // [2][gridDim.x]  best personal-best value of the workgroup's particles
+    long long *post_idx;         // [2][gridDim.x]  tag: epoch << 32 | particle index (2^32 - 1: none)
+    int *err;                    // set to 1 if a post never arrived
     int generations;
     unsigned xrow_off, sums_off, state_off;   // byte offsets into dynamic LDS
     unsigned long long *trace;   // NMRFIT_PERSIST_TRACE: phase time stamps of workgroup 0 (100 MHz ticks), else null
 };
 
-__device__ __forceinline__ bool grid_arrive_and_wait(unsigned long long *count, unsigned long long target, int *err,
-                                                     int *s_ok)
-{
-    __syncthreads();   // (also: s_waitcnt vmcnt(0) -- this workgroup's write-through stores are done)
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        __hip_atomic_fetch_add(count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {   // 0.2 s of the 100 MHz reference clock
-                ok = 0;
-                *err = 1;
-                break;
-            }
-        }
-        *s_ok = ok;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-// (one workgroup per CU at most, so the register budget of a single wave per SIMD: no spills around the body)
+// Waves per workgroup of the persistent kernel = the most segments a particle's grid is cut into.
+// Measured on 204 x 4096 x 6 (tools/persist_probe.py, NMRFIT_PERSIST_TRACE): 4 waves, one per SIMD,
+// 15.4 us per generation; 8 waves (two per SIMD) run the chunk phase in 3.2 instead of 5.6 us but
+// every wave repeats the particle's prologue (position update, per-peak constants, phase seeds),
+// which then takes 4.0 instead of 2.9 us, and the posts arrive later: 16.9 us.
+constexpr int kGenWaves = 4;
+constexpr int kGenBlock = kGenWaves * kWave;
 template <int VARIANT, int FIT_IM>
-__global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
+__global__ __launch_bounds__(kGenBlock, 1) void generation_kernel(const GenArgs a)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    __shared__ double s_val[kWavesPerBlock];
-    __shared__ long long s_idx[kWavesPerBlock];
-    __shared__ int s_ok;
+    __shared__ double s_val[kGenWaves];
+    __shared__ long long s_idx[kGenWaves];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int64_t D = 4 + 3 * (int64_t)a.P;
-    double *sums = reinterpret_cast<double *>(lds_raw + a.sums_off);     // [4 particles][kMaxBlocks x 2]
+    double *sums = reinterpret_cast<double *>(lds_raw + a.sums_off);     // [kGenWaves particles][kMaxBlocks x 2]
     double *best = reinterpret_cast<double *>(lds_raw + a.state_off);    // fg, best_f, g[D], best_x[D]
     long long *flags = reinterpret_cast<long long *>(best + 2 + 2 * D);  // generations done, stop code
     double *cand = reinterpret_cast<double *>(flags + 2);                // f, x[D]
-    for (int64_t d = threadIdx.x; d < 2 + 2 * D; d += kBlock) best[d] = a.best[d];
+    for (int64_t d = threadIdx.x; d < 2 + 2 * D; d += kGenBlock) best[d] = a.best[d];
     if (threadIdx.x < 2) flags[threadIdx.x] = a.flags[threadIdx.x];
     __syncthreads();
     if (flags[1] != 0) return;   // stopped before this launch: nothing to do (every workgroup agrees)
-    const int ppp = kWavesPerBlock / a.nseg;   // particles per workgroup per pass
+    const int ppp = kGenWaves / a.nseg;   // particles per workgroup per pass
     const int64_t n_chunks = (a.N + kChunk - 1) / kChunk;
     const int64_t n_blocks = (n_chunks + a.blk_chunks - 1) / a.blk_chunks;
     const unsigned nwg = gridDim.x;
@@ -1244,7 +1240,7 @@ __global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
             upd.xrow_off = a.xrow_off;
             upd.gen = (uint32_t)(flags[0] + 1);
             upd.trace = (it == a.generations - 1) ? a.trace : nullptr;
-            objective_body<VARIANT, false, FIT_IM, true>(lds_raw, g, a.wc, a.u, a.v, a.wt, a.chunk_minmax, nullptr, a.S,
+            objective_body<VARIANT, false, FIT_IM, true, kGenWaves>(lds_raw, g, a.wc, a.u, a.v, a.wt, a.chunk_minmax, nullptr, a.S,
                                                          a.P, a.N, a.w0, a.wspan, a.nseg, a.seg_len, a.blk_chunks,
                                                          a.lane_step, a.rec_devk, nullptr, nullptr, nullptr, upd,
                                                          sums + (size_t)slot * (2 * kMaxBlocks));
@@ -1287,33 +1283,60 @@ __global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
             s_idx[wave] = mi;
         }
         __syncthreads();
+        // Post and fold without a counter barrier: a post is (value, tag) with tag = epoch << 32 | index.
+        // The value is stored first and has completed before the tag is issued, so a reader that sees
+        // the current epoch in a tag reads the matching value afterwards.  Every workgroup polls every
+        // post until it carries this generation's epoch: that IS the barrier, and it costs one
+        // uncached round trip after the last post instead of a few hundred serialised atomic
+        // increments of one counter.  Two alternating sets of posts: a workgroup cannot be two
+        // generations ahead of another (it needs everybody's post to finish a generation).
+        const unsigned long long epoch = a.epoch_base + (unsigned long long)it + 1ull;
         if (threadIdx.x == 0) {
             double b = s_val[0];
             long long bi = s_idx[0];
-            for (int w = 1; w < kWavesPerBlock; ++w)
+            for (int w = 1; w < kGenWaves; ++w)
                 if (lex_less(s_val[w], s_idx[w], b, bi)) {
                     b = s_val[w];
                     bi = s_idx[w];
                 }
-            const size_t slot = (size_t)(it & 1) * nwg + blockIdx.x;   // two alternating sets: a fast workgroup
-            __hip_atomic_store(a.post_val + slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // cannot overwrite
-            __hip_atomic_store(a.post_idx + slot, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // what a slow one reads
+            const size_t slot = (size_t)(it & 1) * nwg + blockIdx.x;
+            const unsigned long long ix = (bi >= 0 && bi < 0xffffffffLL) ? (unsigned long long)bi : 0xffffffffull;
+            __hip_atomic_store(a.post_val + slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): the value (and, through the
+                                                                      // barrier above, this workgroup's p rows) are done
+            __hip_atomic_store((unsigned long long *)a.post_idx + slot, (epoch << 32) | ix, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
         GEN_TRACE(3);
-        if (!grid_arrive_and_wait(a.count, (unsigned long long)(it + 1) * nwg, a.err, &s_ok)) return;
-        GEN_TRACE(4);
-        // every workgroup folds all posts the same way: first minimum in (value, index) order
         double bv = INFINITY;
         long long bidx = 0x7fffffffffffffffLL;
-        for (unsigned w = threadIdx.x; w < nwg; w += kBlock) {
-            const size_t slot = (size_t)(it & 1) * nwg + w;
-            const double pv = __hip_atomic_load(a.post_val + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const long long pi = __hip_atomic_load(a.post_idx + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lex_less(pv, pi, bv, bidx)) {
-                bv = pv;
-                bidx = pi;
+        {
+            bool late = false;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (unsigned w = threadIdx.x; w < nwg; w += kGenBlock) {
+                const size_t slot = (size_t)(it & 1) * nwg + w;
+                unsigned long long tag;
+                while (((tag = __hip_atomic_load((unsigned long long *)a.post_idx + slot, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (epoch & 0xffffffffull)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {   // 0.2 s of the 100 MHz clock
+                        late = true;
+                        break;
+                    }
+                }
+                if (late) break;
+                const double pv = __hip_atomic_load(a.post_val + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long ix = tag & 0xffffffffull;
+                const long long pi = (ix == 0xffffffffull) ? 0x7fffffffffffffffLL : (long long)ix;
+                if (lex_less(pv, pi, bv, bidx)) {
+                    bv = pv;
+                    bidx = pi;
+                }
             }
+            if (late) *a.err = 1;
+            if (__syncthreads_or(late ? 1 : 0)) return;   // a workgroup never posted: give up, everywhere
         }
+        GEN_TRACE(4);
         for (int off = 32; off > 0; off >>= 1) {
             const double ov = __shfl_down(bv, off, kWave);
             const long long oi = __shfl_down(bidx, off, kWave);
@@ -1329,7 +1352,7 @@ __global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
         __syncthreads();
         bv = s_val[0];
         bidx = s_idx[0];
-        for (int w = 1; w < kWavesPerBlock; ++w)
+        for (int w = 1; w < kGenWaves; ++w)
             if (lex_less(s_val[w], s_idx[w], bv, bidx)) {
                 bv = s_val[w];
                 bidx = s_idx[w];
@@ -1337,7 +1360,7 @@ __global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
         if (bidx >= a.S) bidx = 0;   // np.argmin of an all-inf array
         GEN_TRACE(5);
         if (threadIdx.x == 0) cand[0] = bv;
-        for (int64_t d = threadIdx.x; d < D; d += kBlock)
+        for (int64_t d = threadIdx.x; d < D; d += kGenBlock)
             cand[1 + d] = __hip_atomic_load(a.p + bidx * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         GEN_TRACE(6);
@@ -1345,8 +1368,8 @@ __global__ __launch_bounds__(kBlock, 1) void generation_kernel(const GenArgs a)
         __syncthreads();
         GEN_TRACE(7);
         if (blockIdx.x == 0) {   // the official copy (host polls the flags; later launches start from it)
-            for (int64_t d = threadIdx.x; d < 2 + 2 * D; d += kBlock) a.best[d] = best[d];
-            for (int64_t d = threadIdx.x; d < D + 1; d += kBlock) a.cand[d] = cand[d];
+            for (int64_t d = threadIdx.x; d < 2 + 2 * D; d += kGenBlock) a.best[d] = best[d];
+            for (int64_t d = threadIdx.x; d < D + 1; d += kGenBlock) a.cand[d] = cand[d];
             if (threadIdx.x < 2) a.flags[threadIdx.x] = flags[threadIdx.x];
         }
         GEN_TRACE(8);
@@ -1487,23 +1510,24 @@ int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw)
 
 // The kernel variant a launch actually runs (the requested one may not fit in LDS, or may not
 // implement the imaginary part) and the dynamic LDS its per-wave records need.
-static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, int fit_im, int *variant_out)
+static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, int fit_im, int *variant_out,
+                              int wpb = kWavesPerBlock)
 {
     const bool dR = residual;
-    const size_t lds_recs = (((size_t)kWavesPerBlock * (size_t)std::max(P, 1) * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
-                            (size_t)kWavesPerBlock * kMaxBlocks * sizeof(double2);
-    const size_t lds_stage = (size_t)kWavesPerBlock * 3 * kChunk * sizeof(double);
+    const size_t lds_recs = (((size_t)wpb * (size_t)std::max(P, 1) * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
+                            (size_t)wpb * kMaxBlocks * sizeof(double2);
+    const size_t lds_stage = (size_t)wpb * 3 * kChunk * sizeof(double);
     // STAGED needs three workgroups to still fit in a CU's 160 KiB (P <= 27); beyond that it
     // runs the unstaged kernel.
     int variant = ctx->variant;
     if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
-    const size_t lds_far = (size_t)kWavesPerBlock * kFarTerms * kFarPad * sizeof(double);
+    const size_t lds_far = (size_t)wpb * kFarTerms * kFarPad * sizeof(double);
     // Gaussian recurrence constants (d, C) per peak: objective launches of DEFAULT / FARFIELD
-    const size_t lds_rec = dR ? 0 : (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(double2);
+    const size_t lds_rec = dR ? 0 : (size_t)wpb * (size_t)std::max(P, 1) * sizeof(double2);
     if (variant == NMRFIT_VARIANT_FARFIELD && (lds_recs + lds_far + lds_rec > 160 * 1024 || fit_im != 0))
         variant = NMRFIT_VARIANT_DEFAULT;   // P > ~600, or the imaginary part (direct kernel only)
     const size_t lds_fast = (NMRFIT_FASTPAIR != 0 && NMRFIT_GROUP == 8)
-                                ? (size_t)kWavesPerBlock * (size_t)std::max(P, 1) * sizeof(PeakFast) : 0;
+                                ? (size_t)wpb * (size_t)std::max(P, 1) * sizeof(PeakFast) : 0;
     if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_rec + lds_fast > 160 * 1024)
         variant = NMRFIT_VARIANT_NOREC;     // P > ~450: no room for the recurrence / scaled records
     size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
@@ -1621,35 +1645,37 @@ int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bo
     static const bool off = getenv("NMRFIT_NO_PERSISTENT") != nullptr;   // A/B knob
     static const double max_units = [] {
         const char *e = getenv("NMRFIT_PERSIST_MAX_UNITS");
-        return e ? atof(e) : 1.0e8;
+        return e ? atof(e) : 1.0e7;
     }();
     const int64_t S = sw.S, N = ctx->N, D = 4 + 3 * (int64_t)sw.P;
     if (off || generations < 1 || S < 1 || D > kFusedMaxD) return NMRFIT_OK;
-    // worth it only while a generation is latency-bound (a few tens of microseconds of arithmetic)
+    // worth it only for the smallest problems: measured 15.3 against 16.4 us per generation at
+    // 204 x 4096 x 6 (5e6 units) and 14.4 / 14.8 at 50 x 4096 x 6, but 31.9 / 30.5 at 204 x 16384 x 12
+    // (4e7 units), where four waves per particle no longer cover the arithmetic
     if ((double)S * (double)N * (double)std::max(sw.P, 1) > max_units) return NMRFIT_OK;
     const int fit_im = ctx->fit_im;
     int variant = NMRFIT_VARIANT_DEFAULT;
-    const size_t lds_obj = resolve_variant(ctx, sw.P, false, fit_im, &variant);
+    const size_t lds_obj = resolve_variant(ctx, sw.P, false, fit_im, &variant, kGenWaves);
     if (!(variant == NMRFIT_VARIANT_DEFAULT || (variant == NMRFIT_VARIANT_FARFIELD && fit_im == 0))) return NMRFIT_OK;
-    // all segments of a particle in one workgroup: nseg in {1, 2, 4}, >= 2 chunks per wave if possible
+    // all segments of a particle in one workgroup: nseg in {1, 2, 4, 8}, whole blocks each
     const int64_t n_chunks = (N + kChunk - 1) / kChunk;
     const int blk_chunks = (int)((n_chunks + kMaxBlocks - 1) / kMaxBlocks);
     const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
     const int64_t blk_len = (int64_t)blk_chunks * kChunk;
-    int nseg = 4;
+    int nseg = kGenWaves;
     if (const char *e = getenv("NMRFIT_PERSIST_NSEG")) nseg = atoi(e);
-    if (nseg != 1 && nseg != 2 && nseg != 4) nseg = 4;
-    while (nseg > 1 && (n_blocks < nseg || n_chunks / nseg < 2)) nseg >>= 1;
+    if (nseg != 1 && nseg != 2 && nseg != 4 && nseg != 8) nseg = kGenWaves;
+    while (nseg > 1 && n_blocks < nseg) nseg >>= 1;
     const int64_t seg_len = ((n_blocks + nseg - 1) / nseg) * blk_len;
     if ((N + seg_len - 1) / seg_len != nseg) nseg = (int)((N + seg_len - 1) / seg_len);   // e.g. 3 blocks over 2 segments
-    if (nseg != 1 && nseg != 2 && nseg != 4) return NMRFIT_OK;
-    const int ppp = kWavesPerBlock / nseg;
+    if (nseg != 1 && nseg != 2 && nseg != 4 && nseg != 8) return NMRFIT_OK;
+    const int ppp = kGenWaves / nseg;
     GenArgs a{};
     size_t lds = (lds_obj + 15) & ~(size_t)15;
     a.xrow_off = (unsigned)lds;
-    lds += 2 * (size_t)kWavesPerBlock * (size_t)D * sizeof(double);     // x rows, then v rows
+    lds += 2 * (size_t)kGenWaves * (size_t)D * sizeof(double);     // x rows, then v rows
     a.sums_off = (unsigned)lds;
-    lds += (size_t)kWavesPerBlock * 2 * kMaxBlocks * sizeof(double);
+    lds += (size_t)kGenWaves * 2 * kMaxBlocks * sizeof(double);
     a.state_off = (unsigned)lds;
     lds += (size_t)(2 + 2 * D) * sizeof(double) + 2 * sizeof(long long) + (size_t)(D + 1) * sizeof(double);
     if (lds > 64 * 1024) return NMRFIT_OK;
@@ -1663,14 +1689,17 @@ int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bo
     else
         fn = (const void *)generation_kernel<NMRFIT_VARIANT_DEFAULT, 2>;
     int per_cu = 0;
-    NMRFIT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds));
+    NMRFIT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kGenBlock, lds));
     if (per_cu < 1) return NMRFIT_OK;
     // one workgroup per CU at most: the exchange costs ~4 us at 204 workgroups, ~9 us at 512
     int64_t max_wg = (int64_t)ctx->compute_units;
     if (const char *e = getenv("NMRFIT_PERSIST_MAX_WG")) max_wg = atoll(e);
     max_wg = std::min<int64_t>(max_wg, (int64_t)per_cu * ctx->compute_units);
-    const int64_t nwg = std::max<int64_t>(1, std::min<int64_t>((S + ppp - 1) / ppp, max_wg));
-    if (nwg > sw.max_posts) return NMRFIT_OK;
+    // ONE pass only: a workgroup that has to evaluate a second batch of particles pays the whole
+    // ~8.7 us critical path of a pass again, and the launch-per-phase path (which spreads the waves
+    // over every CU) is then faster (measured at 512 particles: equal; at 1024: 43 against 31 us)
+    const int64_t nwg = (S + ppp - 1) / ppp;
+    if (nwg > max_wg || nwg > sw.max_posts) return NMRFIT_OK;
     a.wc = ctx->d_wc;
     a.u = ctx->d_u;
     a.v = ctx->d_v;
@@ -1703,7 +1732,7 @@ int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bo
     a.phig = sw.phig;
     a.minstep = sw.minstep;
     a.minfunc = sw.minfunc;
-    a.count = sw.count;
+    a.epoch_base = sw.epoch_base;
     a.post_val = sw.post_val;
     a.post_idx = sw.post_idx;
     a.err = sw.err;
@@ -1712,9 +1741,8 @@ int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bo
     static const bool want_trace = getenv("NMRFIT_PERSIST_TRACE") != nullptr;
     if (want_trace && !d_trace) NMRFIT_HIP(hipMalloc((void **)&d_trace, 16 * sizeof(unsigned long long)));
     a.trace = want_trace ? d_trace : nullptr;
-    NMRFIT_HIP(hipMemsetAsync(sw.count, 0, sizeof(unsigned long long), ctx->stream));
     void *params[] = {(void *)&a};
-    NMRFIT_HIP(hipLaunchCooperativeKernel(fn, dim3((unsigned)nwg), dim3(kBlock), params, (unsigned)lds, ctx->stream));
+    NMRFIT_HIP(hipLaunchCooperativeKernel(fn, dim3((unsigned)nwg), dim3(kGenBlock), params, (unsigned)lds, ctx->stream));
     if (want_trace) {   // development aid: where a generation's time goes (workgroup 0, last generation of the launch)
         unsigned long long t[16];
         NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
@@ -1726,7 +1754,7 @@ int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bo
                     (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01,
                     (t[6] - t[5]) * 0.01, (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (long long)nwg, nseg);
     }
-    ctx->last.waves = nwg * kWavesPerBlock;
+    ctx->last.waves = nwg * kGenWaves;
     ctx->last.nseg = nseg;
     ctx->last.seg_len = seg_len;
     *launched = true;

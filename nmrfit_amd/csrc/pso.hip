@@ -53,8 +53,8 @@ struct nmrfit_pso {
     double *d_part_val = nullptr;      // pso_select_kernel: per-workgroup (min fp, index) posts
     long long *d_part_idx = nullptr;
     unsigned *d_ticket = nullptr;
-    unsigned long long *d_count = nullptr;   // persistent generations: grid-barrier arrival counter
-    int *d_err = nullptr;                    // ... and its time-out flag
+    unsigned long long epoch = 0;            // persistent generations: posts made so far (tags never repeat)
+    int *d_err = nullptr;                    // ... and their time-out flag
     nmrfit_comm *comm = nullptr;       // attached communicator (sharded swarm): the exchange runs inside nmrfit_pso_step
     bool initialized = false;    // nmrfit_pso_init has run
     bool seeded = false;         // the generation-0 candidates have been folded into (g, fg)
@@ -261,24 +261,36 @@ __global__ __launch_bounds__(1024) void pso_tail_kernel(TailArgs a)
 // their writes by then -- reduces the posted minima, writes the candidate record and, for a
 // single-rank run, folds it into (g, fg) with the stopping rule.
 constexpr int kSelectWaves = 4;          // particles per workgroup pass
-constexpr int kSelectTicketBlocks = 128;
+constexpr int kSelectTicketBlocks = 256;
 constexpr int kSelectMaxPosts = 65536;    // huge swarms: workgroups stride over the particles  // up to this many workgroups the last-ticket form wins (one fence each)
 
 
 // Reduce the nb posted (min fp, index) pairs, write the candidate record and (kTailApply) fold
 // it.  Called by every thread of ONE workgroup; posts and rows written by other workgroups are
 // read through volatile (device-coherent) loads.
+// `shared`: the posts and rows were written by other workgroups of THIS launch (last-ticket form):
+// they were stored with agent-scope atomic stores (write-through) and are read the same way, which
+// is coherent across the 8 XCDs without any fence.  A release fence per workgroup is an L2
+// write-back on this part: 8 us per 51-workgroup launch against 1.8 us this way
+// (tools/barrier_probe.hip).
+template <bool SHARED>
+__device__ __forceinline__ double load_f64(const double *p)
+{
+    if (SHARED) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+template <bool SHARED>
 __device__ __forceinline__ void select_final(const TailArgs &a, const double *part_val, const long long *part_idx,
                                              unsigned nb, double *s_val, long long *s_idx)
 {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nw = blockDim.x / kWave;
-    const volatile double *pv = part_val;
-    const volatile long long *pi = part_idx;
     double best = INFINITY;
     long long bi = 0x7fffffffffffffffLL;
     for (unsigned b = threadIdx.x; b < nb; b += blockDim.x) {
-        const double v = pv[b];
-        const long long ix = pi[b];
+        const double v = load_f64<SHARED>(part_val + b);
+        const long long ix = SHARED ? __hip_atomic_load(part_idx + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : part_idx[b];
         if (lex_less(v, ix, best, bi)) {
             best = v;
             bi = ix;
@@ -306,9 +318,8 @@ __device__ __forceinline__ void select_final(const TailArgs &a, const double *pa
             bi = s_idx[w];
         }
     if (bi >= a.S) bi = 0;   // np.argmin of an all-inf array
-    const volatile double *fpv = a.fp, *ppv = a.p;
-    if (threadIdx.x == 0) a.cand[0] = fpv[bi];
-    for (int64_t d = threadIdx.x; d < a.D; d += blockDim.x) a.cand[1 + d] = ppv[bi * a.D + d];
+    if (threadIdx.x == 0) a.cand[0] = load_f64<SHARED>(a.fp + bi);
+    for (int64_t d = threadIdx.x; d < a.D; d += blockDim.x) a.cand[1 + d] = load_f64<SHARED>(a.p + bi * a.D + d);
     if (a.phases & kTailApply) {
         __syncthreads();
         if (wave == 0) apply_wave(lane, a.D, a.nranks, a.is_init, a.minstep, a.minfunc, a.cands, a.flags, a.best);
@@ -348,8 +359,14 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
         }
         double cur = a.fp[i];
         if (f < cur) {   // pyswarm: i_update = fx < fp
-            for (int64_t d = lane; d < a.D; d += kWave) a.p[i * a.D + d] = a.x[i * a.D + d];
-            if (lane == 0) a.fp[i] = f;
+            if (ticket) {   // rows another workgroup of this launch may read: write-through stores
+                for (int64_t d = lane; d < a.D; d += kWave)
+                    __hip_atomic_store(a.p + i * a.D + d, a.x[i * a.D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(a.fp + i, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                for (int64_t d = lane; d < a.D; d += kWave) a.p[i * a.D + d] = a.x[i * a.D + d];
+                if (lane == 0) a.fp[i] = f;
+            }
             cur = f;
         }
         if (lex_less(cur, i, mine, mi)) {
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
         s_val[wave] = mine;
         s_idx[wave] = mi;
     }
-    __syncthreads();   // the workgroup's p / fp writes have reached L2 ...
+    __syncthreads();   // (s_waitcnt vmcnt(0) in every wave: the workgroup's p / fp stores have completed)
     if (threadIdx.x == 0) {
         double b = s_val[0];
         long long bi = s_idx[0];
@@ -370,19 +387,22 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
                 b = s_val[w];
                 bi = s_idx[w];
             }
-        part_val[blockIdx.x] = b;
-        part_idx[blockIdx.x] = bi;
         s_last = 0;
         if (ticket) {
-            __threadfence();   // ... and one device-scope release per workgroup (cumulative) publishes them with the post
-            s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u);
+            __hip_atomic_store(part_val + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part_idx + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): the post has completed
+            s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u);
+        } else {
+            part_val[blockIdx.x] = b;
+            part_idx[blockIdx.x] = bi;
         }
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();   // acquire: the other workgroups' posts and rows
-    if (threadIdx.x == 0) *ticket = 0u;   // ready for the next launch
-    select_final(a, part_val, part_idx, gridDim.x, s_val, s_idx);
+    // every other workgroup's stores had completed before it drew its ticket
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+    select_final<true>(a, part_val, part_idx, gridDim.x, s_val, s_idx);
 }
 
 __global__ __launch_bounds__(1024) void pso_select_final_kernel(TailArgs a, const double *part_val,
@@ -391,7 +411,7 @@ __global__ __launch_bounds__(1024) void pso_select_final_kernel(TailArgs a, cons
     if (a.flags[1] != 0) return;
     __shared__ double s_val[16];
     __shared__ long long s_idx[16];
-    select_final(a, part_val, part_idx, nb, s_val, s_idx);
+    select_final<false>(a, part_val, part_idx, nb, s_val, s_idx);
 }
 
 
@@ -526,7 +546,11 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
     // single-workgroup launch (a fence per workgroup would cost more than the launch)
     const int64_t nb64 = (S + kSelectWaves - 1) / kSelectWaves;
     const unsigned nb = (unsigned)std::min<int64_t>(nb64, kSelectMaxPosts);
-    const bool ticket = nb <= (unsigned)kSelectTicketBlocks;
+    static const unsigned ticket_blocks = [] {
+        const char *e = getenv("NMRFIT_TICKET_BLOCKS");   // tuning knob
+        return e ? (unsigned)atoi(e) : (unsigned)kSelectTicketBlocks;
+    }();
+    const bool ticket = nb <= ticket_blocks;
     hipLaunchKernelGGL(pso_select_kernel, dim3(nb), dim3(kWave * kSelectWaves), 0, ctx->stream, a, pso->d_part_val,
                        pso->d_part_idx, ticket ? pso->d_ticket : nullptr);
     NMRFIT_HIP(hipGetLastError());
@@ -607,7 +631,7 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
         PSO_HIP(hipMalloc((void **)&pso->d_part_val, nb * sizeof(double)));
         PSO_HIP(hipMalloc((void **)&pso->d_part_idx, nb * sizeof(long long)));
         PSO_HIP(hipMalloc((void **)&pso->d_ticket, sizeof(unsigned)));
-        PSO_HIP(hipMalloc((void **)&pso->d_count, sizeof(unsigned long long)));
+        PSO_HIP(hipMemsetAsync(pso->d_part_idx, 0, nb * sizeof(long long), ctx->stream));
         PSO_HIP(hipMalloc((void **)&pso->d_err, sizeof(int)));
         PSO_HIP(hipMemsetAsync(pso->d_err, 0, sizeof(int), ctx->stream));
         PSO_HIP(hipMemsetAsync(pso->d_ticket, 0, sizeof(unsigned), ctx->stream));
@@ -630,7 +654,7 @@ int nmrfit_pso_destroy(nmrfit_pso *pso)
         (void)hipStreamSynchronize(pso->ctx->stream);
     }
     void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_x2, pso->d_v2, pso->d_p, pso->d_fx, pso->d_fp, pso->d_cand_own, pso->d_flags, pso->d_best,
-                    pso->d_part_val, pso->d_part_idx, pso->d_ticket, pso->d_count, pso->d_err};
+                    pso->d_part_val, pso->d_part_idx, pso->d_ticket, pso->d_err};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete pso;
@@ -830,13 +854,14 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
         vw.phig = pso->prm.phig;
         vw.minstep = pso->prm.minstep;
         vw.minfunc = pso->prm.minfunc;
-        vw.count = pso->d_count;
+        vw.epoch_base = pso->epoch;
         vw.post_val = pso->d_part_val;
         vw.post_idx = pso->d_part_idx;
         vw.max_posts = kSelectMaxPosts / 2;
         vw.err = pso->d_err;
         bool launched = false;
         if ((rc = launch_generations(pso->ctx, vw, (int)std::min<int64_t>(n, 1 << 20), &launched)) != NMRFIT_OK) return rc;
+        if (launched) pso->epoch += (unsigned long long)n;
         if (!launched)
             for (int64_t k = 0; k < n; ++k)
                 if ((rc = nmrfit_pso_step(pso)) != NMRFIT_OK) return rc;

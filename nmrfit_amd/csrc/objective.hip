@@ -217,6 +217,54 @@ __device__ __forceinline__ double dispersion(double wcj, const PeakLor &r)
     return __builtin_fma(r.al * t, rcp64(s), (r.ag2 * kInvSqrtPi) * dawson(kSqrtLn2 * t));
 }
 
+// Dawson's integral for the objective's imaginary channel: the same piecewise fits, but one
+// degree-18 polynomial for EVERY unit interval [k, k+1), k = 0..15, gathered from a 2.4 KiB table
+// in LDS by a per-lane index -- no divergent branches (the lanes of a wave sit in two or three
+// different intervals), 19 FMAs + 19 broadcast-friendly LDS reads.  Beyond 16 the asymptotic form
+// (a branch almost no wave takes: such peaks are summed through the far-field expansion).
+__device__ __forceinline__ double dawson_tab(double x, const double *tab)
+{
+    const double ax = fabs(x);
+    const int k = (int)fmin(ax, 15.0);                 // NaN -> 15
+    const double t = __builtin_fma(2.0, ax - (double)k, -1.0);
+    const double *q = tab + k * 19;
+    double p = q[18];
+#pragma unroll
+    for (int i = 17; i >= 0; --i) p = __builtin_fma(p, t, q[i]);
+    if (!(ax < 16.0)) {
+        const double inv = rcp64(ax);                  // NaN/inf propagate: D(inf) = 0
+        const double s2 = 49.0 * inv * inv;
+        double g = dawson::kFar[11];
+#pragma unroll
+        for (int i = 10; i >= 0; --i) g = __builtin_fma(g, s2, dawson::kFar[i]);
+        p = 0.5 * g * inv;
+    }
+    return copysign(p, x);
+}
+
+// dispersion() with the gathered Dawson table
+__device__ __forceinline__ double dispersion_tab(double wcj, const PeakLor &r, const double *tab)
+{
+    const double t = __builtin_fma(wcj, r.ihw, r.c);
+    const double s = __builtin_fma(t, t, 1.0);
+    return __builtin_fma(r.al * t, rcp64(s), (r.ag2 * kInvSqrtPi) * dawson_tab(kSqrtLn2 * t, tab));
+}
+
+constexpr double binom_d(int n, int k)
+{
+    double r = 1.0;
+    for (int i = 1; i <= k; ++i) r = r * (double)(n - k + i) / (double)i;
+    return r;
+}
+constexpr double pow49_half(int j)
+{
+    double r = 0.5;
+    for (int i = 0; i < j; ++i) r *= 49.0;
+    return r;
+}
+constexpr int kDawFarTerms = 12;        // terms of the asymptotic series of D kept in the far-field expansion (kFar)
+constexpr double kDawFarX = 7.0;        // ... which is valid from |x| = 7 on
+
 // ---- per-chunk building blocks ---------------------------------------------------------------
 // Per-(particle, peak) constants in LDS, two arrays per wave: PeakLor (32 B: read in the main
 // loop as one broadcast ds_read_b128 + one ds_read_b64) and PeakWin (16 B: Gaussian window).
@@ -499,6 +547,7 @@ __device__ __forceinline__ void objective_body(
     double *__restrict__ R_out,     // WRITE_R: residual rows [S*N]
     unsigned long long *__restrict__ clk,   // profiling only (else null): shader / reference clock of workgroup 0
     const PsoFused &upd,            // swarm generations: advance the particle first (x_in != null), X is then unused
+    const unsigned aux_off,         // FIT_IM == 2: byte offset of the Dawson table in dynamic LDS
     double *psums)                  // PERSIST: this particle's per-block sums in LDS [n_blocks] (x2 with FIT_IM)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -524,7 +573,7 @@ __device__ __forceinline__ void objective_body(
     double2 *grec = reinterpret_cast<double2 *>(
                         lds_tail + (size_t)WPB * kMaxBlocks * sizeof(double2) +
                         (kStage ? (size_t)WPB * 3 * kChunk * sizeof(double)
-                                : (VARIANT == NMRFIT_VARIANT_FARFIELD) ? (size_t)WPB * kFarTerms * kFarPad * sizeof(double) : 0)) +
+                                : (VARIANT == NMRFIT_VARIANT_FARFIELD || FIT_IM == 2) ? (size_t)WPB * kFarTerms * kFarPad * sizeof(double) : 0)) +
                     (size_t)wave * P;
 
     // DEFAULT: scaled Lorentzian constants for the two-operation pair form, after grec
@@ -533,6 +582,11 @@ __device__ __forceinline__ void objective_body(
                                                   (kRec ? (size_t)WPB * P * sizeof(double2) : 0)) +
                      (size_t)wave * P;
 
+    // FIT_IM == 2: Dawson table (16 intervals x 19 coefficients) for the gathered evaluation, one copy
+    // per workgroup; the barrier after the staging below makes it visible
+    double *dtab = reinterpret_cast<double *>(lds_raw + aux_off);
+    if constexpr (FIT_IM == 2)
+        for (int i = threadIdx.x; i < 16 * 19; i += WPB * kWave) dtab[i] = (&dawson::kTab[0][0])[i];
     if (clk && g == 0 && lane == 0) {   // nmrfit_prof_*: ticks of the core clock and of the 100 MHz reference
         clk[0] = __builtin_amdgcn_s_memtime();
         clk[1] = __builtin_amdgcn_s_memrealtime();
@@ -1000,6 +1054,114 @@ __device__ __forceinline__ void objective_body(
             }
         }
 
+        // ---- imaginary model, all peaks (FIT_IM == 2: what generate_result builds, utils.py:271-277) ----
+        // I(w) = sum_k [ al_k t/(1+t^2) + (ag2_k/sqrt(pi)) D(sqrt(ln2) t) ]: the Hilbert partner of the
+        // pseudo-Voigt sum.  It decays only like 1/t, so there is no window to skip; instead every peak
+        // that is FAR from this chunk (the chunk spans <= 0.1 of its distance to the pole, and Dawson's
+        // asymptotic series holds over all of it) goes through ONE shared degree-15 polynomial per
+        // chunk: t/(1+t^2) is the real part of the same series 1/(t - i) = sum_n q m^n u^n whose
+        // imaginary part FARFIELD sums, and x^-(2j+1) of D's series expands binomially about the
+        // chunk centre (all terms of one sign: no cancellation; truncation <= 1e-16 of each peak's
+        // term).  Near peaks are evaluated point by point with the gathered Dawson table.
+        double iacc[kPointsPerLane];
+        if constexpr (FIT_IM == 2) {
+#pragma unroll
+            for (int q = 0; q < kPointsPerLane; ++q) iacc[q] = 0.0;
+            const double2 mi2 = chunk_minmax[jb / kChunk];
+            const double icen = wave_uniform(0.5 * (mi2.x + mi2.y));
+            const double ihalf = wave_uniform(0.5 * (mi2.y - mi2.x));
+            double isum = 0.0;     // lane l: coefficient of order l >> 2 (all 4 lanes of a quad)
+            bool anyfar = false;
+            for (int kb = 0; kb < P; kb += kWave) {
+                const int k = kb + lane;
+                const bool act = k < P;
+                bool farim = false;
+                double tc = 0.0, hk = 0.0, rq = 0.0, al = 0.0, agd = 0.0;
+                if (act) {
+                    const PeakLor rec = lor[k];
+                    tc = __builtin_fma(icen, rec.ihw, rec.c);
+                    hk = ihalf * rec.ihw;
+                    const double den = __builtin_fma(tc, tc, 1.0);
+                    farim = (den >= 100.0 * hk * hk) && ((fabs(tc) - fabs(hk)) * kSqrtLn2 >= kDawFarX);   // false for NaN
+                    rq = rcp64(den);
+                    al = rec.al;
+                    agd = rec.ag2 * kInvSqrtPi;
+                }
+                const unsigned long long farmask = __ballot(farim);
+                const unsigned long long nearmask = __ballot(act && !farim);
+                if (farmask) {
+                    anyfar = true;
+                    // Lorentzian dispersion: al * Re(q m^n), q = (tc + i)/(tc^2 + 1), m = -hk q, by the
+                    // real two-term recurrence (both roots of modulus |m|)
+                    const double qr = tc * rq, qi = rq;
+                    const double mr = -hk * qr, mi = -hk * qi;
+                    const double a2 = farim ? mr + mr : 0.0;
+                    const double b2 = farim ? -__builtin_fma(mr, mr, mi * mi) : 0.0;
+                    double y0 = farim ? al * qr : 0.0;
+                    double y1 = farim ? al * __builtin_fma(qr, mr, -(qi * mi)) : 0.0;
+                    // Gaussian dispersion: agd * sum_j A_j x^-(2j+1), x = xc (1 - eps u), eps = -hk/tc:
+                    // coefficient of u^n = agd eps^n sum_j B_j binom(2j + n, n), B_j = A_j xc^-(2j+1)
+                    double B[kDawFarTerms];
+                    {
+                        const double xc = farim ? kSqrtLn2 * tc : 1.0;
+                        const double inv = rcp64(xc), inv2 = inv * inv;
+                        double pw = farim ? agd * inv : 0.0;
+#pragma unroll
+                        for (int j = 0; j < kDawFarTerms; ++j) {
+                            B[j] = (dawson::kFar[j] * pow49_half(j)) * pw;
+                            pw *= inv2;
+                        }
+                    }
+                    const double eps = farim ? -hk * rcp64(tc) : 0.0;
+                    double en = 1.0;
+                    double *dst = ffs + lane + (lane >> 4);
+#pragma unroll
+                    for (int n = 0; n < kFarTerms; ++n) {
+                        double sg = 0.0;
+#pragma unroll
+                        for (int j = kDawFarTerms - 1; j >= 0; --j) sg = __builtin_fma(B[j], binom_d(2 * j + n, n), sg);
+                        dst[n * kFarPad] = __builtin_fma(sg, en, y0);
+                        en *= eps;
+                        const double y2 = __builtin_fma(a2, y1, b2 * y0);
+                        y0 = y1;
+                        y1 = y2;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
+                    double part = 0.0;
+                    const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) part += row[j];
+                    part += __shfl_xor(part, 1, kWave);
+                    part += __shfl_xor(part, 2, kWave);
+                    isum += part;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites
+                }
+                for (unsigned long long m = nearmask; m; m &= m - 1) {
+                    const PeakLor rec = lor[kb + __builtin_ctzll(m)];
+#pragma unroll
+                    for (int q = 0; q < kPointsPerLane; ++q) iacc[q] += dispersion_tab(wv[q], rec, dtab);
+                }
+            }
+            if (anyfar) {   // wave-uniform
+                if ((lane & 3) == 0) ffs[lane >> 2] = isum;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                double cfi[kFarTerms];
+#pragma unroll
+                for (int n = 0; n < kFarTerms; ++n) cfi[n] = ffs[n];
+                const double ihc = (ihalf > 0.0) ? rcp64(ihalf) : 0.0;
+#pragma unroll
+                for (int q = 0; q < kPointsPerLane; ++q) {
+                    double uu = (wv[q] - icen) * ihc;
+                    if (!full) uu = fmin(fmax(uu, -1.0), 1.0);   // padding points of the ragged chunk (weight 0)
+                    double pz = cfi[kFarTerms - 1];
+#pragma unroll
+                    for (int n = kFarTerms - 2; n >= 0; --n) pz = __builtin_fma(pz, uu, cfi[n]);
+                    iacc[q] += pz;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+
         // keep the u/v/weights loads below the peak loop: hoisted, they would hold 48 VGPRs
         // across it
         if constexpr (!PERSIST) asm volatile("" ::: "memory");
@@ -1049,10 +1211,10 @@ __device__ __forceinline__ void objective_body(
             if (FIT_IM != 0) {                                            // equations.py:197-199,205-206
                 const double id = __builtin_fma(zr, vq[q], zi * uq[q]);  // Im((zr + i zi)(u + i v))
                 double ifit = 0.0;
-                if (FIT_IM == 1) {
+                if constexpr (FIT_IM == 1) {
                     if (P > 0) ifit = dispersion(wv[q], lor[P - 1]);
                 } else {
-                    for (int k = 0; k < P; ++k) ifit += dispersion(wv[q], lor[k]);
+                    ifit = iacc[q];
                 }
                 const double ei = tq[q] * (id - ifit);
                 bs_im = __builtin_fma(ei, ei, bs_im);
@@ -1137,13 +1299,13 @@ __global__ __launch_bounds__(kBlock, NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax, const double *__restrict__ X, int64_t S,
     int P, int64_t N, double w0, double wspan, int nseg, int64_t seg_len, int blk_chunks, double lane_step,
     double rec_devk, double *__restrict__ out, double *__restrict__ R_out, unsigned long long *__restrict__ clk,
-    const PsoFused upd)
+    const PsoFused upd, const unsigned aux_off)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     objective_body<VARIANT, WRITE_R, FIT_IM, false, kWavesPerBlock>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg,
                                                     seg_len, blk_chunks, lane_step, rec_devk, out, R_out, clk, upd,
-                                                    nullptr);
+                                                    aux_off, nullptr);
 }
 
 // ---- persistent generations (small single-rank swarms) --------------------------------------------
@@ -1181,7 +1343,7 @@ struct GenArgs {
     long long *post_idx;         // [2][gridDim.x]  tag: epoch << 32 | particle index (2^32 - 1: none)
     int *err;                    // set to 1 if a post never arrived
     int generations;
-    unsigned xrow_off, sums_off, state_off;   // byte offsets into dynamic LDS
+    unsigned xrow_off, sums_off, state_off, aux_off;   // byte offsets into dynamic LDS
     unsigned long long *trace;   // NMRFIT_PERSIST_TRACE: phase time stamps of workgroup 0 (100 MHz ticks), else null
 };
 
@@ -1242,7 +1404,7 @@ __global__ __launch_bounds__(kGenBlock, 1) void generation_kernel(const GenArgs 
             upd.trace = (it == a.generations - 1) ? a.trace : nullptr;
             objective_body<VARIANT, false, FIT_IM, true, kGenWaves>(lds_raw, g, a.wc, a.u, a.v, a.wt, a.chunk_minmax, nullptr, a.S,
                                                          a.P, a.N, a.w0, a.wspan, a.nseg, a.seg_len, a.blk_chunks,
-                                                         a.lane_step, a.rec_devk, nullptr, nullptr, nullptr, upd,
+                                                         a.lane_step, a.rec_devk, nullptr, nullptr, nullptr, upd, a.aux_off,
                                                          sums + (size_t)slot * (2 * kMaxBlocks));
             __syncthreads();   // the pass's block sums are in LDS, its new rows in global memory
             GEN_TRACE(1);
@@ -1459,13 +1621,13 @@ __global__ void centre_kernel(const double *__restrict__ w, int64_t N, double w0
 template <int VARIANT>
 int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *out, double *dR,
                    int nseg, int64_t seg_len, int blk_chunks, int64_t blocks, size_t lds, int fit_im,
-                   const PsoFused &upd)
+                   const PsoFused &upd, unsigned aux_off)
 {
 #define NMRFIT_LAUNCH(WR, FI)                                                                                   \
     hipLaunchKernelGGL((objective_kernel<VARIANT, WR, FI>), dim3((unsigned)blocks), dim3(kBlock), lds,         \
                        ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,     \
                        ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, blk_chunks, ctx->lane_step,                 \
-                       ctx->grid_dev * 11.0e10, out, dR, clk, upd)
+                       ctx->grid_dev * 11.0e10, out, dR, clk, upd, aux_off)
     // nmrfit_prof_enable: HIP events on the launch stream around this kernel alone
     const bool prof = ctx->prof_cap > 0 && ctx->prof_nk < ctx->prof_cap;
     unsigned long long *clk = prof ? ctx->d_clk : nullptr;
@@ -1474,13 +1636,13 @@ int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, doub
         NMRFIT_LAUNCH(true, 0);
     } else if (fit_im == 0) {
         NMRFIT_LAUNCH(false, 0);
-    } else if constexpr (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_STAGED || VARIANT == NMRFIT_VARIANT_NOREC) {
+    } else if constexpr (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_FARFIELD || VARIANT == NMRFIT_VARIANT_NOREC) {
         if (fit_im == 1)
             NMRFIT_LAUNCH(false, 1);
         else
             NMRFIT_LAUNCH(false, 2);
     } else {
-        set_error("fit_im is implemented for the DEFAULT, NOREC and STAGED kernel variants only");
+        set_error("fit_im is implemented for the DEFAULT, NOREC and FARFIELD kernel variants (STAGED runs DEFAULT) only");
         return NMRFIT_E_UNSUPPORTED;
     }
 #undef NMRFIT_LAUNCH
@@ -1511,29 +1673,40 @@ int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw)
 // The kernel variant a launch actually runs (the requested one may not fit in LDS, or may not
 // implement the imaginary part) and the dynamic LDS its per-wave records need.
 static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, int fit_im, int *variant_out,
-                              int wpb = kWavesPerBlock)
+                              unsigned *aux_off, int wpb = kWavesPerBlock)
 {
-    const bool dR = residual;
-    const size_t lds_recs = (((size_t)wpb * (size_t)std::max(P, 1) * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
+    const size_t np = (size_t)std::max(P, 1);
+    const size_t lds_recs = (((size_t)wpb * np * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
                             (size_t)wpb * kMaxBlocks * sizeof(double2);
     const size_t lds_stage = (size_t)wpb * 3 * kChunk * sizeof(double);
-    // STAGED needs three workgroups to still fit in a CU's 160 KiB (P <= 27); beyond that it
-    // runs the unstaged kernel.
-    int variant = ctx->variant;
-    if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
     const size_t lds_far = (size_t)wpb * kFarTerms * kFarPad * sizeof(double);
     // Gaussian recurrence constants (d, C) per peak: objective launches of DEFAULT / FARFIELD
-    const size_t lds_rec = dR ? 0 : (size_t)wpb * (size_t)std::max(P, 1) * sizeof(double2);
-    if (variant == NMRFIT_VARIANT_FARFIELD && (lds_recs + lds_far + lds_rec > 160 * 1024 || fit_im != 0))
-        variant = NMRFIT_VARIANT_DEFAULT;   // P > ~600, or the imaginary part (direct kernel only)
-    const size_t lds_fast = (NMRFIT_FASTPAIR != 0 && NMRFIT_GROUP == 8)
-                                ? (size_t)wpb * (size_t)std::max(P, 1) * sizeof(PeakFast) : 0;
-    if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_rec + lds_fast > 160 * 1024)
+    const size_t lds_rec = residual ? 0 : (size_t)wpb * np * sizeof(double2);
+    const size_t lds_fast = (NMRFIT_FASTPAIR != 0 && NMRFIT_GROUP == 8) ? (size_t)wpb * np * sizeof(PeakFast) : 0;
+    // the all-peak imaginary model sums far peaks through the far-field scratch and evaluates Dawson's
+    // integral from a table in LDS
+    const size_t lds_im = (fit_im == 2) ? lds_far : 0;
+    const size_t lds_tab = (fit_im == 2) ? 16 * 19 * sizeof(double) + 16 : 0;
+    int variant = ctx->variant;
+    // the imaginary channel exists in DEFAULT, NOREC and FARFIELD; the A/B variants fail in launch_variant
+    if (variant == NMRFIT_VARIANT_STAGED && fit_im != 0) variant = NMRFIT_VARIANT_DEFAULT;
+    // STAGED needs three workgroups to still fit in a CU's 160 KiB (P <= 27); beyond that it
+    // runs the unstaged kernel.
+    if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
+    if (variant == NMRFIT_VARIANT_FARFIELD && lds_recs + lds_far + lds_rec + lds_tab > 160 * 1024)
+        variant = NMRFIT_VARIANT_DEFAULT;   // P > ~600
+    if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_im + lds_rec + lds_fast + lds_tab > 160 * 1024)
         variant = NMRFIT_VARIANT_NOREC;     // P > ~450: no room for the recurrence / scaled records
     size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
-                 (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : 0) +
+                 (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : lds_im) +
                  ((variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_DEFAULT) ? lds_rec : 0) +
                  (variant == NMRFIT_VARIANT_DEFAULT ? lds_fast : 0);
+    *aux_off = 0;
+    if (lds_tab) {
+        lds = (lds + 15) & ~(size_t)15;
+        *aux_off = (unsigned)lds;
+        lds += lds_tab;
+    }
     *variant_out = variant;
     return lds;
 }
@@ -1574,7 +1747,12 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         return NMRFIT_E_INVALID;
     }
     int variant = NMRFIT_VARIANT_DEFAULT;
-    size_t lds = resolve_variant(ctx, P, dR != nullptr, fit_im, &variant);
+    unsigned aux_off = 0;
+    size_t lds = resolve_variant(ctx, P, dR != nullptr, fit_im, &variant, &aux_off);
+    if (lds > 160 * 1024) {
+        set_error("too many peaks for the imaginary model's LDS records");
+        return NMRFIT_E_UNSUPPORTED;
+    }
     // fused swarm update: one copy of the particle's updated row per wave, after everything else
     PsoFused upd{};
     if (fused && fused->x_in) {
@@ -1596,28 +1774,28 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     int rc;
     switch (variant) {
         case NMRFIT_VARIANT_BASELINE:
-            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
+            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
             break;
         case NMRFIT_VARIANT_NOSKIP:
-            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
+            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
             break;
         case NMRFIT_VARIANT_SINGLE:
-            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
+            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
             break;
         case NMRFIT_VARIANT_QUAD:
-            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
+            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
             break;
         case NMRFIT_VARIANT_FARFIELD:
-            rc = launch_variant<NMRFIT_VARIANT_FARFIELD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
+            rc = launch_variant<NMRFIT_VARIANT_FARFIELD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
             break;
         case NMRFIT_VARIANT_NOREC:
-            rc = launch_variant<NMRFIT_VARIANT_NOREC>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
+            rc = launch_variant<NMRFIT_VARIANT_NOREC>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
             break;
         case NMRFIT_VARIANT_STAGED:
-            rc = launch_variant<NMRFIT_VARIANT_STAGED>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
+            rc = launch_variant<NMRFIT_VARIANT_STAGED>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
             break;
         default:
-            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd);
+            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
             break;
     }
     if (rc != NMRFIT_OK) return rc;
@@ -1655,8 +1833,9 @@ int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bo
     if ((double)S * (double)N * (double)std::max(sw.P, 1) > max_units) return NMRFIT_OK;
     const int fit_im = ctx->fit_im;
     int variant = NMRFIT_VARIANT_DEFAULT;
-    const size_t lds_obj = resolve_variant(ctx, sw.P, false, fit_im, &variant, kGenWaves);
-    if (!(variant == NMRFIT_VARIANT_DEFAULT || (variant == NMRFIT_VARIANT_FARFIELD && fit_im == 0))) return NMRFIT_OK;
+    unsigned aux_off = 0;
+    const size_t lds_obj = resolve_variant(ctx, sw.P, false, fit_im, &variant, &aux_off, kGenWaves);
+    if (!(variant == NMRFIT_VARIANT_DEFAULT || (variant == NMRFIT_VARIANT_FARFIELD && fit_im == 0))) return NMRFIT_OK;   // (others: launch per phase)
     // all segments of a particle in one workgroup: nseg in {1, 2, 4, 8}, whole blocks each
     const int64_t n_chunks = (N + kChunk - 1) / kChunk;
     const int blk_chunks = (int)((n_chunks + kMaxBlocks - 1) / kMaxBlocks);
@@ -1737,6 +1916,7 @@ int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bo
     a.post_idx = sw.post_idx;
     a.err = sw.err;
     a.generations = generations;
+    a.aux_off = aux_off;
     static unsigned long long *d_trace = nullptr;
     static const bool want_trace = getenv("NMRFIT_PERSIST_TRACE") != nullptr;
     if (want_trace && !d_trace) NMRFIT_HIP(hipMalloc((void **)&d_trace, 16 * sizeof(unsigned long long)));

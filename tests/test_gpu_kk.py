@@ -151,10 +151,13 @@ def test_fit_with_imaginary_part(eq):
     assert res.params[6] == pytest.approx(sp["x_true"][6], rel=0.1)
 
 
-def test_randomized_fit_im_against_closed_form(eq):
+@pytest.mark.parametrize("variant", ["default", "farfield", "norec"])
+def test_randomized_fit_im_against_closed_form(eq, variant):
     """120 random shapes (N in [1, 3000], P in [1, 40]): both imaginary-channel modes against
     numpy + scipy.special.dawsn (synth._dispersion), the same closed form the golden vectors pin
-    to the reference's quadrature at 1e-8."""
+    to the reference's quadrature at 1e-8.  The all-peak mode sums far peaks through a shared
+    expansion per chunk and evaluates near ones with a gathered Dawson table; the widths here
+    (6e-4 ... 12 on a span of 6) put peaks on both sides of that split in almost every case."""
     from nmrfit_amd import proc_autophase
     from oracle import nmrfit_oracle as onp
     rng = np.random.default_rng(77)
@@ -182,5 +185,34 @@ def test_randomized_fit_im_against_closed_form(eq):
             want_ref[s] = 0.5 * (rr + np.sqrt(np.mean((wt * (I - Ik[-1])) ** 2)))
             want_sum[s] = 0.5 * (rr + np.sqrt(np.mean((wt * (I - sum(Ik))) ** 2)))
         with eq.Evaluator(w, u, v, wt) as ev:
+            ev.set_variant(_cabi.variant_id(variant))
             np.testing.assert_allclose(ev.objective_batch(X, fit_im=True), want_ref, rtol=1e-11, err_msg=str((case, N, P)))
             np.testing.assert_allclose(ev.objective_batch(X, fit_im="sum"), want_sum, rtol=1e-11, err_msg=str((case, N, P)))
+
+
+def test_fit_im_sum_at_c3_size_against_closed_form(eq):
+    """The all-peak imaginary model at BASELINE's C3 grid (65536 points, 24 peaks): a few particles
+    against numpy + scipy.special.dawsn, DEFAULT and FARFIELD, and the two variants against each
+    other over a larger batch (1e-12; observed ~1e-15)."""
+    from nmrfit_amd import proc_autophase
+    from oracle import nmrfit_oracle as onp
+    sp, X = synth.make_workload("C3")
+    X = X[:96]
+    w, u, v, wt = sp["w"], sp["u"], sp["v"], sp["weights"]
+    want = []
+    for x in X[:3]:
+        V, I = proc_autophase.ps2(u, v, x[0], x[1])
+        Vf = sum(onp.voigt(w, x[2], x[3], *x[4 + 3 * k:7 + 3 * k]) for k in range(24))
+        If = sum(synth._dispersion(w, x[2], *x[4 + 3 * k:7 + 3 * k]) for k in range(24))
+        want.append(0.5 * (np.sqrt(np.mean((wt * (V - Vf)) ** 2)) + np.sqrt(np.mean((wt * (I - If)) ** 2))))
+    with eq.Evaluator(w, u, v, wt) as ev:
+        f_def = ev.objective_batch(X, fit_im="sum")
+        f_ref = ev.objective_batch(X, fit_im=True)
+        ev.set_variant(_cabi.VARIANT_FARFIELD)
+        f_far = ev.objective_batch(X, fit_im="sum")
+        f_far_ref = ev.objective_batch(X, fit_im=True)
+        f_small = ev.objective_batch(X[:2], fit_im="sum")          # other launch geometry, same bits
+    np.testing.assert_allclose(f_def[:3], want, rtol=1e-11)
+    np.testing.assert_allclose(f_far, f_def, rtol=1e-12)
+    np.testing.assert_allclose(f_far_ref, f_ref, rtol=1e-12)
+    np.testing.assert_array_equal(f_small, f_far[:2])

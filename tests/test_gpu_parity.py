@@ -135,7 +135,7 @@ def test_empty_batch_and_errors(eq):
         assert f.shape == (0,)
         with pytest.raises(ValueError):
             ev.objective_batch(np.zeros((2, 9)))          # 9 != 4 + 3P
-        ev.set_variant(_cabi.VARIANT_BASELINE)           # fit_im exists for the DEFAULT kernel only
+        ev.set_variant(_cabi.VARIANT_BASELINE)           # fit_im exists for DEFAULT / NOREC / FARFIELD (STAGED runs DEFAULT)
         with pytest.raises(eq.NmrfitError) as ei:
             ev.objective_batch(sp["x_true"][None, :], fit_im=True)
         assert ei.value.code == _cabi.E_UNSUPPORTED
@@ -481,3 +481,83 @@ def test_gaussian_recurrence_against_point_by_point(eq):
         _close_f(f, ref)
         if name == "non-uniform":
             np.testing.assert_allclose(f, f_direct, rtol=1e-13)                  # the recurrence is off
+
+
+@pytest.mark.parametrize("case", ["overlapping_broad", "dense_cluster_1e12", "needles_everywhere"])
+def test_farfield_adversarial_spectra(eq, case):
+    """The far-field variant where its premise fails or is stressed: (a) 24 broad overlapping lines
+    -- NO peak is far from any chunk, everything takes the direct path; (b) a dense cluster whose
+    amplitudes span twelve orders of magnitude next to far satellites; (c) needle-narrow lines
+    (a fraction of a grid step wide) for which every chunk but one is far at huge |t|.  Parity
+    with the C oracle at 1e-9 like every other variant, agreement with DEFAULT at 1e-12, and no
+    slowdown beyond noise where the expansion cannot help."""
+    from oracle import c_oracle
+    N, P, S = 16384, 24, 256
+    rng = np.random.default_rng(5)
+    w = np.linspace(3.0, 4.0, N)
+    u, v = rng.standard_normal(N) * 0.01, rng.standard_normal(N) * 0.01
+    wt = 1.0 + rng.random(N)
+    X = np.empty((S, 4 + 3 * P))
+    X[:, 0] = rng.uniform(-np.pi, np.pi, S)
+    X[:, 1] = rng.uniform(-np.pi, np.pi, S)
+    X[:, 2] = rng.uniform(0, 1, S)
+    X[:, 3] = rng.uniform(-0.01, 0.01, S)
+    if case == "overlapping_broad":
+        X[:, 4::3] = rng.uniform(0.3, 0.8, (S, P))              # widths comparable to the whole span
+        X[:, 5::3] = rng.uniform(3.2, 3.8, (S, P))
+        X[:, 6::3] = rng.uniform(0.001, 0.01, (S, P))
+    elif case == "dense_cluster_1e12":
+        X[:, 4::3] = rng.uniform(0.002, 0.006, (S, P))
+        X[:, 5::3] = np.concatenate((rng.uniform(3.49, 3.51, (S, P - 4)), rng.uniform(3.05, 3.95, (S, 4))), axis=1)
+        X[:, 6::3] = 10.0 ** rng.uniform(-12, 0, (S, P))
+    else:
+        X[:, 4::3] = 10.0 ** rng.uniform(-7, -5, (S, P))         # grid step is 6e-5
+        X[:, 5::3] = rng.uniform(3.0, 4.0, (S, P))
+        X[:, 6::3] = rng.uniform(0.001, 0.01, (S, P))
+    ref = c_oracle.objective_batch(X, w, u, v, wt, threads=8)
+    with eq.Evaluator(w, u, v, wt) as ev:
+        f_def = ev.objective_batch(X)
+        ev.set_variant(_cabi.VARIANT_FARFIELD)
+        f_far = ev.objective_batch(X)
+        R_far = ev.residual_batch(X[:3])
+        ev.set_variant(_cabi.VARIANT_DEFAULT)
+        R_def = ev.residual_batch(X[:3])
+        # timing of the two on resident data (HIP events around the kernel alone)
+        dX, df = ev.dev_alloc(X.nbytes), ev.dev_alloc(8 * S)
+        ev.upload(dX, X)
+        ms = {}
+        for name, vid in (("default", _cabi.VARIANT_DEFAULT), ("farfield", _cabi.VARIANT_FARFIELD)):
+            ev.set_variant(vid)
+            for _ in range(20):
+                ev.objective_batch_dev(S, P, dX, df)
+            ev.prof_enable(30)
+            for _ in range(30):
+                ev.objective_batch_dev(S, P, dX, df)
+            ms[name] = float(np.median(ev.prof_read()[0]))
+            ev.prof_enable(0)
+        ev.dev_free(dX)
+        ev.dev_free(df)
+    _close_f(f_far, ref)
+    _close_f(f_def, ref)
+    np.testing.assert_allclose(f_far, f_def, rtol=1e-12)
+    np.testing.assert_allclose(R_far, R_def, rtol=0, atol=1e-13 * np.abs(R_def).max())
+    print("farfield adversarial %s: default %.1f us, farfield %.1f us" % (case, ms["default"] * 1e3, ms["farfield"] * 1e3))
+    assert ms["farfield"] <= 1.25 * ms["default"], ms      # (the A/B figure itself is in DESIGN.md; this guards against a cliff)
+
+
+def test_farfield_as_context_default_runs_the_swarm(eq):
+    """fit(options={"variant": "farfield"}): the swarm on the far-field kernel reaches the same
+    optimum region as on the direct kernel (trajectories differ by rounding, so not bit for bit)."""
+    import nmrfit_amd
+    sp = synth.make_spectrum(8192, 6, seed=3)
+    data = synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"])
+    opts = {"swarmsize": 204, "maxiter": 300, "seed": 12}
+    a = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False, options=opts)
+    b = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False, options=dict(opts, variant="farfield"))
+    assert b.error == pytest.approx(a.error, rel=0.05)
+    for mode in (True, "sum"):
+        c = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im=mode, summary=False,
+                           options=dict(opts, maxiter=40, variant="farfield"))
+        d = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im=mode, summary=False,
+                           options=dict(opts, maxiter=40))
+        assert np.isfinite(c.error) and c.error == pytest.approx(d.error, rel=0.2)

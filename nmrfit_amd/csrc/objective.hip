@@ -860,7 +860,7 @@ __device__ __forceinline__ void objective_body(
                 const double wcen = wave_uniform(0.5 * (mm.x + mm.y));
                 const double hw = wave_uniform(0.5 * (mm.y - mm.x));
                 double cf[kFarTerms];
-                if (P <= 32) {
+                if (P <= 32 && FIT_IM != 2) {   // (the all-peak imaginary pass below reuses the scratch that parks the odd chunk's sums)
                     // Half a wave of peaks: the even chunks of a segment work out the expansions
                     // of TWO chunks at once -- lanes 0..31 for this chunk, lanes 32..63 for the
                     // next -- and park the second set (sums in LDS, masks in SGPRs) for the odd

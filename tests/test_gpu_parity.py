@@ -539,8 +539,13 @@ def test_farfield_adversarial_spectra(eq, case):
         ev.dev_free(df)
     _close_f(f_far, ref)
     _close_f(f_def, ref)
-    np.testing.assert_allclose(f_far, f_def, rtol=1e-12)
-    np.testing.assert_allclose(R_far, R_def, rtol=0, atol=1e-13 * np.abs(R_def).max())
+    # needles a fraction of a grid step wide: t = (w - loc)*(2/width) is conditioned like 1e-16 * 2e7 near a
+    # core, so any two formulations (these two, or either and the oracle) agree to ~1e-10 only
+    tight = 1e-9 if case == "needles_everywhere" else 1e-12
+    np.testing.assert_allclose(f_far, f_def, rtol=tight)
+    np.testing.assert_allclose(R_far, R_def, rtol=0, atol=(1e-9 if case == "needles_everywhere" else 1e-13) * np.abs(R_def).max())
+    print("   vs oracle: default %.2e, farfield %.2e; farfield vs default %.2e" % (
+        np.max(np.abs(f_def - ref) / ref), np.max(np.abs(f_far - ref) / ref), np.max(np.abs(f_far - f_def) / f_def)))
     print("farfield adversarial %s: default %.1f us, farfield %.1f us" % (case, ms["default"] * 1e3, ms["farfield"] * 1e3))
     assert ms["farfield"] <= 1.25 * ms["default"], ms      # (the A/B figure itself is in DESIGN.md; this guards against a cliff)
 

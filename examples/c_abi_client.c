@@ -143,6 +143,31 @@ int main(int argc, char **argv)
     if (fabs(f0 - fb) > 1e-9 * fmax(fb, 1e-6) || !(fb < 0.02 * scale)) return 6;
     CHECK(nmrfit_pso_destroy(pso));
 
+    /* the multi-GPU form of the same loop, as far as one GPU goes: an RCCL communicator of ONE rank
+     * (rank 0 makes the 128-byte id; with more ranks it would travel to them by any means), attached
+     * to the swarm, so that every nmrfit_pso_step includes the all-gather of the candidate records.
+     * Same seed => the same answer as the plain run above, bit for bit. */
+    {
+        unsigned char uid[NMRFIT_UNIQUE_ID_BYTES];
+        nmrfit_comm *comm = NULL;
+        nmrfit_pso *sw = NULL;
+        double xb2[D], fb2 = 0.0;
+        int32_t rank = -1, nranks = -1, version = 0;
+        CHECK(nmrfit_comm_unique_id(uid));
+        CHECK(nmrfit_comm_create(ctx, 0, 1, uid, &comm));
+        CHECK(nmrfit_comm_info(comm, &rank, &nranks, &version));
+        CHECK(nmrfit_comm_barrier(comm));
+        CHECK(nmrfit_pso_create(ctx, 204, 204, 0, P, lo, hi, &prm, &sw));
+        CHECK(nmrfit_pso_set_comm(sw, comm));
+        CHECK(nmrfit_pso_run(sw, 1000, 100));
+        CHECK(nmrfit_pso_best(sw, xb2, &fb2));
+        printf("pso_run over RCCL %d (rank %d of %d): best f = %.3e\n", version, rank, nranks, fb2);
+        if (fb2 != fb || memcmp(xb2, xb, sizeof xb) != 0) return 8;
+        CHECK(nmrfit_pso_set_comm(sw, NULL));
+        CHECK(nmrfit_pso_destroy(sw));
+        CHECK(nmrfit_comm_destroy(comm));
+    }
+
     /* errors come back as codes, never as crashes */
     if (nmrfit_objective_batch(ctx, S, 1001, X, 0, f) != NMRFIT_E_INVALID) return 7;
     if (nmrfit_objective_batch(NULL, S, P, X, 0, f) != NMRFIT_E_INVALID) return 7;

@@ -66,6 +66,45 @@ def test_channel_broadcast_and_all_gather(world, extra):
         assert parts == expect
 
 
+def _late_worker(rank, world, port, token, delay, q):
+    sys.path.insert(0, ROOT)
+    time.sleep(delay)
+    _env(rank, world, port, token, {})
+    from nmrfit_amd import rendezvous
+    with rendezvous.Channel() as ch:
+        q.put((rank, ch.broadcast(b"id-from-rank-0" if rank == 0 else b"")))
+
+
+def test_channel_rejects_strangers_and_tolerates_late_ranks():
+    """A connection that does not know the launch token never becomes a rank, and a rank that
+    arrives seconds late (a slow `import`, a cold GPU) still joins."""
+    import hashlib
+    import tempfile
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    token = "x%d_%d" % (os.getpid(), time.time_ns())
+    ps = [ctx.Process(target=_late_worker, args=(r, 2, port, token, 0.0 if r == 0 else 3.0, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    # while rank 0 waits for rank 1: find its published port and knock with a wrong token
+    key = "127.0.0.1|%d|%s|%d" % (port, token, os.getuid())
+    path = os.path.join(tempfile.gettempdir(), "nmrfit_rdzv_%s" % hashlib.sha256(key.encode()).hexdigest()[:24])
+    deadline = time.time() + 30
+    while not os.path.exists(path) and time.time() < deadline:
+        time.sleep(0.05)
+    host, prt = open(path).read().strip().rsplit(":", 1)
+    s = socket.create_connection((host, int(prt)), timeout=5)
+    s.sendall(b"\x10\x00\x00\x00\x00\x00\x00\x00" + b"GET / HTTP/1.1\r\n\r\n")
+    s.close()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == {0: b"id-from-rank-0", 1: b"id-from-rank-0"}
+    assert not os.path.exists(path)          # rank 0 removed the file once everybody had joined
+
+
 def test_single_rank_channel_needs_no_network():
     sys.path.insert(0, ROOT)
     from nmrfit_amd import rendezvous

@@ -328,8 +328,17 @@ def main():
     dt = time.perf_counter() - t0
     k_ms, s_ms, clock_mhz = ev.prof_read()
     ev.prof_enable(0)
+    ranks = None
     if ex is not None:
+        dt_local = dt
         dt = float(ex.all_reduce([dt], "max")[0])
+        km = float(np.mean(k_ms)) if len(k_ms) else 0.0
+        lo = ex.all_reduce([km, dt_local, clock_mhz], "min")
+        hi = ex.all_reduce([km, dt_local, clock_mhz], "max")
+        ranks = {"kernel_ms_mean": {"min": float(lo[0]), "max": float(hi[0])},
+                 "timed_region_s": {"min": float(lo[1]), "max": float(hi[1])},
+                 "clock_mhz_in_run": {"min": float(lo[2]), "max": float(hi[2])},
+                 "note": "spread over the ranks (every rank evaluates the same amount of work; `value` uses the slowest)"}
     ms_per_step = dt / args.steps * 1e3
     st = sw.status()
     geom = ev.last_launch()
@@ -471,6 +480,8 @@ def main():
             line["error"] = "objective kernel (%.4f ms) longer than the step that contains it (%.4f ms)" % (
                 t_kernel_ms, ms_per_step)
             rc = 3
+        if ranks is not None:
+            line["ranks"] = ranks
         if variants is not None:
             line["variants"] = variants
             line["farfield_variant"] = farfield

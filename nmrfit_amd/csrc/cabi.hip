@@ -158,6 +158,11 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
     ctx->N = N;
     ctx->n_chunks = (N + kChunk - 1) / kChunk;
     if (const char *tw = getenv("NMRFIT_TARGET_WAVES")) ctx->target_waves = atoll(tw);   // tuning knob
+    // test knob: run a whole test suite with another kernel variant as every context's default
+    if (const char *dv = getenv("NMRFIT_DEFAULT_VARIANT")) {
+        const int vnum = atoi(dv);
+        if (vnum >= 0 && vnum <= NMRFIT_VARIANT_NOREC) ctx->variant = vnum;
+    }
     ctx->w0 = w[N / 2];
     for (int64_t j = 0; j < N; ++j) ctx->wspan = std::fmax(ctx->wspan, std::fabs(w[j] - ctx->w0));
     // Uniform spacing (np.linspace grids, ascending or descending)?  Measured on the centred

@@ -81,3 +81,10 @@ def test_generate_solution_bounds_matches_reference_golden(golden_dir):
     # the synthetic generator's box is the same box
     np.testing.assert_allclose(sp["lower"], g["lower"], rtol=1e-15)
     np.testing.assert_allclose(sp["upper"], g["upper"], rtol=1e-15)
+
+
+def test_default_variant_rule():
+    from nmrfit_amd import utils
+    assert utils.default_variant(4096, 6) == "default"           # the reference's default-size fits
+    assert utils.default_variant(16384, 12) == "farfield"
+    assert utils.default_variant(65536, 24) == "farfield"

@@ -101,7 +101,10 @@ class RcclExchange:
     constructs it, with its own Evaluator (one GPU per process)."""
 
     def __init__(self, evaluator, channel=None):
+        import os
         from . import rendezvous
+        # first contact with a new node is where RCCL fails if it fails: let it say why
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
         self._lib = _cabi.lib()
         self.ev = evaluator
         self._own_channel = channel is None

@@ -189,6 +189,12 @@ int nmrfit_pso_best(nmrfit_pso *pso, double *x_best, double *f_best);
 /* single-rank convenience: init (if needed) + up to maxiter generations, polling the stop
  * flag every `check_every` generations (generations after a stop are no-ops on the GPU). */
 int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every);
+/* Opt-in: run `check_every` generations of nmrfit_pso_run inside ONE cooperative launch (persistent
+ * workgroups that own their particles, one grid-wide exchange per generation through agent-scope
+ * atomics).  Only single-rank swarms small enough for one workgroup per particle qualify (others
+ * silently keep the launch-per-phase path); results are bit-identical either way.  Off by default:
+ * measured 15.3 vs 15.2 us per generation at 204 x 4096 x 6. */
+int nmrfit_pso_set_persistent(nmrfit_pso *pso, int enable);
 /* copy swarm state to host for inspection/tests (any pointer may be NULL):
  * x, v, p are S_local x D; fx, fp are S_local */
 int nmrfit_pso_get_state(nmrfit_pso *pso, double *x, double *v, double *p, double *fx, double *fp);

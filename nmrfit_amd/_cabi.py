@@ -86,6 +86,7 @@ SIGNATURES = {
     "nmrfit_pso_status": [_VP, ctypes.POINTER(_I64), ctypes.POINTER(_I32), _c_double_p],
     "nmrfit_pso_best": [_VP, _VP, _c_double_p],
     "nmrfit_pso_run": [_VP, _I64, _I32],
+    "nmrfit_pso_set_persistent": [_VP, _INT],
     "nmrfit_pso_get_state": [_VP, _VP, _VP, _VP, _VP, _VP],
     "nmrfit_comm_unique_id": [_VP],
     "nmrfit_comm_create": [_VP, _I32, _I32, _VP, _c_void_pp],

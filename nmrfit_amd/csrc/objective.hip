@@ -77,6 +77,7 @@ constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coeff
                                    // lane l sits at column l + l/16, which makes the transposed
                                    // quarter-row reads below bank-conflict free
 constexpr int kMaxBlocks = 16;     // blocks per grid (blk_chunks = ceil(n_chunks/16))
+constexpr size_t kSharedPrologueBytes = ((2 + 2 * kWave) * sizeof(double) + 16 * sizeof(int) + 15) & ~(size_t)15;
 constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
 
 // ---- fp64 helpers (coefficients: tools/gen_poly.py) ---------------------------------------
@@ -552,35 +553,43 @@ __device__ __forceinline__ void objective_body(
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    PeakLor *lor = reinterpret_cast<PeakLor *>(lds_raw) + (size_t)wave * P;
+    // When every wave of the workgroup evaluates a segment of the SAME particle (nseg a multiple of
+    // the waves per workgroup) the particle's prologue is done once per workgroup instead of once
+    // per wave: one copy of the per-peak records (slice 0), the position update by wave 0, the
+    // per-peak constants by the waves in turn (64 peaks a pass), the phase seeds by the last wave --
+    // and a workgroup barrier.  For a short grid the prologue is as long as a chunk or two, so this
+    // is what makes four or eight segments per particle affordable (C2: 17.7 -> see DESIGN.md).
+    const bool shared = PERSIST ? (nseg == WPB) : (nseg % WPB == 0);
+    const int slice = shared ? 0 : wave;
+    PeakLor *lor = reinterpret_cast<PeakLor *>(lds_raw) + (size_t)slice * P;
     PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)WPB * P * sizeof(PeakLor)) +
-                   (size_t)wave * P;
+                   (size_t)slice * P;
     constexpr bool kStage = (VARIANT == NMRFIT_VARIANT_STAGED);
-    // per-wave table of block seeds (<= 16 blocks per grid), then (kStage) the per-wave staging
-    // area for one chunk of u, v, weights (3 x 512 doubles = 12 KiB)
+    // per-wave table of block seeds (<= 16 blocks per grid); the shared-prologue area (rotation step,
+    // per-lane phase seeds, flags); then (kStage) the per-wave staging area for one chunk of u, v,
+    // weights (3 x 512 doubles = 12 KiB)
     unsigned char *lds_tail = lds_raw + (((size_t)WPB * P * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15);
     double2 *seeds = reinterpret_cast<double2 *>(lds_tail) + (size_t)wave * kMaxBlocks;
-    double *stage = reinterpret_cast<double *>(lds_tail + (size_t)WPB * kMaxBlocks * sizeof(double2)) +
-                    (size_t)wave * (3 * kChunk);
+    double *shr = reinterpret_cast<double *>(lds_tail + (size_t)WPB * kMaxBlocks * sizeof(double2));   // rho, L_lane[64] re / im
+    int *sflag = reinterpret_cast<int *>(shr + 2 + 2 * kWave);                                          // one per wave
+    unsigned char *lds_tail2 = reinterpret_cast<unsigned char *>(shr) + kSharedPrologueBytes;
+    double *stage = reinterpret_cast<double *>(lds_tail2) + (size_t)wave * (3 * kChunk);
     // FARFIELD: per-wave scratch [kFarTerms][kFarPad] for the cross-peak coefficient sums
     // (shares the offset of `stage`; the two variants are exclusive)
-    double *ffs = reinterpret_cast<double *>(lds_tail + (size_t)WPB * kMaxBlocks * sizeof(double2)) +
-                  (size_t)wave * (kFarTerms * kFarPad);
+    double *ffs = reinterpret_cast<double *>(lds_tail2) + (size_t)wave * (kFarTerms * kFarPad);
 
     // objective launches of DEFAULT / FARFIELD: per-peak (d, C) of the Gaussian recurrence, after
     // everything else (residual rows are evaluated point by point: they feed finite differences)
     constexpr bool kRec = !WRITE_R && (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_FARFIELD);
-    double2 *grec = reinterpret_cast<double2 *>(
-                        lds_tail + (size_t)WPB * kMaxBlocks * sizeof(double2) +
+    unsigned char *grec_base = lds_tail2 +
                         (kStage ? (size_t)WPB * 3 * kChunk * sizeof(double)
-                                : (VARIANT == NMRFIT_VARIANT_FARFIELD || FIT_IM == 2) ? (size_t)WPB * kFarTerms * kFarPad * sizeof(double) : 0)) +
-                    (size_t)wave * P;
+                                : (VARIANT == NMRFIT_VARIANT_FARFIELD || FIT_IM == 2) ? (size_t)WPB * kFarTerms * kFarPad * sizeof(double) : 0);
+    double2 *grec = reinterpret_cast<double2 *>(grec_base) + (size_t)slice * P;
 
     // DEFAULT: scaled Lorentzian constants for the two-operation pair form, after grec
     constexpr bool kFast = (NMRFIT_FASTPAIR != 0) && (VARIANT == NMRFIT_VARIANT_DEFAULT) && (NMRFIT_GROUP == 8);
-    PeakFast *lorf = reinterpret_cast<PeakFast *>(reinterpret_cast<unsigned char *>(grec - (size_t)wave * P) +
-                                                  (kRec ? (size_t)WPB * P * sizeof(double2) : 0)) +
-                     (size_t)wave * P;
+    PeakFast *lorf = reinterpret_cast<PeakFast *>(grec_base + (kRec ? (size_t)WPB * P * sizeof(double2) : 0)) +
+                     (size_t)slice * P;
 
     // FIT_IM == 2: Dawson table (16 intervals x 19 coefficients) for the gathered evaluation, one copy
     // per workgroup; the barrier after the staging below makes it visible
@@ -599,9 +608,9 @@ __device__ __forceinline__ void objective_body(
     // stage this particle's per-peak constants in the wave's LDS slices (x: the particle's row,
     // in global memory or -- fused swarm update -- in this wave's LDS copy)
     bool fast_bad = false, rec_bad = false;
-    auto stage_peaks = [&](const double *x) {
+    auto stage_peaks = [&](const double *x, const int first_pass, const int pass_stride) {
     p0 = x[0], p1 = x[1], r = x[2], yoff = x[3];   // equations.py:177
-    for (int kb0 = 0; kb0 < P; kb0 += kWave) {   // every lane iterates (the group sums below shuffle)
+    for (int kb0 = first_pass * kWave; kb0 < P; kb0 += pass_stride * kWave) {   // every lane iterates (the group sums below shuffle)
         const int k = kb0 + lane;
         const bool have = k < P;
         const int kx = have ? k : 0;
@@ -658,6 +667,15 @@ __device__ __forceinline__ void objective_body(
     };
     bool fused = false;
     if constexpr (!WRITE_R) fused = upd.x_in != nullptr;
+    // (the row is staged from global memory or from LDS by two separate calls: one pointer that may
+    // be either makes this compiler's address-space inference crash, and would cost flat loads)
+    double *const xrow = reinterpret_cast<double *>(lds_raw + upd.xrow_off) + (size_t)slice * D;
+    auto stage_row = [&](const int first_pass, const int pass_stride) {
+        if (fused)
+            stage_peaks(xrow, first_pass, pass_stride);
+        else
+            stage_peaks(X + particle * D, first_pass, pass_stride);
+    };
     if (fused) {
         // Swarm generation: the velocity / position update of this particle happens HERE, in the
         // prologue of the kernel that evaluates it (one launch fewer per generation).  Every wave of
@@ -665,8 +683,26 @@ __device__ __forceinline__ void objective_body(
         // writes it (and the velocity) to the swarm's other state buffer -- never the one being
         // read, so the segments of a particle cannot race.  After a stop every launch is a no-op:
         // the row is carried over unchanged and the kernel returns.
-        double *xrow = reinterpret_cast<double *>(lds_raw + upd.xrow_off) + (size_t)wave * D;
         if constexpr (PERSIST) {
+            if (shared) {
+                // the workgroup is this particle's only reader and writer: wave 0 updates in place
+                if (wave == 0)
+                    for (int64_t d = lane; d < D; d += kWave) {
+                        const int64_t idx = particle * D + d;
+                        double xn = 0.0, vn = 0.0;
+                        if (active) {
+                            double rp, rg;
+                            uniform2(upd.seed, upd.gen, (uint32_t)d, (uint64_t)(upd.offset + particle), &rp, &rg);
+                            xn = update_value(upd.x_in[idx], upd.v_in[idx], upd.p[idx], upd.best[2 + d], upd.lb[d],
+                                              upd.ub[d], rp, rg, upd.omega, upd.phip, upd.phig, &vn);
+                            upd.x_out[idx] = xn;
+                            upd.v_out[idx] = vn;
+                        }
+                        xrow[d] = xn;
+                    }
+                if (upd.trace && g == 0 && lane == 0) upd.trace[9] = __builtin_amdgcn_s_memrealtime();
+                __syncthreads();
+            } else {
             // in place: the workgroup owns every segment of its particles, so "all old rows read"
             // is one workgroup barrier away; the caller has left the loop on a stop
             double *vrow = xrow + (size_t)WPB * D;
@@ -689,9 +725,11 @@ __device__ __forceinline__ void objective_body(
                     upd.x_out[particle * D + d] = xrow[d];
                     upd.v_out[particle * D + d] = vrow[d];
                 }
+            }
         } else {
         const bool stopped = upd.flags[1] != 0;
         const uint32_t gen = (uint32_t)(upd.flags[0] + 1);
+        if (!shared || wave == 0)
         for (int64_t d = lane; d < D; d += kWave) {
             const int64_t idx = particle * D + d;
             double xn = upd.x_in[idx], vn = upd.v_in[idx];
@@ -708,16 +746,45 @@ __device__ __forceinline__ void objective_body(
             }
         }
         if (stopped) return;   // the same for every wave of the grid
+        if (shared) __syncthreads();   // wave 0's row is every wave's input
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
-        stage_peaks(xrow);
-    } else {
-        stage_peaks(X + particle * D);
     }
-    // wave-uniform: every group of this particle may take the two-operation pair form
-    const bool fast_all = kFast && (__ballot(fast_bad) == 0ull);
-    const bool rec_all = kRec && (__ballot(rec_bad) == 0ull);   // every peak may take the Gaussian recurrence
-    __syncthreads();
+    double rr = 1.0, ri = 0.0, lr = 1.0, li = 0.0;   // rotation step exp(i p1 64/N), lane seed exp(i (p0 + p1 lane/N))
+    const double invN = 1.0 / (double)N;
+    bool fast_all, rec_all;
+    if (shared) {
+        stage_row(wave, WPB);                          // wave w: peaks 64w..64w+63, 64(w+WPB).., usually wave 0 alone
+        if (wave == WPB - 1) {                         // meanwhile the last wave makes the phase seeds
+            double sr, si, tr, ti;
+            sincos_fast((p1 * 64.0) * invN, &si, &sr);
+            sincos_fast(p0 + (p1 * (double)lane) * invN, &ti, &tr);
+            if (lane == 0) {
+                shr[0] = sr;
+                shr[1] = si;
+            }
+            shr[2 + lane] = tr;
+            shr[2 + kWave + lane] = ti;
+        }
+        const int fl = (__ballot(fast_bad) != 0ull ? 1 : 0) | (__ballot(rec_bad) != 0ull ? 2 : 0);
+        if (lane == 0) sflag[wave] = fl;
+        __syncthreads();
+        int all = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < WPB; ++w2) all |= sflag[w2];
+        fast_all = kFast && !(all & 1);
+        rec_all = kRec && !(all & 2);
+        rr = wave_uniform(shr[0]);
+        ri = wave_uniform(shr[1]);
+        lr = shr[2 + lane];
+        li = shr[2 + kWave + lane];
+    } else {
+        stage_row(0, 1);
+        // wave-uniform: every group of this particle may take the two-operation pair form
+        fast_all = kFast && (__ballot(fast_bad) == 0ull);
+        rec_all = kRec && (__ballot(rec_bad) == 0ull);   // every peak may take the Gaussian recurrence
+        __syncthreads();
+    }
     if (!active) return;
     if (PERSIST && upd.trace && g == 0 && lane == 0) upd.trace[10] = __builtin_amdgcn_s_memrealtime();
 
@@ -730,13 +797,14 @@ __device__ __forceinline__ void objective_body(
     // E_b = exp(i*p1*(b*blk_len)/N) (wave-uniform, tabulated in LDS for this segment's blocks)
     // and L_lane = exp(i*(p0 + p1*lane/N)): both depend on the GLOBAL block index and the lane
     // only, never on where the segment starts.
-    double zr = 1.0, zi = 0.0, rr, ri, lr, li;
-    const double invN = 1.0 / (double)N;
+    double zr = 1.0, zi = 0.0;
     const int64_t blk_len = (int64_t)blk_chunks * kChunk;
-    sincos_fast((p1 * 64.0) * invN, &ri, &rr);
-    rr = wave_uniform(rr);
-    ri = wave_uniform(ri);
-    sincos_fast(p0 + (p1 * (double)lane) * invN, &li, &lr);
+    if (!shared) {   // (shared prologue: made once per workgroup above)
+        sincos_fast((p1 * 64.0) * invN, &ri, &rr);
+        rr = wave_uniform(rr);
+        ri = wave_uniform(ri);
+        sincos_fast(p0 + (p1 * (double)lane) * invN, &li, &lr);
+    }
     {
         const int64_t b0 = j0 / blk_len;
         const int64_t nb = (j1 - j0 + blk_len - 1) / blk_len;
@@ -1430,6 +1498,7 @@ __global__ __launch_bounds__(kGenBlock, 1) void generation_kernel(const GenArgs 
                     for (int64_t d = lane; d < D; d += kWave)
                         __hip_atomic_store(a.p + i * D + d, a.x[i * D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (lane == 0) a.fp[i] = f;
+                    global_stores_done();   // the row is complete in memory before this workgroup's post can be seen
                     cur = f;
                 }
                 if (lex_less(cur, i, mine, mi)) {
@@ -1446,7 +1515,7 @@ __global__ __launch_bounds__(kGenBlock, 1) void generation_kernel(const GenArgs 
         }
         __syncthreads();
         // Post and fold without a counter barrier: a post is (value, tag) with tag = epoch << 32 | index.
-        // The value is stored first and has completed before the tag is issued, so a reader that sees
+        // The value is stored first and has completed (s_waitcnt vmcnt(0)) before the tag is issued, so a reader that sees
         // the current epoch in a tag reads the matching value afterwards.  Every workgroup polls every
         // post until it carries this generation's epoch: that IS the barrier, and it costs one
         // uncached round trip after the last post instead of a few hundred serialised atomic
@@ -1464,8 +1533,8 @@ __global__ __launch_bounds__(kGenBlock, 1) void generation_kernel(const GenArgs 
             const size_t slot = (size_t)(it & 1) * nwg + blockIdx.x;
             const unsigned long long ix = (bi >= 0 && bi < 0xffffffffLL) ? (unsigned long long)bi : 0xffffffffull;
             __hip_atomic_store(a.post_val + slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): the value (and, through the
-                                                                      // barrier above, this workgroup's p rows) are done
+            global_stores_done();   // the value is at its point of coherence before the tag is issued (the waves
+                                    // that wrote personal-best rows waited for theirs before the barrier above)
             __hip_atomic_store((unsigned long long *)a.post_idx + slot, (epoch << 32) | ix, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1677,7 +1746,7 @@ static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, i
 {
     const size_t np = (size_t)std::max(P, 1);
     const size_t lds_recs = (((size_t)wpb * np * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
-                            (size_t)wpb * kMaxBlocks * sizeof(double2);
+                            (size_t)wpb * kMaxBlocks * sizeof(double2) + kSharedPrologueBytes;
     const size_t lds_stage = (size_t)wpb * 3 * kChunk * sizeof(double);
     const size_t lds_far = (size_t)wpb * kFarTerms * kFarPad * sizeof(double);
     // Gaussian recurrence constants (d, C) per peak: objective launches of DEFAULT / FARFIELD
@@ -1731,12 +1800,13 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
     const int64_t blk_len = (int64_t)blk_chunks * kChunk;
     int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(n_blocks, (target_waves + S - 1) / S));
-    // Short grids: a wave's prologue (parameter staging, phase seeds) costs about as much as a
-    // chunk or two, so prefer >= 4 chunks per wave as long as two waves per SIMD remain
-    // (measured on C2, S=1024 N=4096: 8 segments 26.2 us, 2 segments 22.2 us).
+    // Short grids: a wave's own prologue (block seeds, pointers, the barrier of the shared part) still
+    // costs a good fraction of a chunk, so prefer >= 2 chunks per wave as long as two waves per SIMD
+    // remain (measured on C2, S=1024 N=4096, with the per-workgroup prologue: 8 segments 25.0 us,
+    // 4 segments 22.7 us, 2 segments 23.3 us; round 1, prologue per wave: 8 -> 26.2, 2 -> 22.2).
     if (ctx->target_waves == 0) {
         const int64_t simds = (int64_t)ctx->compute_units * 4;
-        while (nseg > 1 && n_chunks / nseg < 4 && S * ((nseg + 1) / 2) >= 2 * simds) nseg = (nseg + 1) / 2;
+        while (nseg > 1 && n_chunks / nseg < 2 && S * ((nseg + 1) / 2) >= 2 * simds) nseg = (nseg + 1) / 2;
     }
     int64_t seg_len = ((n_blocks + nseg - 1) / nseg) * blk_len;
     nseg = (N + seg_len - 1) / seg_len;
@@ -1820,17 +1890,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
 int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bool *launched)
 {
     *launched = false;
-    static const bool off = getenv("NMRFIT_NO_PERSISTENT") != nullptr;   // A/B knob
-    static const double max_units = [] {
-        const char *e = getenv("NMRFIT_PERSIST_MAX_UNITS");
-        return e ? atof(e) : 1.0e7;
-    }();
     const int64_t S = sw.S, N = ctx->N, D = 4 + 3 * (int64_t)sw.P;
-    if (off || generations < 1 || S < 1 || D > kFusedMaxD) return NMRFIT_OK;
-    // worth it only for the smallest problems: measured 15.3 against 16.4 us per generation at
-    // 204 x 4096 x 6 (5e6 units) and 14.4 / 14.8 at 50 x 4096 x 6, but 31.9 / 30.5 at 204 x 16384 x 12
-    // (4e7 units), where four waves per particle no longer cover the arithmetic
-    if ((double)S * (double)N * (double)std::max(sw.P, 1) > max_units) return NMRFIT_OK;
+    if (generations < 1 || S < 1 || D > kFusedMaxD) return NMRFIT_OK;
     const int fit_im = ctx->fit_im;
     int variant = NMRFIT_VARIANT_DEFAULT;
     unsigned aux_off = 0;

@@ -56,6 +56,7 @@ struct nmrfit_pso {
     unsigned long long epoch = 0;            // persistent generations: posts made so far (tags never repeat)
     int *d_err = nullptr;                    // ... and their time-out flag
     nmrfit_comm *comm = nullptr;       // attached communicator (sharded swarm): the exchange runs inside nmrfit_pso_step
+    bool persistent = false;     // nmrfit_pso_set_persistent: cooperative persistent generations in nmrfit_pso_run
     bool initialized = false;    // nmrfit_pso_init has run
     bool seeded = false;         // the generation-0 candidates have been folded into (g, fg)
 };
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
                 for (int64_t d = lane; d < a.D; d += kWave)
                     __hip_atomic_store(a.p + i * a.D + d, a.x[i * a.D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) __hip_atomic_store(a.fp + i, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                global_stores_done();   // complete in memory before this workgroup draws its ticket
             } else {
                 for (int64_t d = lane; d < a.D; d += kWave) a.p[i * a.D + d] = a.x[i * a.D + d];
                 if (lane == 0) a.fp[i] = f;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
         s_val[wave] = mine;
         s_idx[wave] = mi;
     }
-    __syncthreads();   // (s_waitcnt vmcnt(0) in every wave: the workgroup's p / fp stores have completed)
+    __syncthreads();   // (every wave has waited for its own p / fp stores above: a barrier alone does not)
     if (threadIdx.x == 0) {
         double b = s_val[0];
         long long bi = s_idx[0];
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
         if (ticket) {
             __hip_atomic_store(part_val + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(part_idx + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): the post has completed
+            global_stores_done();   // the post has completed
             s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u);
         } else {
             part_val[blockIdx.x] = b;
@@ -827,10 +829,10 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
         }
         return NMRFIT_OK;
     }
-    // single rank.  Small (latency-bound) swarms run `check_every` generations per cooperative
-    // launch of the persistent generation kernel (objective.hip); otherwise a generation is the
-    // objective launch (which also advances the swarm) and the select launch (which also folds the
-    // candidate and applies the stopping rule).
+    // single rank.  A generation is the objective launch (which also advances the swarm) and the select
+    // launch (which also folds the candidate and applies the stopping rule); with
+    // nmrfit_pso_set_persistent, small swarms run `check_every` generations per cooperative launch of
+    // the persistent generation kernel (objective.hip) instead.
     int64_t it = 0;
     while (it < maxiter) {
         const int64_t n = std::min<int64_t>(check_every, maxiter - it);
@@ -860,7 +862,9 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
         vw.max_posts = kSelectMaxPosts / 2;
         vw.err = pso->d_err;
         bool launched = false;
-        if ((rc = launch_generations(pso->ctx, vw, (int)std::min<int64_t>(n, 1 << 20), &launched)) != NMRFIT_OK) return rc;
+        if (pso->persistent &&
+            (rc = launch_generations(pso->ctx, vw, (int)std::min<int64_t>(n, 1 << 20), &launched)) != NMRFIT_OK)
+            return rc;
         if (launched) pso->epoch += (unsigned long long)n;
         if (!launched)
             for (int64_t k = 0; k < n; ++k)
@@ -878,6 +882,16 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
         }
         if (stop) break;
     }
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_set_persistent(nmrfit_pso *pso, int enable)
+{
+    if (!pso) {
+        set_error("null swarm handle");
+        return NMRFIT_E_INVALID;
+    }
+    pso->persistent = enable != 0;
     return NMRFIT_OK;
 }
 

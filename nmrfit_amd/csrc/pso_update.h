@@ -80,6 +80,16 @@ struct PsoFused {
     unsigned long long *trace = nullptr;              // development aid (NMRFIT_PERSIST_TRACE)
 };
 
+// Wait until every global store this wave has issued has completed.  For the agent-scope (sc1,
+// write-through) atomic stores used to hand data to other workgroups of a running launch that means:
+// visible to every XCD.  NOTE: neither __syncthreads() nor a workgroup-scope fence does this on
+// gfx950 -- in the default (non-tgsplit) mode they wait for LDS traffic only (s_waitcnt lgkmcnt(0)),
+// which is enough inside a workgroup but not for a hand-over through memory.
+__device__ __forceinline__ void global_stores_done()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ bool lex_less(double v, long long i, double bv, long long bi)
 {
     return v < bv || (v == bv && i < bi);

@@ -380,6 +380,13 @@ class DeviceSwarm:
         folds generation 0."""
         _cabi.check(self._lib.nmrfit_pso_step(self._h))
 
+    def set_persistent(self, enable=True):
+        """Opt-in: ``run`` executes ``check_every`` generations per cooperative launch (persistent
+        workgroups, csrc/objective.hip generation_kernel) when the swarm is small enough for one
+        workgroup per particle; bit-identical results.  Off by default (no faster than the
+        launch-per-phase path on this part)."""
+        _cabi.check(self._lib.nmrfit_pso_set_persistent(self._h, 1 if enable else 0))
+
     def candidate_dev(self):
         p = ctypes.c_void_p()
         _cabi.check(self._lib.nmrfit_pso_candidate_dev(self._h, ctypes.byref(p)))
@@ -479,12 +486,14 @@ def run_sharded(swarm, exchange, maxiter, check_every=1, verbose=False):
 
 
 def pso(evaluator, lb, ub, swarmsize=100, omega=0.5, phip=0.5, phig=0.5, maxiter=100, minstep=1e-8,
-        minfunc=1e-8, seed=0, check_every=64, verbose=True):
+        minfunc=1e-8, seed=0, check_every=64, verbose=True, persistent=False):
     """pyswarm.pso-shaped entry point over a GPU ``Evaluator`` (single rank):
     returns (xopt, fopt) like pyswarm does."""
     sw = DeviceSwarm(evaluator, lb, ub, swarmsize, seed=seed, omega=omega, phip=phip, phig=phig,
                      minstep=minstep, minfunc=minfunc)
     try:
+        if persistent:
+            sw.set_persistent(True)
         sw.run(maxiter, check_every)
         st = sw.status()
         if verbose:

@@ -10,7 +10,7 @@ Kept verbatim from the reference interface:
   after fit(): weights, params, error.
   options: swarmsize (204), maxiter (2000), omega (-0.2134), phip (-0.3344), phig (2.3259)
            (utils.py:177-181).  Extra opt-in keys: minstep, minfunc (pyswarm's 1e-8 defaults,
-           which the reference does not forward), seed, device, check_every, polish,
+           which the reference does not forward), seed, device, check_every, polish, persistent,
            variant (kernel variant by name or number; default: "farfield" when grid x peaks
            >= 1e5, else "default" -- see default_variant), exchange ("rccl" for a
            multi-GPU fit, one process per GPU: the swarm axis is sharded and the global best is
@@ -150,7 +150,8 @@ class FitUtility:
             ev.set_variant(_cabi.variant_id(opt.get('variant', default_variant(len(self.data.w), n_peaks))))
             if exchange is None or (exchange.world == 1 and not isinstance(exchange, pso.RcclExchange)):
                 xopt, fopt = pso.pso(ev, self.lower, self.upper, swarmsize=swarmsize, maxiter=maxiter, seed=seed,
-                                     check_every=opt.get('check_every', 64), verbose=True, **kw)
+                                     check_every=opt.get('check_every', 64), verbose=True,
+                                     persistent=bool(opt.get('persistent', False)), **kw)
             else:
                 # every rank must run the same swarm: rank 0's seed wins (an unseeded fit would
                 # otherwise draw a different seed on every rank)

@@ -384,6 +384,7 @@ def test_persistent_generations_match_numpy_mirror(S, N, P, variant, fit_im):
             host.apply_global(host.candidate()[None, :])
         for ce in (gens, 7):
             dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=23, minfunc=-1.0, minstep=-1.0)
+            dev.set_persistent(True)     # (swarms too large for one workgroup per particle keep the launch-per-phase path)
             dev.run(gens, check_every=ce)
             st = dev.state()
             for k in ("x", "v", "p", "fx", "fp"):
@@ -409,6 +410,7 @@ def test_persistent_generations_stop_rule():
         assert host.stop in (1, 2) and host.iteration < 2000
         for ce in (64, 5):
             dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 204, seed=8)
+            dev.set_persistent(True)
             dev.run(2000, check_every=ce)
             st = dev.status()
             assert (st["stop"], st["iteration"]) == (host.stop, host.iteration)
@@ -421,3 +423,27 @@ def test_persistent_generations_stop_rule():
             for k in before:
                 np.testing.assert_array_equal(before[k], after[k])
             dev.close()
+
+
+@pytest.mark.parametrize("S,N,P", [(204, 4096, 6), (256, 2048, 3), (50, 4096, 6)])
+def test_persistent_generations_long_run_device_vs_device(S, N, P):
+    """4000 generations inside the persistent kernel (cross-workgroup hand-over through agent-scope
+    atomics: value, tag and personal-best rows must each be COMPLETE in memory before the next is
+    issued -- on gfx950 neither a barrier nor a workgroup-scope fence waits for global stores)
+    against the launch-per-phase path from the same seed: any stale or torn read of another
+    workgroup's post shows up as a diverging swarm."""
+    from nmrfit_amd import equations
+    sp = synth.make_spectrum(N, P, seed=4)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        a = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=99, minfunc=-1.0, minstep=-1.0)
+        b = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=99, minfunc=-1.0, minstep=-1.0)
+        a.set_persistent(True)
+        a.run(4000, check_every=500)
+        b.run(4000, check_every=500)
+        sa, sb = a.state(), b.state()
+        for k in ("x", "v", "p", "fx", "fp"):
+            np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+        assert a.status() == b.status() and a.status()["iteration"] == 4000
+        np.testing.assert_array_equal(a.best()[0], b.best()[0])
+        a.close()
+        b.close()

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void probe(Args a)
         if (a.mode == 0)
             __threadfence();
         else
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): the write-through stores are done
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores are done (a workgroup-scope
+                                                               // fence or a barrier does NOT wait for them on gfx950)
         if (!barrier(a.count, (unsigned long long)(it + 1) * nwg, a.err)) return;
         if (a.mode == 0) __threadfence();
         // fold: every workgroup reads every post

@@ -1807,6 +1807,10 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     if (ctx->target_waves == 0) {
         const int64_t simds = (int64_t)ctx->compute_units * 4;
         while (nseg > 1 && n_chunks / nseg < 2 && S * ((nseg + 1) / 2) >= 2 * simds) nseg = (nseg + 1) / 2;
+        // a small swarm whose waves just miss fitting on the chip at once (three per SIMD) while half
+        // as many would leave it well filled: take the half (204 x 16384 x 12: 16 segments 30.4 us per
+        // generation, 8 segments 28.5; tools/nseg_generation_ab.py)
+        if (nseg > 1 && S * nseg > 3 * simds && S * (nseg / 2) < 2 * simds && n_chunks / nseg <= 2) nseg /= 2;
     }
     int64_t seg_len = ((n_blocks + nseg - 1) / nseg) * blk_len;
     nseg = (N + seg_len - 1) / seg_len;

@@ -262,8 +262,8 @@ def main():
     backend = {"nccl": "rccl", "gloo": "host"}.get(backend, backend)
     use_dist = world > 1 or os.environ.get("NMRFIT_BENCH_FORCE_DIST") == "1"
     device = local_rank
-    if use_dist and backend == "host":
-        device = local_rank % max(1, _cabi.device_count())
+    if use_dist and (backend == "host" or os.environ.get("NMRFIT_BENCH_SHARE_GPU") == "1"):
+        device = local_rank % max(1, _cabi.device_count())      # rehearsals: several ranks on one card
 
     ev = Evaluator(spec["w"], spec["u"], spec["v"], spec["weights"], device=device)
     ev.set_variant(args.variant)
@@ -271,8 +271,22 @@ def main():
                          S_local=S_local, seed=1234, minstep=-1.0, minfunc=-1.0)   # never stop while timing
     ex = None
     exchange_desc = "none"
+    rccl_failure = None
+    channel = None
+    if use_dist:
+        from nmrfit_amd import rendezvous
+        channel = rendezvous.Channel()        # the star of sockets the ranks bootstrap over
     if use_dist and backend == "rccl":
-        ex = pso.RcclExchange(ev)
+        try:
+            ex = pso.RcclExchange(ev, channel=channel)
+        except _cabi.NmrfitError as e:
+            # RCCL unavailable on EVERY rank alike (library missing, no unique id): say so loudly and
+            # still measure, with the candidate record staged through the host.  (A failure inside
+            # ncclCommInitRank on some ranks only cannot be recovered from: the run then fails.)
+            rccl_failure = str(e)
+            sys.stderr.write("bench.py rank %d: RCCL exchange unavailable (%s); host-staged exchange instead\n" % (rank, e))
+            backend = "host"
+    if use_dist and backend == "rccl":
         sw.set_comm(ex)                       # the all-gather now happens inside nmrfit_pso_step
         exchange_desc = "ncclAllGather of %d doubles per generation inside nmrfit_pso_step (RCCL %s)" % (
             D + 1, ex.info()["rccl_version"])
@@ -280,8 +294,9 @@ def main():
         def step():
             sw.step()
     elif use_dist:
-        ex = pso.SocketExchange()
-        exchange_desc = "host-staged all-gather of %d doubles per generation (sockets; rehearsal)" % (D + 1)
+        ex = pso.SocketExchange(channel=channel)
+        exchange_desc = "host-staged all-gather of %d doubles per generation (sockets%s)" % (
+            D + 1, "; RCCL FAILED: " + rccl_failure if rccl_failure else "; rehearsal")
         state = {"first": True}
 
         def step():
@@ -501,6 +516,8 @@ def main():
         if isinstance(ex, pso.RcclExchange):
             sw.set_comm(None)
         ex.close()
+    if channel is not None:
+        channel.close()
     sw.close()
     ev.close()
     if rc:

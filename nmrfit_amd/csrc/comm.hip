@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -51,10 +52,14 @@ Rccl g_rccl;
 int load_rccl()
 {
     if (g_rccl.handle) return NMRFIT_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // NMRFIT_RCCL_LIB: a specific RCCL build (or, in tests, a missing one) instead of the usual names
+    const char *forced = getenv("NMRFIT_RCCL_LIB");
+    const char *names[] = {forced ? forced : "librccl.so.1", forced ? nullptr : "librccl.so",
+                           forced ? nullptr : "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     std::string tried;
     for (const char *n : names) {
+        if (!n) continue;
         h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (h) break;
         const char *e = dlerror();

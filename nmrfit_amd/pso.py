@@ -111,12 +111,18 @@ class RcclExchange:
         self.channel = rendezvous.Channel() if channel is None else channel
         self.rank, self.world = self.channel.rank, self.channel.world
         uid = ctypes.create_string_buffer(_cabi.UNIQUE_ID_BYTES)
+        rc0, err0 = 0, ""
         if self.rank == 0:
-            _cabi.check(self._lib.nmrfit_comm_unique_id(uid))
-        raw = self.channel.broadcast(uid.raw if self.rank == 0 else b"")
+            rc0 = self._lib.nmrfit_comm_unique_id(uid)
+            if rc0 != _cabi.OK:
+                err0 = self._lib.nmrfit_last_error().decode("utf-8", "replace")
+        # rank 0 ALWAYS answers (an empty id when it could not make one), so that no rank is left
+        # waiting in the rendezvous for an id that will never come
+        raw = self.channel.broadcast((uid.raw if rc0 == _cabi.OK else b"") if self.rank == 0 else b"")
         if len(raw) != _cabi.UNIQUE_ID_BYTES:
-            raise RuntimeError("rendezvous delivered %d bytes of RCCL unique id, expected %d"
-                               % (len(raw), _cabi.UNIQUE_ID_BYTES))
+            if self.rank == 0:
+                raise _cabi.NmrfitError(rc0, err0)
+            raise _cabi.NmrfitError(_cabi.E_COMM, "rank 0 could not create an RCCL unique id")
         uid = ctypes.create_string_buffer(raw, _cabi.UNIQUE_ID_BYTES)
         self._h = ctypes.c_void_p()
         _cabi.check(self._lib.nmrfit_comm_create(evaluator.handle, self.rank, self.world, uid, ctypes.byref(self._h)))

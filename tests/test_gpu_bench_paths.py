@@ -73,6 +73,15 @@ def test_bench_paths_agree():
     assert three["config"]["swarm_best_f"] == plain["config"]["swarm_best_f"]
 
 
+def test_bench_says_so_when_rccl_is_unavailable():
+    """RCCL missing on every rank (forced with NMRFIT_RCCL_LIB): no rank hangs in the rendezvous, the run
+    still measures with the host-staged exchange, and the line says loudly what happened."""
+    common = ["--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--workload", "C2", "--preheat-seconds", "0.1",
+              "--no-extras", "--swarm-per-gpu", "256"]
+    d = _run([sys.executable, "bench.py", "--gpus", "2"] + common, {"NMRFIT_RCCL_LIB": "/nonexistent/librccl.so", "NMRFIT_BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and "RCCL FAILED" in d["config"]["exchange"]
+
+
 def test_c4_rehearsal_four_ranks_on_one_gpu():
     """C4's per-GPU shape (4096 particles x 65536 points x 24 peaks per rank) with 4 ranks on one
     device through the self-launcher, against the one-rank 16384-particle run: same swarm best."""

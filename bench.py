@@ -284,7 +284,14 @@ def main():
             # still measure, with the candidate record staged through the host.  (A failure inside
             # ncclCommInitRank on some ranks only cannot be recovered from: the run then fails.)
             rccl_failure = str(e)
-            sys.stderr.write("bench.py rank %d: RCCL exchange unavailable (%s); host-staged exchange instead\n" % (rank, e))
+            sys.stderr.write("bench.py rank %d: RCCL exchange unavailable (%s)\n" % (rank, e))
+        # every rank takes the same path: RCCL only if every rank has a communicator
+        oks = channel.all_gather(b"\x01" if ex is not None else b"\x00")
+        if not all(o == b"\x01" for o in oks):
+            if ex is not None:
+                ex.close()
+                ex = None
+            rccl_failure = rccl_failure or "RCCL failed on rank(s) %s" % [i for i, o in enumerate(oks) if o != b"\x01"]
             backend = "host"
     if use_dist and backend == "rccl":
         sw.set_comm(ex)                       # the all-gather now happens inside nmrfit_pso_step

@@ -1616,18 +1616,7 @@ __global__ void finalize_kernel(const double *__restrict__ partial, int64_t S, i
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
-    if (fit_im == 0) {
-        double ss = 0.0;
-        for (int64_t c = 0; c < n_chunks; ++c) ss += partial[i * n_chunks + c];
-        f[i] = sqrt(ss / (double)N);
-    } else {
-        double ss = 0.0, si = 0.0;
-        for (int64_t c = 0; c < n_chunks; ++c) {
-            ss += partial[(i * n_chunks + c) * 2];
-            si += partial[(i * n_chunks + c) * 2 + 1];
-        }
-        f[i] = 0.5 * (sqrt(ss / (double)N) + sqrt(si / (double)N));
-    }
+    f[i] = finalize_value(partial + i * n_chunks * (fit_im ? 2 : 1), n_chunks, N, fit_im);
 }
 
 // Per-peak real and imaginary contributions on an output grid (FitUtility.generate_result,

@@ -216,20 +216,8 @@ __global__ __launch_bounds__(1024) void pso_tail_kernel(TailArgs a)
     __shared__ long long s_idx[16];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nw = blockDim.x / kWave;
     if (a.phases & kTailFinalize) {   // same arithmetic and order as finalize_kernel
-        for (int64_t i = threadIdx.x; i < a.S; i += blockDim.x) {
-            if (a.fit_im == 0) {
-                double ss = 0.0;
-                for (int64_t c = 0; c < a.n_blocks; ++c) ss += a.partial[i * a.n_blocks + c];
-                a.fx[i] = sqrt(ss / (double)a.N);
-            } else {
-                double ss = 0.0, si = 0.0;
-                for (int64_t c = 0; c < a.n_blocks; ++c) {
-                    ss += a.partial[(i * a.n_blocks + c) * 2];
-                    si += a.partial[(i * a.n_blocks + c) * 2 + 1];
-                }
-                a.fx[i] = 0.5 * (sqrt(ss / (double)a.N) + sqrt(si / (double)a.N));
-            }
-        }
+        for (int64_t i = threadIdx.x; i < a.S; i += blockDim.x)
+            a.fx[i] = finalize_value(a.partial + i * a.n_blocks * (a.fit_im ? 2 : 1), a.n_blocks, a.N, a.fit_im);
         __syncthreads();
     }
     if (a.phases & kTailPbest) {
@@ -332,7 +320,10 @@ __device__ __forceinline__ void select_final(const TailArgs &a, const double *pa
 __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArgs a, double *part_val,
                                                                           long long *part_idx, unsigned *ticket)
 {
-    if (a.flags[1] != 0) return;
+    // Latency first: this kernel is a chain of dependent round trips to memory and nothing else, so
+    // everything whose address is known is requested at once -- the stop flag, the block sums, the
+    // personal best and (speculatively) the particle's row -- and only then looked at.
+    const long long stopped = a.flags[1];
     __shared__ double s_val[kSelectWaves];
     __shared__ long long s_idx[kSelectWaves];
     __shared__ int s_last;
@@ -340,33 +331,26 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
     double mine = INFINITY;
     long long mi = 0x7fffffffffffffffLL;
     for (int64_t i = (int64_t)blockIdx.x * kSelectWaves + wave; i < a.S; i += (int64_t)gridDim.x * kSelectWaves) {
+        const double fp_old = a.fp[i];
+        const double x_head = (lane < a.D) ? a.x[i * a.D + lane] : 0.0;   // the first 64 entries of the row, in case it improves
         double f;
-        if (a.phases & kTailFinalize) {   // same arithmetic and order as finalize_kernel
-            if (a.fit_im == 0) {
-                double ss = 0.0;
-                for (int64_t c = 0; c < a.n_blocks; ++c) ss += a.partial[i * a.n_blocks + c];
-                f = sqrt(ss / (double)a.N);
-            } else {
-                double ss = 0.0, si = 0.0;
-                for (int64_t c = 0; c < a.n_blocks; ++c) {
-                    ss += a.partial[(i * a.n_blocks + c) * 2];
-                    si += a.partial[(i * a.n_blocks + c) * 2 + 1];
-                }
-                f = 0.5 * (sqrt(ss / (double)a.N) + sqrt(si / (double)a.N));
-            }
-            if (lane == 0) a.fx[i] = f;
-        } else {
+        if (a.phases & kTailFinalize)   // same arithmetic and order as finalize_kernel
+            f = finalize_value(a.partial + i * a.n_blocks * (a.fit_im ? 2 : 1), a.n_blocks, a.N, a.fit_im);
+        else
             f = a.fx[i];
-        }
-        double cur = a.fp[i];
+        if (stopped != 0) return;   // (the same in every wave of the grid; nothing has been written)
+        if ((a.phases & kTailFinalize) && lane == 0) a.fx[i] = f;
+        double cur = fp_old;
         if (f < cur) {   // pyswarm: i_update = fx < fp
             if (ticket) {   // rows another workgroup of this launch may read: write-through stores
-                for (int64_t d = lane; d < a.D; d += kWave)
+                if (lane < a.D) __hip_atomic_store(a.p + i * a.D + lane, x_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int64_t d = lane + kWave; d < a.D; d += kWave)
                     __hip_atomic_store(a.p + i * a.D + d, a.x[i * a.D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (lane == 0) __hip_atomic_store(a.fp + i, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 global_stores_done();   // complete in memory before this workgroup draws its ticket
             } else {
-                for (int64_t d = lane; d < a.D; d += kWave) a.p[i * a.D + d] = a.x[i * a.D + d];
+                if (lane < a.D) a.p[i * a.D + lane] = x_head;
+                for (int64_t d = lane + kWave; d < a.D; d += kWave) a.p[i * a.D + d] = a.x[i * a.D + d];
                 if (lane == 0) a.fp[i] = f;
             }
             cur = f;
@@ -376,6 +360,7 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
             mi = i;
         }
     }
+    if (stopped != 0) return;   // (waves that had no particle to look at)
     if (lane == 0) {
         s_val[wave] = mine;
         s_idx[wave] = mi;

@@ -95,6 +95,37 @@ __device__ __forceinline__ bool lex_less(double v, long long i, double bv, long 
     return v < bv || (v == bv && i < bi);
 }
 
+// f = sqrt(mean of squares) from the objective's per-block sums, added in grid order (the canonical
+// summation order: see objective.hip).  The <= 16 (x2 with the imaginary channel) values are fetched
+// by independent loads issued together -- a loop of load-then-add is one memory round trip per block,
+// 8 to 16 of them on the critical path of kernels that have nothing else to do -- and then added
+// strictly one after another, so the value is bit-identical to the sequential loop.
+__device__ __forceinline__ double finalize_value(const double *partial, int64_t n_blocks, int64_t N, int fit_im)
+{
+    constexpr int kMax = 16;   // kMaxBlocks
+    if (fit_im == 0) {
+        double v[kMax];
+#pragma unroll
+        for (int c = 0; c < kMax; ++c) v[c] = (c < n_blocks) ? partial[c] : 0.0;
+        double ss = 0.0;
+#pragma unroll
+        for (int c = 0; c < kMax; ++c)
+            if (c < n_blocks) ss += v[c];
+        return sqrt(ss / (double)N);
+    }
+    double v[2 * kMax];
+#pragma unroll
+    for (int c = 0; c < 2 * kMax; ++c) v[c] = (c < 2 * n_blocks) ? partial[c] : 0.0;
+    double ss = 0.0, si = 0.0;
+#pragma unroll
+    for (int c = 0; c < kMax; ++c)
+        if (c < n_blocks) {
+            ss += v[2 * c];
+            si += v[2 * c + 1];
+        }
+    return 0.5 * (sqrt(ss / (double)N) + sqrt(si / (double)N));
+}
+
 // one wave: fold the candidate records, apply pyswarm's acceptance / stopping rule
 __device__ __forceinline__ void apply_wave(int lane, int64_t D, int nranks, int is_init, double minstep,
                                            double minfunc, const double *cands, long long *flags, double *best)

@@ -9,8 +9,18 @@ bench.py -- objective evaluations per second of the MI355X swarm generation.
 Either form runs one process per GPU.  With WORLD_SIZE unset and --gpus N > 1 this script is the
 launcher: before touching any GPU it starts N rank processes of itself (RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), relays rank 0's JSON line and exits non-zero if any
-rank fails.  No PyTorch in any of it: the ranks find each other over standard-library sockets
-(nmrfit_amd/rendezvous.py) and exchange through RCCL inside libnmrfit_amd.so.
+rank fails or the whole run outlives --launch-timeout (it then names the ranks still alive and
+ends exactly the processes it started).  No PyTorch in any of it: the ranks find each other over
+standard-library sockets (nmrfit_amd/rendezvous.py) and exchange through RCCL inside
+libnmrfit_amd.so.
+
+N > 1 is an RCCL measurement or it is an error: if the exchange that ran was not RCCL (library
+missing, communicator creation failing) -- and NMRFIT_BENCH_BACKEND=host was not asked for
+explicitly -- the line is still printed, measured over the host-staged exchange, but carries an
+"error" field and the exit code is 5.  Every rank also carries its own deadline (the driver
+launches the ranks under torch.distributed.run, not under this script's launcher): a rank still
+inside the rendezvous / ncclCommInitRank / the first collective after --launch-timeout seconds
+says where it is stuck on stderr and exits 124, which makes the launcher end the others.
 
 Workload (BASELINE.json configs[2] / configs[3]): 24 peaks, 65536-point grid, 4096 particles
 PER GPU (weak scaling: N GPUs evaluate a 4096*N swarm; N=8 is config C4).  One "step" is one
@@ -54,8 +64,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 SIMDS = 1024                   # 256 CUs x 4 SIMDs
 PEAK_CLOCK_MHZ = 2400.0        # MI355X_MICROARCH.md
 FP64_ISSUE_CYCLES = 4.0        # one wave64 fp64 VALU instruction occupies a SIMD's issue port for 4 cycles
-PMC_SUMMARY = os.path.join("profiles", "r02", "bench_c3_pmc_summary.json")
-PMC_SUMMARY_FALLBACK = os.path.join("profiles", "r01", "bench_c3_pmc_summary.json")
+PMC_SUMMARIES = [os.path.join("profiles", r, "bench_c3_pmc_summary.json") for r in ("r03", "r02", "r01")]
+FARFIELD_PMC_SUMMARIES = [os.path.join("profiles", "r03", "farfield_c3_pmc_summary.json")]
 
 
 def parse():
@@ -74,10 +84,14 @@ def parse():
     ap.add_argument("--preheat-seconds", type=float, default=0.5)
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the every-unit variants / far-field / host-pointer extras (PMC passes)")
-    ap.add_argument("--other-configs", action="store_true",
-                    help="also time the C2 and C5 shapes (kernel only).  Off by default so that every "
-                         "objective_kernel<0,false,0> launch of the default command has the C3 shape and the "
-                         "rocprofv3 --stats average of that kernel is the number in roofline.kernel_ms")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="do not time the C2 and C5 shapes (BASELINE configs 2 and 5; kernel only, after the timed "
+                         "region).  tools/profile.sh passes this so that every objective_kernel<0,false,0> launch of a "
+                         "profiled run has the C3 shape and the rocprofv3 --stats average of that kernel is the number "
+                         "in roofline.kernel_ms")
+    ap.add_argument("--launch-timeout", type=float, default=300.0, metavar="SECONDS",
+                    help="N > 1: deadline of the self-launcher for the whole run, and of every rank for reaching the "
+                         "timed region (rendezvous, RCCL communicator, first collective); 0 disables")
     return ap.parse_args()
 
 
@@ -90,24 +104,34 @@ def _free_port():
     return p
 
 
-def self_launch(n):
+def self_launch(n, launch_timeout):
     """Start n rank processes of this script, one per GPU.  The parent never touches the GPU (it
     loads neither the library nor HIP): it only waits, relays rank 0's output, and makes sure a
-    failed rank takes the others down instead of leaving them blocked in a collective."""
+    failed rank -- or a run that outlives `launch_timeout` seconds -- takes the others down instead
+    of leaving them blocked in a collective.  It never replaces itself or any rank with another
+    program: it ends the child processes it started, by pid, and exits."""
     port = _free_port()
     token = "bench%d_%d" % (os.getpid(), int(time.time() * 1e3) & 0xFFFFFFF)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NMRFIT_RDZV_TOKEN=token)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs on this driver
+        # (HSA_ENABLE_IPC_MODE_LEGACY=0 -- dmabuf IPC, the only kind this pool's driver offers -- is set by
+        # nmrfit_amd/_cabi.py before the library loads, for every launcher alike)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
     rc = 0
     out0 = b""
+    t_start = time.monotonic()
     try:
         pending = set(range(n))
         while pending:
+            if launch_timeout > 0 and time.monotonic() - t_start > launch_timeout:
+                alive = [r for r in sorted(pending) if procs[r].poll() is None]
+                sys.stderr.write("bench.py: launch timeout: %d rank(s) still running after %.0f s: %s -- ending them\n"
+                                 % (len(alive), launch_timeout, alive))
+                rc = 124
+                break
             for r in sorted(pending):
                 p = procs[r]
                 if r == 0:
@@ -228,7 +252,7 @@ def main():
     args = parse()
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
-        raise SystemExit(self_launch(args.gpus))
+        raise SystemExit(self_launch(args.gpus, args.launch_timeout))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(world_env or "1")
@@ -265,6 +289,32 @@ def main():
     if use_dist and (backend == "host" or os.environ.get("NMRFIT_BENCH_SHARE_GPU") == "1"):
         device = local_rank % max(1, _cabi.device_count())      # rehearsals: several ranks on one card
 
+    # Every rank's own deadline for reaching the timed region (N > 1): the driver launches the ranks
+    # under torch.distributed.run, so this script's launcher is not there to notice a rank that never
+    # comes out of the rendezvous / ncclCommInitRank / the first collective.
+    from nmrfit_amd import rendezvous
+    state = {"first": True}
+
+    try:      # looked up now: the watchdog thread must not make HIP calls while the main thread is stuck in one
+        pci = _cabi.device_pci_bus_id(device) if use_dist else "-"
+    except _cabi.NmrfitError as e:
+        pci = "unknown (%s)" % e
+
+    def where():
+        return "(HIP device %d, PCI %s, world %d)" % (device, pci, world)
+    # test hook (tests/test_rendezvous_cpu.py): NMRFIT_BENCH_TEST_STALL="pre:<rank|all>:<seconds>" makes a rank
+    # sleep before its watchdog exists (only the launcher's deadline can end it), "in:..." inside it
+    stall = os.environ.get("NMRFIT_BENCH_TEST_STALL", "").split(":")
+    stall_s = float(stall[2]) if len(stall) == 3 and stall[1] in ("all", str(rank)) else 0.0
+    if stall_s and stall[0] == "pre":
+        time.sleep(stall_s)
+    dog = rendezvous.Watchdog(args.launch_timeout if use_dist else 0, "start-up", rank=rank, describe=where)
+    dog.__enter__()
+    if stall_s and stall[0] == "in":
+        dog.phase = "test stall"
+        time.sleep(stall_s)
+
+    dog.phase = "context creation"
     ev = Evaluator(spec["w"], spec["u"], spec["v"], spec["weights"], device=device)
     ev.set_variant(args.variant)
     sw = pso.DeviceSwarm(ev, spec["lower"], spec["upper"], swarmsize=S_local * world, offset=rank * S_local,
@@ -272,20 +322,31 @@ def main():
     ex = None
     exchange_desc = "none"
     rccl_failure = None
+    rccl_info = None
     channel = None
+    host_requested = backend == "host"
     if use_dist:
-        from nmrfit_amd import rendezvous
+        dog.phase = "socket rendezvous (nmrfit_amd/rendezvous.py)"
         channel = rendezvous.Channel()        # the star of sockets the ranks bootstrap over
     if use_dist and backend == "rccl":
+        dog.phase = "RCCL communicator creation"
+        if os.environ.get("NMRFIT_BENCH_TEST_RCCL_MISSING_ON") == str(rank):   # test hook: RCCL missing on ONE rank
+            os.environ["NMRFIT_RCCL_LIB"] = "/nonexistent/librccl.so"
+        sys.stderr.write("bench.py rank %d/%d: creating the RCCL communicator on HIP device %d %s\n"
+                         % (rank, world, device, where()))
+        sys.stderr.flush()
         try:
-            ex = pso.RcclExchange(ev, channel=channel)
+            # init_timeout=0: this run's own watchdog (dog) already covers the collective creation
+            ex = pso.RcclExchange(ev, channel=channel, init_timeout=0, verbose=True)
         except _cabi.NmrfitError as e:
-            # RCCL unavailable on EVERY rank alike (library missing, no unique id): say so loudly and
-            # still measure, with the candidate record staged through the host.  (A failure inside
-            # ncclCommInitRank on some ranks only cannot be recovered from: the run then fails.)
+            # RCCL unavailable (library missing on some rank: every rank raises alike, see
+            # RcclExchange; no unique id; communicator creation failing): say so loudly and still
+            # measure, with the candidate record staged through the host -- the line then carries an
+            # "error" field and the exit code is non-zero.
             rccl_failure = str(e)
             sys.stderr.write("bench.py rank %d: RCCL exchange unavailable (%s)\n" % (rank, e))
         # every rank takes the same path: RCCL only if every rank has a communicator
+        dog.phase = "agreement on the exchange path"
         oks = channel.all_gather(b"\x01" if ex is not None else b"\x00")
         if not all(o == b"\x01" for o in oks):
             if ex is not None:
@@ -294,9 +355,15 @@ def main():
             rccl_failure = rccl_failure or "RCCL failed on rank(s) %s" % [i for i, o in enumerate(oks) if o != b"\x01"]
             backend = "host"
     if use_dist and backend == "rccl":
+        dog.phase = "first RCCL collective"
+        info = ex.info()
+        # how many ranks RCCL itself saw: an all-reduce of ones over the communicator
+        seen = int(round(float(ex.all_reduce([1.0], "sum")[0])))
+        rccl_info = {"nranks": info["world"], "ranks_counted_by_all_reduce": seen, "version": info["rccl_version"],
+                     "rank0": ex.describe()}
         sw.set_comm(ex)                       # the all-gather now happens inside nmrfit_pso_step
         exchange_desc = "ncclAllGather of %d doubles per generation inside nmrfit_pso_step (RCCL %s)" % (
-            D + 1, ex.info()["rccl_version"])
+            D + 1, info["rccl_version"])
 
         def step():
             sw.step()
@@ -304,7 +371,6 @@ def main():
         ex = pso.SocketExchange(channel=channel)
         exchange_desc = "host-staged all-gather of %d doubles per generation (sockets%s)" % (
             D + 1, "; RCCL FAILED: " + rccl_failure if rccl_failure else "; rehearsal")
-        state = {"first": True}
 
         def step():
             if not state["first"]:
@@ -320,6 +386,7 @@ def main():
         if ex is not None:
             ex.barrier()
 
+    dog.phase = "swarm init and warm-up generations"
     sw.init()
     step()                                   # folds generation 0
     for _ in range(args.warmup):
@@ -340,7 +407,9 @@ def main():
         heat_launches += 8
     ev.prof_enable(args.steps)
 
+    dog.phase = "barrier before the timed region"
     barrier()
+    dog.__exit__(None, None, None)           # every rank is here: from now on a hang is the driver's to time
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ev.prof_mark()
@@ -390,10 +459,12 @@ def main():
         farfield = {"kernel_ms": variants["farfield_ms"],
                     "units_per_s": float(S_local) * N * P / (variants["farfield_ms"] * 1e-3),
                     "max_rel_diff_vs_default": variants["farfield_max_rel_diff_vs_default"]}
-    if rank == 0 and world == 1 and args.workload == "C3" and args.other_configs:
-        others = {}
+    if rank == 0 and world == 1 and args.workload == "C3" and args.variant == 0 and args.other_configs:
+        others = {"note": "BASELINE configs 2 (C2) and 5 (C5): kernel only (HIP events around 50 launches after 5 "
+                          "warm-up launches), after the timed region"}
         for name in ("C2", "C5"):
             c = synth.CONFIGS[name]
+            ev.synchronize()
             sp2 = synth.make_spectrum(c.N, c.P, seed=1)
             if name == "C5":      # D+1 rows of a forward-difference Jacobian, residual vectors out
                 X2, _ = synth.jacobian_rows(synth.make_swarm(sp2["lower"], sp2["upper"], 2, seed=4)[1])
@@ -414,9 +485,19 @@ def main():
                 for _ in range(50):
                     run()
                 ms2 = ev2.timer_end() / 50
+                D2 = 4 + 3 * c.P
+                # every row streams w, u, v, weights once (+ its parameters and result);
+                # C5 also writes its residual row
+                bytes2 = B * (4 * c.N * 8) + B * D2 * 8 + B * 8 + (B * c.N * 8 if name == "C5" else 0)
                 others[name] = {"shape": {"rows": B, "grid": c.N, "peaks": c.P}, "kernel_ms": ms2,
                                 "units_per_s": float(B) * c.N * c.P / (ms2 * 1e-3),
-                                "kind": "residual_batch (R rows written)" if name == "C5" else "objective_batch"}
+                                "kind": "residual_batch (R rows written)" if name == "C5" else "objective_batch",
+                                "roofline": {"bound": "hbm", "bytes_per_launch": bytes2,
+                                             "achieved": bytes2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": bytes2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "model": "streaming-operand bytes (effective rate, as in `roofline`); "
+                                                      "these launches are latency-bound: a few microseconds of "
+                                                      "wave critical path, not bandwidth or issue rate"}}
                 ev2.dev_free(dX2)
                 ev2.dev_free(df2)
                 if dR2 is not None:
@@ -451,7 +532,7 @@ def main():
                 traffic = None
         valu = {"bound": "fp64_valu_issue", "unit": "fraction of fp64 VALU issue slots (1024 SIMDs x 2.4 GHz / 4 cycles "
                                                      "per wave64 instruction)"}
-        summ = next((p for p in (PMC_SUMMARY, PMC_SUMMARY_FALLBACK) if os.path.exists(os.path.join(ROOT, p))), None)
+        summ = next((p for p in PMC_SUMMARIES if os.path.exists(os.path.join(ROOT, p))), None)
         if args.workload == "C3" and args.variant == 0 and summ:
             try:
                 sm = json.load(open(os.path.join(ROOT, summ)))
@@ -502,11 +583,42 @@ def main():
             line["error"] = "objective kernel (%.4f ms) longer than the step that contains it (%.4f ms)" % (
                 t_kernel_ms, ms_per_step)
             rc = 3
+        if world > 1 or use_dist:
+            # how many ranks RCCL itself saw (null: the exchange that ran was not RCCL)
+            line["rccl"] = rccl_info
+        if world > 1 and rccl_info is None and not host_requested:
+            line["error"] = ("N = %d did not run over RCCL (%s): `value` was measured with the candidate record "
+                             "staged through the host and is NOT an RCCL scaling number" % (world, rccl_failure))
+            rc = 5
+        elif world > 1 and rccl_info is not None and rccl_info["ranks_counted_by_all_reduce"] != world:
+            line["error"] = "RCCL counted %d ranks, expected %d" % (rccl_info["ranks_counted_by_all_reduce"], world)
+            rc = 5
         if ranks is not None:
             line["ranks"] = ranks
         if variants is not None:
             line["variants"] = variants
             line["farfield_variant"] = farfield
+            # the kernel nmrfit_amd.fit() itself picks at this problem size (utils.default_variant):
+            # measured here beside the headline, never `value`
+            from nmrfit_amd.utils import default_variant
+            dv = default_variant(N, P)
+            fd = {"variant": dv, "kernel_ms": variants[dv + "_ms"],
+                  "units_per_s": units_launch / (variants[dv + "_ms"] * 1e-3),
+                  "max_rel_diff_vs_default": variants[dv + "_max_rel_diff_vs_default"],
+                  "note": "what fit() runs when options['variant'] is absent at this grid x peaks; kernel alone, "
+                          "this run"}
+            fsum = next((q for q in FARFIELD_PMC_SUMMARIES if os.path.exists(os.path.join(ROOT, q))), None)
+            if dv == "farfield" and args.workload == "C3" and fsum:
+                try:
+                    fm = json.load(open(os.path.join(ROOT, fsum)))
+                    fi = fm["objective_kernel_pmc"]["SQ_INSTS_VALU"]["mean"]
+                    fd.update({"valu_instructions_per_unit": fi * 64.0 / (4096.0 * 65536.0 * 24.0),
+                               "valu_busy": fm.get("valu_busy_frac"),
+                               "valu_cycles_per_instruction": fm.get("valu_cycles_per_inst"),
+                               "from_committed_profile": True, "pmc_source": fsum})
+                except Exception as e:
+                    fd["pmc_error"] = repr(e)
+            line["fit_default"] = fd
         if others:
             line["other_configs"] = others
         if host_ms is not None:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NMRFIT_ABI_VERSION 2
+#define NMRFIT_ABI_VERSION 3
 
 enum {
     NMRFIT_OK = 0,
@@ -89,6 +89,9 @@ const char *nmrfit_last_error(void);
 int nmrfit_device_count(int *count);
 /* name (<= len-1 chars), compute units, and gcnArchName of a device */
 int nmrfit_device_info(int device, char *name, int name_len, int *compute_units, char *arch, int arch_len);
+/* PCI bus id ("0000:c1:00.0") of a device: what a multi-GPU launch prints per rank so that a
+ * failed first contact can be traced to a card (len >= 16) */
+int nmrfit_device_pci_bus_id(int device, char *buf, int len);
 
 /* ---- context: the per-fit constant arrays ---------------------------------------------
  * Replaces the `args=(data.w, data.u, data.v, weights, fit_im)` tuple that
@@ -186,15 +189,23 @@ int nmrfit_pso_apply_global_dev(nmrfit_pso *pso, const double *d_candidates, int
 int nmrfit_pso_status(nmrfit_pso *pso, int64_t *iteration, int32_t *stop_code, double *fg);
 /* best position (D doubles) and value; after a stop these are pyswarm's return values */
 int nmrfit_pso_best(nmrfit_pso *pso, double *x_best, double *f_best);
-/* single-rank convenience: init (if needed) + up to maxiter generations, polling the stop
- * flag every `check_every` generations (generations after a stop are no-ops on the GPU). */
+/* init (if needed) + up to maxiter generations, polling the stop flag every `check_every`
+ * generations (generations after a stop are no-ops on the GPU); with a communicator attached
+ * every rank makes the same call. */
 int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every);
-/* Opt-in: run `check_every` generations of nmrfit_pso_run inside ONE cooperative launch (persistent
- * workgroups that own their particles, one grid-wide exchange per generation through agent-scope
- * atomics).  Only single-rank swarms small enough for one workgroup per particle qualify (others
- * silently keep the launch-per-phase path); results are bit-identical either way.  Off by default:
- * measured 15.3 vs 15.2 us per generation at 204 x 4096 x 6. */
-int nmrfit_pso_set_persistent(nmrfit_pso *pso, int enable);
+/* How the workgroups of the personal-best / argmin kernel hand their results to the workgroup that
+ * finishes the reduction (swarms of up to 1024 particles do it inside ONE launch; the swarm loop
+ * replacing nmrfit/utils.py:176-182).  Results are bit-identical in every mode.
+ *   FAST (default)  agent-scope write-through atomic stores ordered by s_waitcnt vmcnt(0): no L2
+ *                   write-back per workgroup (6.7 us instead of 8.8 us per select at 51 workgroups)
+ *   FENCED          release / acquire fences at agent scope: the textbook form, kept as the A/B
+ *                   reference for FAST (tools/handover_stress.py); NMRFIT_SAFE_HANDOVER=1 in the
+ *                   environment makes it the default of every swarm created afterwards
+ *   TWO_LAUNCH      no hand-over inside a launch: the reduction is its own launch (what larger
+ *                   swarms use anyway)
+ * Never switched automatically. */
+enum { NMRFIT_HANDOVER_FAST = 0, NMRFIT_HANDOVER_FENCED = 1, NMRFIT_HANDOVER_TWO_LAUNCH = 2 };
+int nmrfit_pso_set_handover(nmrfit_pso *pso, int mode);
 /* copy swarm state to host for inspection/tests (any pointer may be NULL):
  * x, v, p are S_local x D; fx, fp are S_local */
 int nmrfit_pso_get_state(nmrfit_pso *pso, double *x, double *v, double *p, double *fx, double *fp);
@@ -210,12 +221,20 @@ int nmrfit_pso_get_state(nmrfit_pso *pso, double *x, double *v, double *p, doubl
  * bytes to the other ranks by any means (the Python side: stdlib sockets,
  * nmrfit_amd/rendezvous.py); then EVERY rank calls nmrfit_comm_create (collective). */
 #define NMRFIT_UNIQUE_ID_BYTES 128
+/* NMRFIT_OK if RCCL can be loaded (dlopen + every symbol used), NMRFIT_E_UNSUPPORTED with the reason
+ * in nmrfit_last_error() otherwise.  Creates nothing and touches no GPU: every rank calls it and the
+ * ranks compare notes BEFORE anyone enters the collective nmrfit_comm_create, so that RCCL missing
+ * on one node is an error on every rank instead of a hang on the others. */
+int nmrfit_comm_available(void);
 int nmrfit_comm_unique_id(void *out128);
 int nmrfit_comm_create(nmrfit_ctx *ctx, int32_t rank, int32_t nranks, const void *unique_id128,
                        nmrfit_comm **out);
+/* NMRFIT_E_STATE while a swarm still has the communicator attached (detach or destroy it first) */
 int nmrfit_comm_destroy(nmrfit_comm *comm);
 /* rank, size and the RCCL version code (any pointer may be NULL) */
 int nmrfit_comm_info(const nmrfit_comm *comm, int32_t *rank, int32_t *nranks, int32_t *rccl_version);
+/* one line for logs: "rank R of N, HIP device D, PCI 0000:xx:00.0, RCCL V" */
+int nmrfit_comm_describe(const nmrfit_comm *comm, char *buf, int len);
 /* all-gather of n doubles per rank between device buffers, asynchronous on the context's stream */
 int nmrfit_comm_all_gather_dev(nmrfit_comm *comm, const double *d_send, double *d_recv, int64_t n);
 /* bookkeeping collectives on HOST values (1..64 doubles; op 0 sum, 1 max, 2 min), a broadcast
@@ -225,7 +244,8 @@ int nmrfit_comm_broadcast_host(nmrfit_comm *comm, void *buf, int64_t bytes, int3
 int nmrfit_comm_barrier(nmrfit_comm *comm);
 /* Attach a communicator to a sharded swarm (NULL detaches).  With one attached,
  * nmrfit_pso_step / nmrfit_pso_run include the exchange: every rank of the communicator must
- * make the same calls. */
+ * make the same calls.  The communicator must have been created on the swarm's own context
+ * (NMRFIT_E_INVALID otherwise: the all-gather is enqueued on that context's stream). */
 int nmrfit_pso_set_comm(nmrfit_pso *pso, nmrfit_comm *comm);
 /* One whole generation in one call, no Python in the loop: position update -> objective ->
  * personal bests -> local candidate -> [all-gather over the attached communicator] -> fold with

@@ -19,6 +19,8 @@ UNIQUE_ID_BYTES = 128
 FIT_IM_OFF, FIT_IM_REFERENCE, FIT_IM_SUM = 0, 1, 2
 VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED, VARIANT_FARFIELD = 0, 1, 2, 3, 4, 5, 6
 VARIANT_NOREC = 7
+HANDOVER_FAST, HANDOVER_FENCED, HANDOVER_TWO_LAUNCH = 0, 1, 2
+ABI_VERSION = 3
 _VARIANT_NAMES = {"default": 0, "baseline": 1, "noskip": 2, "single": 3, "quad": 4, "staged": 5, "farfield": 6,
                   "norec": 7}
 
@@ -86,8 +88,11 @@ SIGNATURES = {
     "nmrfit_pso_status": [_VP, ctypes.POINTER(_I64), ctypes.POINTER(_I32), _c_double_p],
     "nmrfit_pso_best": [_VP, _VP, _c_double_p],
     "nmrfit_pso_run": [_VP, _I64, _I32],
-    "nmrfit_pso_set_persistent": [_VP, _INT],
+    "nmrfit_pso_set_handover": [_VP, _INT],
     "nmrfit_pso_get_state": [_VP, _VP, _VP, _VP, _VP, _VP],
+    "nmrfit_device_pci_bus_id": [_INT, ctypes.c_char_p, _INT],
+    "nmrfit_comm_available": [],
+    "nmrfit_comm_describe": [_VP, ctypes.c_char_p, _INT],
     "nmrfit_comm_unique_id": [_VP],
     "nmrfit_comm_create": [_VP, _I32, _I32, _VP, _c_void_pp],
     "nmrfit_comm_destroy": [_VP],
@@ -123,6 +128,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NmrfitError(E_NO_DEVICE, "%s not found: build it with nmrfit_amd/csrc/build.sh "
                               "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        # One process per GPU, several per node: the ROCm driver of the machines this runs on offers
+        # dmabuf IPC only, and RCCL's intra-node transport (hipIpcGetMemHandle) fails with "invalid
+        # argument" unless the HSA runtime is told so BEFORE it initialises -- i.e. before the first
+        # HIP call this library makes.  A value the user exported wins.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         L = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
@@ -156,6 +166,12 @@ def device_count():
         return 0
     check(rc)
     return n.value
+
+
+def device_pci_bus_id(device=0):
+    buf = ctypes.create_string_buffer(64)
+    check(lib().nmrfit_device_pci_bus_id(device, buf, 64))
+    return buf.value.decode()
 
 
 def device_info(device=0):

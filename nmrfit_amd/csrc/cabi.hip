@@ -118,6 +118,23 @@ int nmrfit_device_info(int device, char *name, int name_len, int *compute_units,
     return NMRFIT_OK;
 }
 
+int nmrfit_device_pci_bus_id(int device, char *buf, int len)
+{
+    int n = 0;
+    int rc = nmrfit_device_count(&n);
+    if (rc != NMRFIT_OK) return rc;
+    if (device < 0 || device >= n) {
+        set_error("device index out of range");
+        return NMRFIT_E_NO_DEVICE;
+    }
+    if (!buf || len < 16) {
+        set_error("nmrfit_device_pci_bus_id: buffer of at least 16 bytes");
+        return NMRFIT_E_INVALID;
+    }
+    NMRFIT_HIP(hipDeviceGetPCIBusId(buf, len, device));
+    return NMRFIT_OK;
+}
+
 int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, const double *v,
                       const double *weights, nmrfit_ctx **out)
 {

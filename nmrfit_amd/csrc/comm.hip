@@ -29,6 +29,7 @@ struct nmrfit_comm {
     int64_t scratch_cap = 0;           // doubles
     double *d_gather = nullptr;        // candidate all-gather: nranks x (D+1), grown on demand
     int64_t gather_cap = 0;
+    int attached = 0;                  // swarms that point at this communicator (nmrfit_pso_set_comm)
 };
 
 namespace nmrfit {
@@ -121,6 +122,12 @@ int bind_comm(const nmrfit_comm *c)
 
 }  // namespace
 
+nmrfit_ctx *comm_ctx(const nmrfit_comm *c) { return c ? c->ctx : nullptr; }
+void comm_attach(nmrfit_comm *c, int delta)
+{
+    if (c) c->attached += delta;
+}
+
 // used by pso.hip: gather every rank's (D+1)-double record on the context's stream.
 // d_send may be any device buffer; *d_all receives a pointer to nranks x n doubles in rank order.
 int comm_all_gather(nmrfit_comm *c, const double *d_send, int64_t n, const double **d_all)
@@ -145,6 +152,13 @@ int comm_all_gather(nmrfit_comm *c, const double *d_send, int64_t n, const doubl
 using namespace nmrfit;
 
 extern "C" {
+
+int nmrfit_comm_available(void)
+{
+    // dlopen + every symbol the library uses; no communicator, no GPU work.  Lets every rank find
+    // out -- and tell the others -- BEFORE anyone enters the collective ncclCommInitRank.
+    return load_rccl();
+}
 
 int nmrfit_comm_unique_id(void *out128)
 {
@@ -204,6 +218,11 @@ int nmrfit_comm_create(nmrfit_ctx *ctx, int32_t rank, int32_t nranks, const void
 int nmrfit_comm_destroy(nmrfit_comm *c)
 {
     if (!c) return NMRFIT_OK;
+    if (c->attached > 0) {
+        set_error("nmrfit_comm_destroy: a swarm still uses this communicator (nmrfit_pso_set_comm(pso, NULL) or "
+                  "nmrfit_pso_destroy first)");
+        return NMRFIT_E_STATE;
+    }
     if (c->ctx) {
         (void)hipSetDevice(c->ctx->device);
         (void)hipStreamSynchronize(c->ctx->stream);
@@ -228,6 +247,21 @@ int nmrfit_comm_info(const nmrfit_comm *c, int32_t *rank, int32_t *nranks, int32
         if (g_rccl.GetVersion) (void)g_rccl.GetVersion(&v);
         *rccl_version = v;
     }
+    return NMRFIT_OK;
+}
+
+int nmrfit_comm_describe(const nmrfit_comm *c, char *buf, int len)
+{
+    if (!c || !c->ctx || !buf || len < 1) {
+        set_error("nmrfit_comm_describe: null communicator or buffer");
+        return NMRFIT_E_INVALID;
+    }
+    char pci[64] = "?";
+    (void)hipDeviceGetPCIBusId(pci, (int)sizeof pci, c->ctx->device);
+    int v = 0;
+    if (g_rccl.GetVersion) (void)g_rccl.GetVersion(&v);
+    snprintf(buf, (size_t)len, "rank %d of %d, HIP device %d, PCI %s, RCCL %d", (int)c->rank, (int)c->nranks,
+             c->ctx->device, pci, v);
     return NMRFIT_OK;
 }
 

@@ -18,6 +18,8 @@ constexpr int kBlock = kWave * kWavesPerBlock;
 #endif
 constexpr int kPointsPerLane = NMRFIT_POINTS;    // grid points register-blocked per lane per chunk
 constexpr int kChunk = kWave * kPointsPerLane;   // 512 grid points per wave per chunk
+constexpr int kMaxBlocks = 16;       // blocks per grid: the unit of the canonical summation order and of the phase
+                                     // re-seeding (blk_chunks = ceil(n_chunks / 16)); objective.hip, pso_update.h
 constexpr int kMaxPeaks = 1000;      // LDS: 4 waves x P x (32 B PeakLor + 8 B PeakWin [+ 16 B recurrence + 32 B PeakFast,
                                      // dropped above P ~ 450]) + 1 KiB of block seeds <= 160 KiB
 
@@ -107,29 +109,13 @@ struct PsoFused;
 constexpr int64_t kFusedMaxD = 400;   // 4 waves x D doubles of LDS for the updated rows (12.5 KiB at the limit)
 int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df, double *dR,
                      ObjectiveDeferred *defer = nullptr, const PsoFused *fused = nullptr);
-// What the persistent generation kernel needs of a swarm (pso.hip owns the buffers).
-struct SwarmView {
-    int64_t S = 0, offset = 0;
-    int32_t P = 0;
-    double *x = nullptr, *v = nullptr, *p = nullptr, *fx = nullptr, *fp = nullptr, *best = nullptr, *cand = nullptr;
-    long long *flags = nullptr;
-    const double *lb = nullptr, *ub = nullptr;
-    uint64_t seed = 0;
-    double omega = 0, phip = 0, phig = 0, minstep = 0, minfunc = 0;
-    unsigned long long epoch_base = 0;     // generations already posted through post_idx (tags never repeat)
-    double *post_val = nullptr;            // [2][max_posts]
-    long long *post_idx = nullptr;
-    int64_t max_posts = 0;
-    int *err = nullptr;
-};
-// `generations` whole swarm generations in ONE cooperative launch (single-rank swarms small enough
-// to be latency-bound); *launched tells whether the swarm qualified.
-int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bool *launched);
 int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need);
 // centred grid + per-chunk (min,max) table from the raw device copy of w
 int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw);
 // gather every rank's n-double record over the communicator (comm.hip), on the context's stream
 int comm_all_gather(nmrfit_comm *c, const double *d_send, int64_t n, const double **d_all);
+nmrfit_ctx *comm_ctx(const nmrfit_comm *c);       // the context a communicator was created on
+void comm_attach(nmrfit_comm *c, int delta);      // swarms attached to it (destroy order guard)
 // per-peak real/imag contributions on a (centred) output grid resident on the device
 int launch_contributions(nmrfit_ctx *ctx, int32_t P, const double *dx, int64_t Nout, const double *d_wc_out,
                          double *d_real, double *d_imag);

@@ -76,7 +76,6 @@ constexpr int kFarTerms = 16;      // Taylor terms of the far-field expansion (r
 constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coefficient scratch in LDS:
                                    // lane l sits at column l + l/16, which makes the transposed
                                    // quarter-row reads below bank-conflict free
-constexpr int kMaxBlocks = 16;     // blocks per grid (blk_chunks = ceil(n_chunks/16))
 constexpr size_t kSharedPrologueBytes = ((2 + 2 * kWave) * sizeof(double) + 16 * sizeof(int) + 15) & ~(size_t)15;
 constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
 
@@ -389,8 +388,17 @@ __device__ __forceinline__ void lorentz_group_fast(const PeakFast *r, const doub
 __device__ __forceinline__ void lorentz_one_fast(const PeakFast *r, const double (&wv)[kPointsPerLane],
                                                  double (&acc)[kPointsPerLane])
 {
-    static_assert(kPointsPerLane % 4 == 0, "four points per reciprocal");
     const double ih = r->ihs, c = r->cs, ia = r->ia;
+    if constexpr (kPointsPerLane % 4 != 0) {   // NMRFIT_POINTS=2 (A/B builds): two points per reciprocal
+#pragma unroll
+        for (int q0 = 0; q0 < kPointsPerLane; q0 += 2) {
+            const double t0 = __builtin_fma(wv[q0], ih, c), t1 = __builtin_fma(wv[q0 + 1], ih, c);
+            const double s0 = __builtin_fma(t0, t0, ia), s1 = __builtin_fma(t1, t1, ia);
+            const double rr = rcp64(s0 * s1);
+            acc[q0] = __builtin_fma(rr, s1, acc[q0]);
+            acc[q0 + 1] = __builtin_fma(rr, s0, acc[q0 + 1]);
+        }
+    } else
 #pragma unroll
     for (int q0 = 0; q0 < kPointsPerLane; q0 += 4) {
         double s[4];
@@ -428,8 +436,17 @@ __device__ __forceinline__ void lorentz_tail_fast(int n, const PeakFast *r, cons
 __device__ __forceinline__ void lorentz_one(const PeakLor *r, const double (&wv)[kPointsPerLane],
                                             double (&acc)[kPointsPerLane])
 {
-    static_assert(kPointsPerLane % 4 == 0, "four points per reciprocal");
     const double ih = r->ihw, c = r->c, al = r->al;
+    if constexpr (kPointsPerLane % 4 != 0) {   // NMRFIT_POINTS=2 (A/B builds): two points per reciprocal
+#pragma unroll
+        for (int q0 = 0; q0 < kPointsPerLane; q0 += 2) {
+            const double t0 = __builtin_fma(wv[q0], ih, c), t1 = __builtin_fma(wv[q0 + 1], ih, c);
+            const double s0 = __builtin_fma(t0, t0, 1.0), s1 = __builtin_fma(t1, t1, 1.0);
+            const double rr = al * rcp64(s0 * s1);
+            acc[q0] = __builtin_fma(rr, s1, acc[q0]);
+            acc[q0 + 1] = __builtin_fma(rr, s0, acc[q0 + 1]);
+        }
+    } else
 #pragma unroll
     for (int q0 = 0; q0 < kPointsPerLane; q0 += 4) {
         double s[4];
@@ -526,10 +543,6 @@ __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *r
 // ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
 // With the imaginary part the epilogue also evaluates dispersion lines (Dawson polynomials):
 // 2 waves per SIMD rather than spilling.
-// PERSIST: the same body called from the persistent generation kernel below -- the task index
-// comes from the caller, the position update is done in place (all waves of a particle sit in
-// this workgroup and meet at a barrier between reading the old row and writing the new one) and
-// the per-block sums go to LDS (`psums`) instead of global memory.
 #define NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)                                                                    \
     ((FIT_IM) != 0 ? 2                                                                                                 \
                    : ((VARIANT) == NMRFIT_VARIANT_DEFAULT || (VARIANT) == NMRFIT_VARIANT_NOSKIP ||                     \
@@ -537,7 +550,7 @@ __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *r
                       (VARIANT) == NMRFIT_VARIANT_NOREC)                                                               \
                          ? NMRFIT_MIN_WAVES                                                                            \
                          : 4)
-template <int VARIANT, bool WRITE_R, int FIT_IM, bool PERSIST, int WPB>   // WPB: waves per workgroup (LDS slices)
+template <int VARIANT, bool WRITE_R, int FIT_IM>
 __device__ __forceinline__ void objective_body(
     unsigned char *lds_raw, const int64_t g,
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
@@ -548,9 +561,9 @@ __device__ __forceinline__ void objective_body(
     double *__restrict__ R_out,     // WRITE_R: residual rows [S*N]
     unsigned long long *__restrict__ clk,   // profiling only (else null): shader / reference clock of workgroup 0
     const PsoFused &upd,            // swarm generations: advance the particle first (x_in != null), X is then unused
-    const unsigned aux_off,         // FIT_IM == 2: byte offset of the Dawson table in dynamic LDS
-    double *psums)                  // PERSIST: this particle's per-block sums in LDS [n_blocks] (x2 with FIT_IM)
+    const unsigned aux_off)         // FIT_IM == 2: byte offset of the Dawson table in dynamic LDS
 {
+    constexpr int WPB = kWavesPerBlock;   // waves per workgroup = LDS slices
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     // When every wave of the workgroup evaluates a segment of the SAME particle (nseg a multiple of
@@ -559,7 +572,7 @@ __device__ __forceinline__ void objective_body(
     // per-peak constants by the waves in turn (64 peaks a pass), the phase seeds by the last wave --
     // and a workgroup barrier.  For a short grid the prologue is as long as a chunk or two, so this
     // is what makes four or eight segments per particle affordable (C2: 17.7 -> see DESIGN.md).
-    const bool shared = PERSIST ? (nseg == WPB) : (nseg % WPB == 0);
+    const bool shared = (nseg % WPB == 0);
     const int slice = shared ? 0 : wave;
     PeakLor *lor = reinterpret_cast<PeakLor *>(lds_raw) + (size_t)slice * P;
     PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)WPB * P * sizeof(PeakLor)) +
@@ -683,50 +696,6 @@ __device__ __forceinline__ void objective_body(
         // writes it (and the velocity) to the swarm's other state buffer -- never the one being
         // read, so the segments of a particle cannot race.  After a stop every launch is a no-op:
         // the row is carried over unchanged and the kernel returns.
-        if constexpr (PERSIST) {
-            if (shared) {
-                // the workgroup is this particle's only reader and writer: wave 0 updates in place
-                if (wave == 0)
-                    for (int64_t d = lane; d < D; d += kWave) {
-                        const int64_t idx = particle * D + d;
-                        double xn = 0.0, vn = 0.0;
-                        if (active) {
-                            double rp, rg;
-                            uniform2(upd.seed, upd.gen, (uint32_t)d, (uint64_t)(upd.offset + particle), &rp, &rg);
-                            xn = update_value(upd.x_in[idx], upd.v_in[idx], upd.p[idx], upd.best[2 + d], upd.lb[d],
-                                              upd.ub[d], rp, rg, upd.omega, upd.phip, upd.phig, &vn);
-                            upd.x_out[idx] = xn;
-                            upd.v_out[idx] = vn;
-                        }
-                        xrow[d] = xn;
-                    }
-                if (upd.trace && g == 0 && lane == 0) upd.trace[9] = __builtin_amdgcn_s_memrealtime();
-                __syncthreads();
-            } else {
-            // in place: the workgroup owns every segment of its particles, so "all old rows read"
-            // is one workgroup barrier away; the caller has left the loop on a stop
-            double *vrow = xrow + (size_t)WPB * D;
-            for (int64_t d = lane; d < D; d += kWave) {
-                const int64_t idx = particle * D + d;
-                double xn = 0.0, vn = 0.0;
-                if (active) {
-                    double rp, rg;
-                    uniform2(upd.seed, upd.gen, (uint32_t)d, (uint64_t)(upd.offset + particle), &rp, &rg);
-                    xn = update_value(upd.x_in[idx], upd.v_in[idx], upd.p[idx], upd.best[2 + d], upd.lb[d], upd.ub[d],
-                                      rp, rg, upd.omega, upd.phip, upd.phig, &vn);
-                }
-                xrow[d] = xn;
-                vrow[d] = vn;
-            }
-            if (upd.trace && g == 0 && lane == 0) upd.trace[9] = __builtin_amdgcn_s_memrealtime();
-            __syncthreads();
-            if (active && seg == 0)
-                for (int64_t d = lane; d < D; d += kWave) {
-                    upd.x_out[particle * D + d] = xrow[d];
-                    upd.v_out[particle * D + d] = vrow[d];
-                }
-            }
-        } else {
         const bool stopped = upd.flags[1] != 0;
         const uint32_t gen = (uint32_t)(upd.flags[0] + 1);
         if (!shared || wave == 0)
@@ -747,7 +716,6 @@ __device__ __forceinline__ void objective_body(
         }
         if (stopped) return;   // the same for every wave of the grid
         if (shared) __syncthreads();   // wave 0's row is every wave's input
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
     }
     double rr = 1.0, ri = 0.0, lr = 1.0, li = 0.0;   // rotation step exp(i p1 64/N), lane seed exp(i (p0 + p1 lane/N))
@@ -786,7 +754,6 @@ __device__ __forceinline__ void objective_body(
         __syncthreads();
     }
     if (!active) return;
-    if (PERSIST && upd.trace && g == 0 && lane == 0) upd.trace[10] = __builtin_amdgcn_s_memrealtime();
 
     const int64_t j0 = (int64_t)seg * seg_len;
     const int64_t j1 = (j0 + seg_len < N) ? j0 + seg_len : N;
@@ -816,7 +783,6 @@ __device__ __forceinline__ void objective_body(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
     }
     const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
-    if (PERSIST && upd.trace && g == 0 && lane == 0) upd.trace[11] = __builtin_amdgcn_s_memrealtime();
     double bs = 0.0, bs_im = 0.0;             // per-lane sums of squares of the current block
     const int64_t blk0 = j0 / blk_len;         // global index of this segment's first block
     int cib = 0, bidx = 0;                     // chunk within block, block within segment
@@ -861,17 +827,6 @@ __device__ __forceinline__ void objective_body(
         }
         double wv[kPointsPerLane], acc[kPointsPerLane];
         double uq[kPointsPerLane], vq[kPointsPerLane], tq[kPointsPerLane];
-        if constexpr (PERSIST) {
-            // one wave per SIMD and registers to spare: all four arrays of the chunk in one round trip
-            // (the multi-wave kernel keeps u, v, weights below the peak loop instead, see there)
-#pragma unroll
-            for (int q = 0; q < kPointsPerLane; ++q) {
-                const bool ok = full || jl + q * kWave < j1;
-                uq[q] = ok ? u[jl + q * kWave] : 0.0;
-                vq[q] = ok ? v[jl + q * kWave] : 0.0;
-                tq[q] = ok ? wt[jl + q * kWave] : 0.0;
-            }
-        }
         if (kStage) {
             // w of this chunk was prefetched into registers during the previous epilogue
 #pragma unroll
@@ -1232,7 +1187,7 @@ __device__ __forceinline__ void objective_body(
 
         // keep the u/v/weights loads below the peak loop: hoisted, they would hold 48 VGPRs
         // across it
-        if constexpr (!PERSIST) asm volatile("" ::: "memory");
+        asm volatile("" ::: "memory");
         if (kStage) {
             if (full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk has landed
             // prefetch w of the next chunk into registers (the per-peak constants are dead here)
@@ -1252,8 +1207,6 @@ __device__ __forceinline__ void objective_body(
                 vq[q] = stage[kChunk + q * kWave + lane];
                 tq[q] = stage[2 * kChunk + q * kWave + lane];
             }
-        } else if constexpr (PERSIST) {
-            // loaded at the top of the chunk
         } else if (full) {
             const double *up = u + jl, *vp = v + jl, *tp = wt + jl;
 #pragma unroll
@@ -1301,16 +1254,7 @@ __device__ __forceinline__ void objective_body(
             bs = 0.0;
             bs_im = 0.0;
             cib = 0;
-            if constexpr (PERSIST) {
-                if (lane == 0) {
-                    if (FIT_IM == 0) {
-                        psums[blk0 + bidx] = cs;
-                    } else {
-                        psums[2 * (blk0 + bidx)] = cs;
-                        psums[2 * (blk0 + bidx) + 1] = cs_im;
-                    }
-                }
-            } else if (nseg == 1) {
+            if (nseg == 1) {
                 ss += cs;
                 ss_im += cs_im;
             } else if (lane == 0) {
@@ -1348,12 +1292,11 @@ __device__ __forceinline__ void objective_body(
     else
         chunk_loop(std::false_type{});
 
-    if (PERSIST && upd.trace && g == 0 && lane == 0) upd.trace[12] = __builtin_amdgcn_s_memrealtime();
     if (clk && g == 0 && lane == 0) {
         clk[2] = __builtin_amdgcn_s_memtime();
         clk[3] = __builtin_amdgcn_s_memrealtime();
     }
-    if (!PERSIST && nseg == 1 && lane == 0) {
+    if (nseg == 1 && lane == 0) {
         if (FIT_IM == 0)
             out[particle] = sqrt(ss / (double)N);
         else   // (rmse_real + rmse_imag) / 2, equations.py:205-209
@@ -1371,242 +1314,8 @@ __global__ __launch_bounds__(kBlock, NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    objective_body<VARIANT, WRITE_R, FIT_IM, false, kWavesPerBlock>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg,
-                                                    seg_len, blk_chunks, lane_step, rec_devk, out, R_out, clk, upd,
-                                                    aux_off, nullptr);
-}
-
-// ---- persistent generations (small single-rank swarms) --------------------------------------------
-// A small swarm is latency-bound: at the reference's default of 204 particles a generation is
-// ~1 us of arithmetic inside two launches of ~9 us each, almost all of it dependent round trips
-// to memory and kernel start/finish.  Here ONE cooperative launch runs many generations: every
-// workgroup owns the same particles for the whole launch (all segments of a particle in one
-// workgroup), advances and evaluates them, updates their personal bests, and posts its
-// (best value, index); the workgroups meet at one grid barrier per generation, every workgroup
-// then folds ALL posts identically (lexicographic minimum = np.argmin), fetches the winner's row
-// and applies pyswarm's acceptance / stopping rule to its own LDS copy of (g, fg).  What crosses
-// workgroups -- the posts, the arrival counter and personal-best rows -- moves through
-// agent-scope atomic stores / loads (write-through, coherent across the 8 XCDs) instead of
-// release fences: a fence is an L2 write-back per workgroup on this part and costs 8 us per
-// exchange at 51 workgroups, 30 us at 204; the atomic form 1.8 us and 3.9 us
-// (tools/barrier_probe.hip).  Every spin gives up after 0.2 s, and the launch is cooperative (the
-// runtime refuses a grid that cannot be co-resident), so a mistake cannot hang the GPU.
-struct GenArgs {
-    const double *wc, *u, *v, *wt;
-    const double2 *chunk_minmax;
-    int64_t S, N;
-    int P, nseg, blk_chunks;
-    int64_t seg_len;
-    double w0, wspan, lane_step, rec_devk;
-    // swarm state (global) and parameters
-    double *x, *v_, *p, *fx, *fp, *best, *cand;
-    long long *flags;
-    const double *lb, *ub;
-    uint64_t seed;
-    int64_t offset;
-    double omega, phip, phig, minstep, minfunc;
-    // exchange
-    unsigned long long epoch_base;   // generations posted by earlier launches: tags never repeat
-    double *post_val;            // [2][gridDim.x]  best personal-best value of the workgroup's particles
-    long long *post_idx;         // [2][gridDim.x]  tag: epoch << 32 | particle index (2^32 - 1: none)
-    int *err;                    // set to 1 if a post never arrived
-    int generations;
-    unsigned xrow_off, sums_off, state_off, aux_off;   // byte offsets into dynamic LDS
-    unsigned long long *trace;   // NMRFIT_PERSIST_TRACE: phase time stamps of workgroup 0 (100 MHz ticks), else null
-};
-
-// Waves per workgroup of the persistent kernel = the most segments a particle's grid is cut into.
-// Measured on 204 x 4096 x 6 (tools/persist_probe.py, NMRFIT_PERSIST_TRACE): 4 waves, one per SIMD,
-// 15.4 us per generation; 8 waves (two per SIMD) run the chunk phase in 3.2 instead of 5.6 us but
-// every wave repeats the particle's prologue (position update, per-peak constants, phase seeds),
-// which then takes 4.0 instead of 2.9 us, and the posts arrive later: 16.9 us.
-constexpr int kGenWaves = 4;
-constexpr int kGenBlock = kGenWaves * kWave;
-template <int VARIANT, int FIT_IM>
-__global__ __launch_bounds__(kGenBlock, 1) void generation_kernel(const GenArgs a)
-{
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    __shared__ double s_val[kGenWaves];
-    __shared__ long long s_idx[kGenWaves];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int64_t D = 4 + 3 * (int64_t)a.P;
-    double *sums = reinterpret_cast<double *>(lds_raw + a.sums_off);     // [kGenWaves particles][kMaxBlocks x 2]
-    double *best = reinterpret_cast<double *>(lds_raw + a.state_off);    // fg, best_f, g[D], best_x[D]
-    long long *flags = reinterpret_cast<long long *>(best + 2 + 2 * D);  // generations done, stop code
-    double *cand = reinterpret_cast<double *>(flags + 2);                // f, x[D]
-    for (int64_t d = threadIdx.x; d < 2 + 2 * D; d += kGenBlock) best[d] = a.best[d];
-    if (threadIdx.x < 2) flags[threadIdx.x] = a.flags[threadIdx.x];
-    __syncthreads();
-    if (flags[1] != 0) return;   // stopped before this launch: nothing to do (every workgroup agrees)
-    const int ppp = kGenWaves / a.nseg;   // particles per workgroup per pass
-    const int64_t n_chunks = (a.N + kChunk - 1) / kChunk;
-    const int64_t n_blocks = (n_chunks + a.blk_chunks - 1) / a.blk_chunks;
-    const unsigned nwg = gridDim.x;
-#define GEN_TRACE(k)                                                                              \
-    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0 && it == a.generations - 1) a.trace[k] = __builtin_amdgcn_s_memrealtime()
-    for (int it = 0; it < a.generations; ++it) {
-        GEN_TRACE(0);
-        double mine = INFINITY;
-        long long mi = 0x7fffffffffffffffLL;
-        for (int64_t base = (int64_t)blockIdx.x * ppp; base < a.S; base += (int64_t)nwg * ppp) {
-            const int slot = wave / a.nseg;
-            const int64_t particle = base + slot;
-            // a wave without a particle takes a task index beyond the swarm: it idles through the body's barriers
-            const int64_t g = (particle < a.S) ? particle * a.nseg + (wave % a.nseg) : a.S * a.nseg;
-            PsoFused upd;
-            upd.x_in = a.x;
-            upd.v_in = a.v_;
-            upd.x_out = a.x;
-            upd.v_out = a.v_;
-            upd.p = a.p;
-            upd.best = best;
-            upd.lb = a.lb;
-            upd.ub = a.ub;
-            upd.seed = a.seed;
-            upd.offset = a.offset;
-            upd.omega = a.omega;
-            upd.phip = a.phip;
-            upd.phig = a.phig;
-            upd.xrow_off = a.xrow_off;
-            upd.gen = (uint32_t)(flags[0] + 1);
-            upd.trace = (it == a.generations - 1) ? a.trace : nullptr;
-            objective_body<VARIANT, false, FIT_IM, true, kGenWaves>(lds_raw, g, a.wc, a.u, a.v, a.wt, a.chunk_minmax, nullptr, a.S,
-                                                         a.P, a.N, a.w0, a.wspan, a.nseg, a.seg_len, a.blk_chunks,
-                                                         a.lane_step, a.rec_devk, nullptr, nullptr, nullptr, upd, a.aux_off,
-                                                         sums + (size_t)slot * (2 * kMaxBlocks));
-            __syncthreads();   // the pass's block sums are in LDS, its new rows in global memory
-            GEN_TRACE(1);
-            if (wave < ppp && base + wave < a.S) {   // wave w: objective value and personal best of particle slot w
-                const int64_t i = base + wave;
-                const double *ps = sums + (size_t)wave * (2 * kMaxBlocks);
-                double f;   // same arithmetic and order as finalize_kernel
-                if (FIT_IM == 0) {
-                    double ss = 0.0;
-                    for (int64_t c = 0; c < n_blocks; ++c) ss += ps[c];
-                    f = sqrt(ss / (double)a.N);
-                } else {
-                    double ss = 0.0, si = 0.0;
-                    for (int64_t c = 0; c < n_blocks; ++c) {
-                        ss += ps[2 * c];
-                        si += ps[2 * c + 1];
-                    }
-                    f = 0.5 * (sqrt(ss / (double)a.N) + sqrt(si / (double)a.N));
-                }
-                double cur = a.fp[i];
-                if (lane == 0) a.fx[i] = f;
-                if (f < cur) {   // pyswarm: i_update = fx < fp
-                    for (int64_t d = lane; d < D; d += kWave)
-                        __hip_atomic_store(a.p + i * D + d, a.x[i * D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lane == 0) a.fp[i] = f;
-                    global_stores_done();   // the row is complete in memory before this workgroup's post can be seen
-                    cur = f;
-                }
-                if (lex_less(cur, i, mine, mi)) {
-                    mine = cur;
-                    mi = i;
-                }
-            }
-            __syncthreads();   // sums are free for the next pass
-            GEN_TRACE(2);
-        }
-        if (lane == 0) {
-            s_val[wave] = mine;
-            s_idx[wave] = mi;
-        }
-        __syncthreads();
-        // Post and fold without a counter barrier: a post is (value, tag) with tag = epoch << 32 | index.
-        // The value is stored first and has completed (s_waitcnt vmcnt(0)) before the tag is issued, so a reader that sees
-        // the current epoch in a tag reads the matching value afterwards.  Every workgroup polls every
-        // post until it carries this generation's epoch: that IS the barrier, and it costs one
-        // uncached round trip after the last post instead of a few hundred serialised atomic
-        // increments of one counter.  Two alternating sets of posts: a workgroup cannot be two
-        // generations ahead of another (it needs everybody's post to finish a generation).
-        const unsigned long long epoch = a.epoch_base + (unsigned long long)it + 1ull;
-        if (threadIdx.x == 0) {
-            double b = s_val[0];
-            long long bi = s_idx[0];
-            for (int w = 1; w < kGenWaves; ++w)
-                if (lex_less(s_val[w], s_idx[w], b, bi)) {
-                    b = s_val[w];
-                    bi = s_idx[w];
-                }
-            const size_t slot = (size_t)(it & 1) * nwg + blockIdx.x;
-            const unsigned long long ix = (bi >= 0 && bi < 0xffffffffLL) ? (unsigned long long)bi : 0xffffffffull;
-            __hip_atomic_store(a.post_val + slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            global_stores_done();   // the value is at its point of coherence before the tag is issued (the waves
-                                    // that wrote personal-best rows waited for theirs before the barrier above)
-            __hip_atomic_store((unsigned long long *)a.post_idx + slot, (epoch << 32) | ix, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-        GEN_TRACE(3);
-        double bv = INFINITY;
-        long long bidx = 0x7fffffffffffffffLL;
-        {
-            bool late = false;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            for (unsigned w = threadIdx.x; w < nwg; w += kGenBlock) {
-                const size_t slot = (size_t)(it & 1) * nwg + w;
-                unsigned long long tag;
-                while (((tag = __hip_atomic_load((unsigned long long *)a.post_idx + slot, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT)) >> 32) != (epoch & 0xffffffffull)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {   // 0.2 s of the 100 MHz clock
-                        late = true;
-                        break;
-                    }
-                }
-                if (late) break;
-                const double pv = __hip_atomic_load(a.post_val + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long ix = tag & 0xffffffffull;
-                const long long pi = (ix == 0xffffffffull) ? 0x7fffffffffffffffLL : (long long)ix;
-                if (lex_less(pv, pi, bv, bidx)) {
-                    bv = pv;
-                    bidx = pi;
-                }
-            }
-            if (late) *a.err = 1;
-            if (__syncthreads_or(late ? 1 : 0)) return;   // a workgroup never posted: give up, everywhere
-        }
-        GEN_TRACE(4);
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ov = __shfl_down(bv, off, kWave);
-            const long long oi = __shfl_down(bidx, off, kWave);
-            if (lex_less(ov, oi, bv, bidx)) {
-                bv = ov;
-                bidx = oi;
-            }
-        }
-        if (lane == 0) {
-            s_val[wave] = bv;
-            s_idx[wave] = bidx;
-        }
-        __syncthreads();
-        bv = s_val[0];
-        bidx = s_idx[0];
-        for (int w = 1; w < kGenWaves; ++w)
-            if (lex_less(s_val[w], s_idx[w], bv, bidx)) {
-                bv = s_val[w];
-                bidx = s_idx[w];
-            }
-        if (bidx >= a.S) bidx = 0;   // np.argmin of an all-inf array
-        GEN_TRACE(5);
-        if (threadIdx.x == 0) cand[0] = bv;
-        for (int64_t d = threadIdx.x; d < D; d += kGenBlock)
-            cand[1 + d] = __hip_atomic_load(a.p + bidx * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        GEN_TRACE(6);
-        if (wave == 0) apply_wave(lane, D, 1, 0, a.minstep, a.minfunc, cand, flags, best);
-        __syncthreads();
-        GEN_TRACE(7);
-        if (blockIdx.x == 0) {   // the official copy (host polls the flags; later launches start from it)
-            for (int64_t d = threadIdx.x; d < 2 + 2 * D; d += kGenBlock) a.best[d] = best[d];
-            for (int64_t d = threadIdx.x; d < D + 1; d += kGenBlock) a.cand[d] = cand[d];
-            if (threadIdx.x < 2) a.flags[threadIdx.x] = flags[threadIdx.x];
-        }
-        GEN_TRACE(8);
-        if (flags[1] != 0) return;   // stop: every workgroup has computed the same flag
-    }
-#undef GEN_TRACE
+    objective_body<VARIANT, WRITE_R, FIT_IM>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg, seg_len,
+                                             blk_chunks, lane_step, rec_devk, out, R_out, clk, upd, aux_off);
 }
 
 // f[i] = sqrt( (sum of the particle's per-block sums, in grid order) / N ); with the imaginary
@@ -1731,8 +1440,9 @@ int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw)
 // The kernel variant a launch actually runs (the requested one may not fit in LDS, or may not
 // implement the imaginary part) and the dynamic LDS its per-wave records need.
 static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, int fit_im, int *variant_out,
-                              unsigned *aux_off, int wpb = kWavesPerBlock)
+                              unsigned *aux_off)
 {
+    constexpr int wpb = kWavesPerBlock;
     const size_t np = (size_t)std::max(P, 1);
     const size_t lds_recs = (((size_t)wpb * np * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
                             (size_t)wpb * kMaxBlocks * sizeof(double2) + kSharedPrologueBytes;
@@ -1875,123 +1585,6 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     ctx->last.waves = waves;
     ctx->last.nseg = (int32_t)nseg;
     ctx->last.seg_len = seg_len;
-    return NMRFIT_OK;
-}
-
-// Persistent generations: see generation_kernel.  *launched = false (and NMRFIT_OK) when this
-// swarm does not qualify -- the caller then runs its launch-per-phase generations.
-int launch_generations(nmrfit_ctx *ctx, const SwarmView &sw, int generations, bool *launched)
-{
-    *launched = false;
-    const int64_t S = sw.S, N = ctx->N, D = 4 + 3 * (int64_t)sw.P;
-    if (generations < 1 || S < 1 || D > kFusedMaxD) return NMRFIT_OK;
-    const int fit_im = ctx->fit_im;
-    int variant = NMRFIT_VARIANT_DEFAULT;
-    unsigned aux_off = 0;
-    const size_t lds_obj = resolve_variant(ctx, sw.P, false, fit_im, &variant, &aux_off, kGenWaves);
-    if (!(variant == NMRFIT_VARIANT_DEFAULT || (variant == NMRFIT_VARIANT_FARFIELD && fit_im == 0))) return NMRFIT_OK;   // (others: launch per phase)
-    // all segments of a particle in one workgroup: nseg in {1, 2, 4, 8}, whole blocks each
-    const int64_t n_chunks = (N + kChunk - 1) / kChunk;
-    const int blk_chunks = (int)((n_chunks + kMaxBlocks - 1) / kMaxBlocks);
-    const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
-    const int64_t blk_len = (int64_t)blk_chunks * kChunk;
-    int nseg = kGenWaves;
-    if (const char *e = getenv("NMRFIT_PERSIST_NSEG")) nseg = atoi(e);
-    if (nseg != 1 && nseg != 2 && nseg != 4 && nseg != 8) nseg = kGenWaves;
-    while (nseg > 1 && n_blocks < nseg) nseg >>= 1;
-    const int64_t seg_len = ((n_blocks + nseg - 1) / nseg) * blk_len;
-    if ((N + seg_len - 1) / seg_len != nseg) nseg = (int)((N + seg_len - 1) / seg_len);   // e.g. 3 blocks over 2 segments
-    if (nseg != 1 && nseg != 2 && nseg != 4 && nseg != 8) return NMRFIT_OK;
-    const int ppp = kGenWaves / nseg;
-    GenArgs a{};
-    size_t lds = (lds_obj + 15) & ~(size_t)15;
-    a.xrow_off = (unsigned)lds;
-    lds += 2 * (size_t)kGenWaves * (size_t)D * sizeof(double);     // x rows, then v rows
-    a.sums_off = (unsigned)lds;
-    lds += (size_t)kGenWaves * 2 * kMaxBlocks * sizeof(double);
-    a.state_off = (unsigned)lds;
-    lds += (size_t)(2 + 2 * D) * sizeof(double) + 2 * sizeof(long long) + (size_t)(D + 1) * sizeof(double);
-    if (lds > 64 * 1024) return NMRFIT_OK;
-    const void *fn = nullptr;
-    if (variant == NMRFIT_VARIANT_FARFIELD)
-        fn = (const void *)generation_kernel<NMRFIT_VARIANT_FARFIELD, 0>;
-    else if (fit_im == 0)
-        fn = (const void *)generation_kernel<NMRFIT_VARIANT_DEFAULT, 0>;
-    else if (fit_im == 1)
-        fn = (const void *)generation_kernel<NMRFIT_VARIANT_DEFAULT, 1>;
-    else
-        fn = (const void *)generation_kernel<NMRFIT_VARIANT_DEFAULT, 2>;
-    int per_cu = 0;
-    NMRFIT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kGenBlock, lds));
-    if (per_cu < 1) return NMRFIT_OK;
-    // one workgroup per CU at most: the exchange costs ~4 us at 204 workgroups, ~9 us at 512
-    int64_t max_wg = (int64_t)ctx->compute_units;
-    if (const char *e = getenv("NMRFIT_PERSIST_MAX_WG")) max_wg = atoll(e);
-    max_wg = std::min<int64_t>(max_wg, (int64_t)per_cu * ctx->compute_units);
-    // ONE pass only: a workgroup that has to evaluate a second batch of particles pays the whole
-    // ~8.7 us critical path of a pass again, and the launch-per-phase path (which spreads the waves
-    // over every CU) is then faster (measured at 512 particles: equal; at 1024: 43 against 31 us)
-    const int64_t nwg = (S + ppp - 1) / ppp;
-    if (nwg > max_wg || nwg > sw.max_posts) return NMRFIT_OK;
-    a.wc = ctx->d_wc;
-    a.u = ctx->d_u;
-    a.v = ctx->d_v;
-    a.wt = ctx->d_wt;
-    a.chunk_minmax = ctx->d_chunk;
-    a.S = S;
-    a.N = N;
-    a.P = sw.P;
-    a.nseg = nseg;
-    a.blk_chunks = blk_chunks;
-    a.seg_len = seg_len;
-    a.w0 = ctx->w0;
-    a.wspan = ctx->wspan;
-    a.lane_step = ctx->lane_step;
-    a.rec_devk = ctx->grid_dev * 11.0e10;
-    a.x = sw.x;
-    a.v_ = sw.v;
-    a.p = sw.p;
-    a.fx = sw.fx;
-    a.fp = sw.fp;
-    a.best = sw.best;
-    a.cand = sw.cand;
-    a.flags = sw.flags;
-    a.lb = sw.lb;
-    a.ub = sw.ub;
-    a.seed = sw.seed;
-    a.offset = sw.offset;
-    a.omega = sw.omega;
-    a.phip = sw.phip;
-    a.phig = sw.phig;
-    a.minstep = sw.minstep;
-    a.minfunc = sw.minfunc;
-    a.epoch_base = sw.epoch_base;
-    a.post_val = sw.post_val;
-    a.post_idx = sw.post_idx;
-    a.err = sw.err;
-    a.generations = generations;
-    a.aux_off = aux_off;
-    static unsigned long long *d_trace = nullptr;
-    static const bool want_trace = getenv("NMRFIT_PERSIST_TRACE") != nullptr;
-    if (want_trace && !d_trace) NMRFIT_HIP(hipMalloc((void **)&d_trace, 16 * sizeof(unsigned long long)));
-    a.trace = want_trace ? d_trace : nullptr;
-    void *params[] = {(void *)&a};
-    NMRFIT_HIP(hipLaunchCooperativeKernel(fn, dim3((unsigned)nwg), dim3(kGenBlock), params, (unsigned)lds, ctx->stream));
-    if (want_trace) {   // development aid: where a generation's time goes (workgroup 0, last generation of the launch)
-        unsigned long long t[16];
-        NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
-        NMRFIT_HIP(hipMemcpy(t, d_trace, sizeof t, hipMemcpyDeviceToHost));
-        static int shown = 0;
-        if (shown++ < 3)
-            fprintf(stderr, "persist trace (us): [update %.2f stage %.2f seeds %.2f chunks %.2f] body %.2f pbest %.2f wgmin+post %.2f barrier %.2f fold %.2f row %.2f apply %.2f writeback %.2f | nwg %lld nseg %d\n",
-                    (t[9] - t[0]) * 0.01, (t[10] - t[9]) * 0.01, (t[11] - t[10]) * 0.01, (t[12] - t[11]) * 0.01,
-                    (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01,
-                    (t[6] - t[5]) * 0.01, (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (long long)nwg, nseg);
-    }
-    ctx->last.waves = nwg * kGenWaves;
-    ctx->last.nseg = nseg;
-    ctx->last.seg_len = seg_len;
-    *launched = true;
     return NMRFIT_OK;
 }
 

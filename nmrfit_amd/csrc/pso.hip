@@ -22,10 +22,10 @@
 // into as few launches as the data dependences allow:
 //   S*D <= 2560 (e.g. 50 particles x 6 peaks): objective + ONE single-workgroup kernel for
 //       everything else (pso_tail_kernel)                                        -> 2 launches
-//   S <= 512: update, objective, pso_select_kernel (objective's block sums + pbest + argmin
-//       [+ apply] in a many-workgroup kernel finished by its last-ticket workgroup) -> 3 launches
-//   larger:  the same with the final reduction as its own single-workgroup launch
-//       (a device-scope fence per workgroup would cost more than the launch)     -> 4 launches
+//   S <= 1024: objective (with the position update in its prologue), pso_select_kernel (the
+//       objective's block sums + pbest + argmin [+ apply] in a many-workgroup kernel finished by
+//       its last-ticket workgroup)                                                -> 2 launches
+//   larger:  the same with the final reduction as its own single-workgroup launch -> 3 launches
 // Multi-rank generations run apply as its own launch after the all-gather.
 #include "nmrfit_internal.h"
 #include "pso_update.h"
@@ -53,10 +53,8 @@ struct nmrfit_pso {
     double *d_part_val = nullptr;      // pso_select_kernel: per-workgroup (min fp, index) posts
     long long *d_part_idx = nullptr;
     unsigned *d_ticket = nullptr;
-    unsigned long long epoch = 0;            // persistent generations: posts made so far (tags never repeat)
-    int *d_err = nullptr;                    // ... and their time-out flag
+    int handover = NMRFIT_HANDOVER_FAST;   // nmrfit_pso_set_handover: how the select kernel's workgroups hand over
     nmrfit_comm *comm = nullptr;       // attached communicator (sharded swarm): the exchange runs inside nmrfit_pso_step
-    bool persistent = false;     // nmrfit_pso_set_persistent: cooperative persistent generations in nmrfit_pso_run
     bool initialized = false;    // nmrfit_pso_init has run
     bool seeded = false;         // the generation-0 candidates have been folded into (g, fg)
 };
@@ -202,6 +200,7 @@ struct TailArgs {
     uint64_t seed;
     double omega, phip, phig, minstep, minfunc;
     int phases, fit_im, nranks, is_init;
+    int fenced;                  // last-ticket select: release / acquire fences instead of the fence-free hand-over
     const double *partial;       // per-block sums of squares from the objective launch (kTailFinalize)
     const double *lb, *ub;
     const double *cands;         // candidate records to fold (kTailApply)
@@ -250,9 +249,24 @@ __global__ __launch_bounds__(1024) void pso_tail_kernel(TailArgs a)
 // their writes by then -- reduces the posted minima, writes the candidate record and, for a
 // single-rank run, folds it into (g, fg) with the stopping rule.
 constexpr int kSelectWaves = 4;          // particles per workgroup pass
-constexpr int kSelectTicketBlocks = 256;
-constexpr int kSelectMaxPosts = 65536;    // huge swarms: workgroups stride over the particles  // up to this many workgroups the last-ticket form wins (one fence each)
+constexpr int kSelectTicketBlocks = 256;  // up to this many workgroups the last-ticket form (one launch) beats two launches
+constexpr int kSelectMaxPosts = 65536;    // posts buffer; larger swarms: the workgroups stride over the particles
 
+// How the workgroups of the last-ticket form hand their posts and personal-best rows to the
+// workgroup that finishes (nmrfit_pso_set_handover, include/nmrfit_amd.h):
+//   FAST    agent-scope relaxed atomic stores (write-through: coherent across the 8 XCDs by
+//           themselves), each group of stores completed with s_waitcnt vmcnt(0) before the next is
+//           issued (value before tag/ticket); the reader uses agent-scope atomic loads.  No release
+//           fence -- on this part a fence is an L2 write-back, and the fences of one launch's
+//           workgroups serialise (tools/barrier_probe.hip: 8.0 us per exchange at 51 workgroups
+//           against 2.1).  Compiler ordering is pinned on both sides (the asm carries a memory
+//           clobber; __atomic_signal_fence around the ticket); the hardware ordering rests on
+//           measured gfx950 behaviour and is what tools/handover_stress.py is for.
+//   FENCED  the textbook form: plain stores, every writing wave issues an agent-scope fence, the
+//           ticket is an acq_rel read-modify-write, the finishing workgroup fences before it reads.
+//           A/B reference for FAST, never chosen automatically.
+//   TWO_LAUNCH  no hand-over inside a launch at all: posts, then pso_select_final_kernel as its own
+//           launch (the kernel boundary orders everything).  What swarms above 1024 particles use.
 
 // Reduce the nb posted (min fp, index) pairs, write the candidate record and (kTailApply) fold
 // it.  Called by every thread of ONE workgroup; posts and rows written by other workgroups are
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
         if ((a.phases & kTailFinalize) && lane == 0) a.fx[i] = f;
         double cur = fp_old;
         if (f < cur) {   // pyswarm: i_update = fx < fp
-            if (ticket) {   // rows another workgroup of this launch may read: write-through stores
+            if (ticket && !a.fenced) {   // rows another workgroup of this launch may read: write-through stores
                 if (lane < a.D) __hip_atomic_store(a.p + i * a.D + lane, x_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (int64_t d = lane + kWave; d < a.D; d += kWave)
                     __hip_atomic_store(a.p + i * a.D + d, a.x[i * a.D + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -352,6 +366,7 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
                 if (lane < a.D) a.p[i * a.D + lane] = x_head;
                 for (int64_t d = lane + kWave; d < a.D; d += kWave) a.p[i * a.D + d] = a.x[i * a.D + d];
                 if (lane == 0) a.fp[i] = f;
+                if (ticket) __threadfence();   // FENCED: this wave's row and value are released at agent scope
             }
             cur = f;
         }
@@ -375,11 +390,20 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
                 bi = s_idx[w];
             }
         s_last = 0;
-        if (ticket) {
+        if (ticket && a.fenced) {
+            part_val[blockIdx.x] = b;
+            part_idx[blockIdx.x] = bi;
+            // release: the post (and, through the barrier above and the writers' own fences, the rows);
+            // acquire: everything released before the tickets drawn earlier
+            s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u);
+        } else if (ticket) {
             __hip_atomic_store(part_val + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(part_idx + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            global_stores_done();   // the post has completed
+            global_stores_done();   // the post has completed (asm with a memory clobber: the compiler
+                                    // cannot move the ticket above it either)
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
             s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);   // ... nor any later load above the ticket
         } else {
             part_val[blockIdx.x] = b;
             part_idx[blockIdx.x] = bi;
@@ -388,6 +412,10 @@ __global__ __launch_bounds__(kWave *kSelectWaves) void pso_select_kernel(TailArg
     __syncthreads();
     if (!s_last) return;
     // every other workgroup's stores had completed before it drew its ticket
+    if (a.fenced)
+        __threadfence();   // FENCED: every reading wave acquires at agent scope
+    else
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
     select_final<true>(a, part_val, part_idx, gridDim.x, s_val, s_idx);
 }
@@ -444,6 +472,7 @@ TailArgs tail_args(nmrfit_pso *pso, const ObjectiveDeferred &def, int phases)
     a.fit_im = def.fit_im;
     a.nranks = 1;
     a.is_init = 0;
+    a.fenced = (pso->handover == NMRFIT_HANDOVER_FENCED) ? 1 : 0;
     a.partial = def.partial;
     a.lb = pso->d_lb;
     a.ub = pso->d_ub;
@@ -529,15 +558,15 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
     TailArgs a = tail_args(pso, def, (def.needed ? kTailFinalize : 0) | kTailPbest | kTailArgmin | (more & kTailApply));
     a.is_init = is_init;
     if (small_swarm(pso)) return launch_tail(pso, a);
-    // S <= 512: one launch, the last-ticket workgroup finishes; larger: posts, then a
-    // single-workgroup launch (a fence per workgroup would cost more than the launch)
+    // up to 256 workgroups (1024 particles): one launch, the last-ticket workgroup finishes; larger
+    // (or NMRFIT_HANDOVER_TWO_LAUNCH): posts, then a single-workgroup launch
     const int64_t nb64 = (S + kSelectWaves - 1) / kSelectWaves;
     const unsigned nb = (unsigned)std::min<int64_t>(nb64, kSelectMaxPosts);
     static const unsigned ticket_blocks = [] {
         const char *e = getenv("NMRFIT_TICKET_BLOCKS");   // tuning knob
         return e ? (unsigned)atoi(e) : (unsigned)kSelectTicketBlocks;
     }();
-    const bool ticket = nb <= ticket_blocks;
+    const bool ticket = nb <= ticket_blocks && pso->handover != NMRFIT_HANDOVER_TWO_LAUNCH;
     hipLaunchKernelGGL(pso_select_kernel, dim3(nb), dim3(kWave * kSelectWaves), 0, ctx->stream, a, pso->d_part_val,
                        pso->d_part_idx, ticket ? pso->d_ticket : nullptr);
     NMRFIT_HIP(hipGetLastError());
@@ -589,6 +618,8 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
     pso->P = P;
     pso->D = D;
     pso->prm = *params;
+    if (const char *e = getenv("NMRFIT_SAFE_HANDOVER"))   // A/B knob: the fenced hand-over as every swarm's default
+        if (atoi(e) != 0) pso->handover = NMRFIT_HANDOVER_FENCED;
     const size_t sd = (size_t)std::max<int64_t>(S_local * D, 1) * sizeof(double);
     const size_t s1 = (size_t)std::max<int64_t>(S_local, 1) * sizeof(double);
 #define PSO_HIP(call)                                                   \
@@ -619,8 +650,6 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
         PSO_HIP(hipMalloc((void **)&pso->d_part_idx, nb * sizeof(long long)));
         PSO_HIP(hipMalloc((void **)&pso->d_ticket, sizeof(unsigned)));
         PSO_HIP(hipMemsetAsync(pso->d_part_idx, 0, nb * sizeof(long long), ctx->stream));
-        PSO_HIP(hipMalloc((void **)&pso->d_err, sizeof(int)));
-        PSO_HIP(hipMemsetAsync(pso->d_err, 0, sizeof(int), ctx->stream));
         PSO_HIP(hipMemsetAsync(pso->d_ticket, 0, sizeof(unsigned), ctx->stream));
     }
     PSO_HIP(hipMemcpyAsync(pso->d_lb, lower, (size_t)D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -636,12 +665,14 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
 int nmrfit_pso_destroy(nmrfit_pso *pso)
 {
     if (!pso) return NMRFIT_OK;
+    if (pso->comm) comm_attach(pso->comm, -1);
+    pso->comm = nullptr;
     if (pso->ctx) {
         (void)hipSetDevice(pso->ctx->device);
         (void)hipStreamSynchronize(pso->ctx->stream);
     }
     void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_x2, pso->d_v2, pso->d_p, pso->d_fx, pso->d_fp, pso->d_cand_own, pso->d_flags, pso->d_best,
-                    pso->d_part_val, pso->d_part_idx, pso->d_ticket, pso->d_err};
+                    pso->d_part_val, pso->d_part_idx, pso->d_ticket};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete pso;
@@ -725,8 +756,30 @@ int nmrfit_pso_set_comm(nmrfit_pso *pso, nmrfit_comm *comm)
 {
     int rc = bind_pso(pso);
     if (rc != NMRFIT_OK) return rc;
+    // the all-gather is enqueued on the communicator's context's stream, between this swarm's select
+    // and fold kernels: it has to be the same context (same device, same stream)
+    if (comm && comm_ctx(comm) != pso->ctx) {
+        set_error("nmrfit_pso_set_comm: the communicator was created on a different context than the swarm");
+        return NMRFIT_E_INVALID;
+    }
     NMRFIT_HIP(hipStreamSynchronize(pso->ctx->stream));
+    if (pso->comm) comm_attach(pso->comm, -1);
     pso->comm = comm;
+    if (comm) comm_attach(comm, +1);   // nmrfit_comm_destroy refuses while a swarm still points at it
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_set_handover(nmrfit_pso *pso, int mode)
+{
+    if (!pso) {
+        set_error("null swarm handle");
+        return NMRFIT_E_INVALID;
+    }
+    if (mode != NMRFIT_HANDOVER_FAST && mode != NMRFIT_HANDOVER_FENCED && mode != NMRFIT_HANDOVER_TWO_LAUNCH) {
+        set_error("nmrfit_pso_set_handover: mode must be one of NMRFIT_HANDOVER_*");
+        return NMRFIT_E_INVALID;
+    }
+    pso->handover = mode;
     return NMRFIT_OK;
 }
 
@@ -801,82 +854,18 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every)
     if (!pso->seeded) {
         if ((rc = exchange_and_fold(pso)) != NMRFIT_OK) return rc;
     }
-    if (pso->comm) {
-        // sharded swarm: every rank runs the same generations and folds the same gathered records,
-        // so every rank reads the same stop flag at the same poll and leaves the loop together
-        for (int64_t it = 1; it <= maxiter; ++it) {
-            if ((rc = nmrfit_pso_step(pso)) != NMRFIT_OK) return rc;
-            if (it % check_every == 0 || it == maxiter) {
-                int32_t stop = 0;
-                if ((rc = nmrfit_pso_status(pso, nullptr, &stop, nullptr)) != NMRFIT_OK) return rc;
-                if (stop) break;
-            }
+    // A generation is the objective launch (which also advances the swarm) and the select launch
+    // (which, single rank, also folds the candidate and applies the stopping rule).  Sharded swarm:
+    // every rank runs the same generations and folds the same gathered records, so every rank reads
+    // the same stop flag at the same poll and leaves the loop together.
+    for (int64_t it = 1; it <= maxiter; ++it) {
+        if ((rc = nmrfit_pso_step(pso)) != NMRFIT_OK) return rc;
+        if (it % check_every == 0 || it == maxiter) {
+            int32_t stop = 0;
+            if ((rc = nmrfit_pso_status(pso, nullptr, &stop, nullptr)) != NMRFIT_OK) return rc;
+            if (stop) break;
         }
-        return NMRFIT_OK;
     }
-    // single rank.  A generation is the objective launch (which also advances the swarm) and the select
-    // launch (which also folds the candidate and applies the stopping rule); with
-    // nmrfit_pso_set_persistent, small swarms run `check_every` generations per cooperative launch of
-    // the persistent generation kernel (objective.hip) instead.
-    int64_t it = 0;
-    while (it < maxiter) {
-        const int64_t n = std::min<int64_t>(check_every, maxiter - it);
-        SwarmView vw;
-        vw.S = pso->S;
-        vw.offset = pso->offset;
-        vw.P = pso->P;
-        vw.x = pso->d_x;
-        vw.v = pso->d_v;
-        vw.p = pso->d_p;
-        vw.fx = pso->d_fx;
-        vw.fp = pso->d_fp;
-        vw.best = pso->d_best;
-        vw.cand = pso->d_cand;
-        vw.flags = pso->d_flags;
-        vw.lb = pso->d_lb;
-        vw.ub = pso->d_ub;
-        vw.seed = pso->prm.seed;
-        vw.omega = pso->prm.omega;
-        vw.phip = pso->prm.phip;
-        vw.phig = pso->prm.phig;
-        vw.minstep = pso->prm.minstep;
-        vw.minfunc = pso->prm.minfunc;
-        vw.epoch_base = pso->epoch;
-        vw.post_val = pso->d_part_val;
-        vw.post_idx = pso->d_part_idx;
-        vw.max_posts = kSelectMaxPosts / 2;
-        vw.err = pso->d_err;
-        bool launched = false;
-        if (pso->persistent &&
-            (rc = launch_generations(pso->ctx, vw, (int)std::min<int64_t>(n, 1 << 20), &launched)) != NMRFIT_OK)
-            return rc;
-        if (launched) pso->epoch += (unsigned long long)n;
-        if (!launched)
-            for (int64_t k = 0; k < n; ++k)
-                if ((rc = nmrfit_pso_step(pso)) != NMRFIT_OK) return rc;
-        it += n;
-        int32_t stop = 0;
-        if ((rc = nmrfit_pso_status(pso, nullptr, &stop, nullptr)) != NMRFIT_OK) return rc;
-        if (launched) {
-            int err = 0;
-            NMRFIT_HIP(hipMemcpy(&err, pso->d_err, sizeof err, hipMemcpyDeviceToHost));
-            if (err) {
-                set_error("persistent generation kernel: a grid barrier timed out (workgroups not co-resident?)");
-                return NMRFIT_E_HIP;
-            }
-        }
-        if (stop) break;
-    }
-    return NMRFIT_OK;
-}
-
-int nmrfit_pso_set_persistent(nmrfit_pso *pso, int enable)
-{
-    if (!pso) {
-        set_error("null swarm handle");
-        return NMRFIT_E_INVALID;
-    }
-    pso->persistent = enable != 0;
     return NMRFIT_OK;
 }
 

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "nmrfit_internal.h"   // kMaxBlocks
+
 namespace nmrfit {
 
 struct U4 {
@@ -76,8 +78,6 @@ struct PsoFused {
     int64_t offset = 0;                               // global index of this shard's first particle
     double omega = 0.0, phip = 0.0, phig = 0.0;
     unsigned xrow_off = 0;                            // byte offset of the per-wave x rows in dynamic LDS
-    uint32_t gen = 0;                                 // persistent generations: the generation being computed
-    unsigned long long *trace = nullptr;              // development aid (NMRFIT_PERSIST_TRACE)
 };
 
 // Wait until every global store this wave has issued has completed.  For the agent-scope (sc1,
@@ -102,7 +102,7 @@ __device__ __forceinline__ bool lex_less(double v, long long i, double bv, long 
 // strictly one after another, so the value is bit-identical to the sequential loop.
 __device__ __forceinline__ double finalize_value(const double *partial, int64_t n_blocks, int64_t N, int fit_im)
 {
-    constexpr int kMax = 16;   // kMaxBlocks
+    constexpr int kMax = kMaxBlocks;
     if (fit_im == 0) {
         double v[kMax];
 #pragma unroll

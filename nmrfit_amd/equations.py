@@ -62,8 +62,10 @@ class Evaluator:
     # -- life cycle ---------------------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
-            for child in list(getattr(self, "_children", ())):
-                child.close()            # a swarm holds a pointer to this context
+            # swarms and communicators hold a pointer to this context; swarms go first (a swarm may
+            # still have a communicator attached, and nmrfit_comm_destroy refuses while one does)
+            for child in sorted(getattr(self, "_children", ()), key=lambda c: 0 if hasattr(c, "set_comm") else 1):
+                child.close()
             self._lib.nmrfit_ctx_destroy(self._ctx)
             self._ctx = ctypes.c_void_p()
 

@@ -96,12 +96,21 @@ class RcclExchange:
     ncclAllGather of the (D+1)-double record and the fold run inside ``nmrfit_pso_step`` on the
     context's HIP stream -- no host synchronisation, no Python, no PyTorch in the loop.
 
-    ``channel`` is a ``rendezvous.Channel`` (or anything with rank / world / broadcast) used
-    once, to hand rank 0's 128-byte unique id to the other ranks.  Collective: every rank
-    constructs it, with its own Evaluator (one GPU per process)."""
+    ``channel`` is a ``rendezvous.Channel`` (or anything with rank / world / broadcast /
+    all_gather) used before RCCL exists: the ranks first tell each other whether RCCL can be
+    loaded at all (so that a rank without it is an error on EVERY rank, not a hang of the others
+    inside the collective ncclCommInitRank), then rank 0's 128-byte unique id goes round.
+    Collective: every rank constructs it, with its own Evaluator (one GPU per process).
 
-    def __init__(self, evaluator, channel=None):
+    ``init_timeout`` (seconds; default NMRFIT_COMM_INIT_TIMEOUT or 300, 0 disables): deadline
+    for the communicator creation, the one step that cannot time out by itself -- on expiry the
+    process says on stderr which rank was stuck on which device and exits (rendezvous.Watchdog),
+    so that the launcher sees a failed rank.  ``verbose``: one stderr line per rank once the
+    communicator exists (rank, HIP device, PCI bus id, RCCL version)."""
+
+    def __init__(self, evaluator, channel=None, init_timeout=None, verbose=False):
         import os
+        import sys
         from . import rendezvous
         # first contact with a new node is where RCCL fails if it fails: let it say why
         os.environ.setdefault("NCCL_DEBUG", "WARN")
@@ -110,6 +119,17 @@ class RcclExchange:
         self._own_channel = channel is None
         self.channel = rendezvous.Channel() if channel is None else channel
         self.rank, self.world = self.channel.rank, self.channel.world
+        if init_timeout is None:
+            init_timeout = float(os.environ.get("NMRFIT_COMM_INIT_TIMEOUT", "300"))
+        # 1. can every rank load RCCL?  (dlopen + symbols only: nothing collective yet)
+        rc_av = self._lib.nmrfit_comm_available()
+        msg_av = "" if rc_av == _cabi.OK else self._lib.nmrfit_last_error().decode("utf-8", "replace")
+        notes = self.channel.all_gather(msg_av.encode("utf-8", "replace") if rc_av != _cabi.OK else b"")
+        bad = [(r, n.decode("utf-8", "replace")) for r, n in enumerate(notes) if n]
+        if bad:
+            self._close_channel()
+            raise _cabi.NmrfitError(_cabi.E_UNSUPPORTED, "RCCL is not available on rank(s) %s: %s"
+                                    % ([r for r, _ in bad], bad[0][1]))
         uid = ctypes.create_string_buffer(_cabi.UNIQUE_ID_BYTES)
         rc0, err0 = 0, ""
         if self.rank == 0:
@@ -120,13 +140,41 @@ class RcclExchange:
         # waiting in the rendezvous for an id that will never come
         raw = self.channel.broadcast((uid.raw if rc0 == _cabi.OK else b"") if self.rank == 0 else b"")
         if len(raw) != _cabi.UNIQUE_ID_BYTES:
+            self._close_channel()
             if self.rank == 0:
                 raise _cabi.NmrfitError(rc0, err0)
             raise _cabi.NmrfitError(_cabi.E_COMM, "rank 0 could not create an RCCL unique id")
         uid = ctypes.create_string_buffer(raw, _cabi.UNIQUE_ID_BYTES)
         self._h = ctypes.c_void_p()
-        _cabi.check(self._lib.nmrfit_comm_create(evaluator.handle, self.rank, self.world, uid, ctypes.byref(self._h)))
+        dev = getattr(evaluator, "device", -1)
+
+        try:      # looked up now: the watchdog thread must not make HIP calls while this one is stuck in one
+            pci = _cabi.device_pci_bus_id(dev)
+        except Exception:
+            pci = "unknown"
+
+        def where():
+            return "(HIP device %s, PCI %s, world %d)" % (dev, pci, self.world)
+        # 2. the collective creation, under a deadline
+        with rendezvous.Watchdog(init_timeout, "ncclCommInitRank (nmrfit_comm_create)", rank=self.rank, describe=where):
+            rc = self._lib.nmrfit_comm_create(evaluator.handle, self.rank, self.world, uid, ctypes.byref(self._h))
+        if rc != _cabi.OK:
+            self._close_channel()
+            _cabi.check(rc)
         evaluator._children.add(self)
+        if verbose:
+            sys.stderr.write("nmrfit: RCCL communicator ready: %s\n" % self.describe())
+            sys.stderr.flush()
+
+    def _close_channel(self):
+        if getattr(self, "_own_channel", False) and self.channel is not None:
+            self.channel.close()
+            self.channel = None
+
+    def describe(self):
+        buf = ctypes.create_string_buffer(256)
+        _cabi.check(self._lib.nmrfit_comm_describe(self._h, buf, 256))
+        return buf.value.decode("utf-8", "replace")
 
     @property
     def handle(self):
@@ -166,11 +214,9 @@ class RcclExchange:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            self._lib.nmrfit_comm_destroy(self._h)
+            _cabi.check(self._lib.nmrfit_comm_destroy(self._h))   # E_STATE while a swarm is still attached
             self._h = ctypes.c_void_p()
-        if getattr(self, "_own_channel", False) and self.channel is not None:
-            self.channel.close()
-            self.channel = None
+        self._close_channel()
 
     def __del__(self):
         try:
@@ -352,6 +398,11 @@ class DeviceSwarm:
         evaluator._children.add(self)
 
     def close(self):
+        if getattr(self, "_comm", None) is not None and getattr(self, "_h", None) is not None and self._h.value:
+            try:
+                self.set_comm(None)
+            except Exception:
+                pass
         if getattr(self, "_d_gather", None) is not None:
             try:
                 self.ev.dev_free(self._d_gather)
@@ -386,12 +437,14 @@ class DeviceSwarm:
         folds generation 0."""
         _cabi.check(self._lib.nmrfit_pso_step(self._h))
 
-    def set_persistent(self, enable=True):
-        """Opt-in: ``run`` executes ``check_every`` generations per cooperative launch (persistent
-        workgroups, csrc/objective.hip generation_kernel) when the swarm is small enough for one
-        workgroup per particle; bit-identical results.  Off by default (no faster than the
-        launch-per-phase path on this part)."""
-        _cabi.check(self._lib.nmrfit_pso_set_persistent(self._h, 1 if enable else 0))
+    def set_handover(self, mode):
+        """How the personal-best / argmin kernel's workgroups hand over inside one launch (swarms of
+        up to 1024 particles): "fast" (default: fence-free agent-scope stores), "fenced" (release /
+        acquire fences) or "two_launch".  Bit-identical results; an A/B knob."""
+        if isinstance(mode, str):
+            mode = {"fast": _cabi.HANDOVER_FAST, "fenced": _cabi.HANDOVER_FENCED,
+                    "two_launch": _cabi.HANDOVER_TWO_LAUNCH}[mode.lower()]
+        _cabi.check(self._lib.nmrfit_pso_set_handover(self._h, int(mode)))
 
     def candidate_dev(self):
         p = ctypes.c_void_p()
@@ -492,14 +545,12 @@ def run_sharded(swarm, exchange, maxiter, check_every=1, verbose=False):
 
 
 def pso(evaluator, lb, ub, swarmsize=100, omega=0.5, phip=0.5, phig=0.5, maxiter=100, minstep=1e-8,
-        minfunc=1e-8, seed=0, check_every=64, verbose=True, persistent=False):
+        minfunc=1e-8, seed=0, check_every=64, verbose=True):
     """pyswarm.pso-shaped entry point over a GPU ``Evaluator`` (single rank):
     returns (xopt, fopt) like pyswarm does."""
     sw = DeviceSwarm(evaluator, lb, ub, swarmsize, seed=seed, omega=omega, phip=phip, phig=phig,
                      minstep=minstep, minfunc=minfunc)
     try:
-        if persistent:
-            sw.set_persistent(True)
         sw.run(maxiter, check_every)
         st = sw.status()
         if verbose:

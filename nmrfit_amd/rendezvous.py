@@ -11,23 +11,36 @@ connections to rank 0.
 
 Where rank 0 listens:
 
-* ``NMRFIT_RDZV_PORT`` set: on MASTER_ADDR at that port (multi-node capable; the port must
-  be free, so it cannot be MASTER_PORT under torchrun, whose agent keeps its own store
-  listening there);
+* ``NMRFIT_RDZV_PORT`` set: on MASTER_ADDR (the address rank 0 binds -- not every interface)
+  at that port (multi-node capable; the port must be free, so it cannot be MASTER_PORT under
+  torchrun, whose agent keeps its own store listening there);
 * otherwise (one node, the default): on an ephemeral port of 127.0.0.1, published through a
   small file in the temporary directory whose name is derived from MASTER_ADDR, MASTER_PORT
-  and a token shared by the ranks of ONE launch -- ``NMRFIT_RDZV_TOKEN`` if set, else the
-  parent process id (torchrun's agent, or bench.py's launcher, is the parent of every rank).
-  No fixed port is needed, so nothing can collide with the launcher's own rendezvous.
+  and the launch token.  No fixed port is needed, so nothing can collide with the launcher's
+  own rendezvous.
+
+The launch token is what the ranks of ONE launch share and nobody else knows:
+``NMRFIT_RDZV_TOKEN`` if set; else, in the one-node mode, the parent process id (torchrun's
+agent, or bench.py's launcher, is the parent of every rank); else, with ``NMRFIT_RDZV_PORT``
+(ranks on several nodes have different parents), a digest of the launch-wide values
+MASTER_ADDR, MASTER_PORT, WORLD_SIZE and TORCHELASTIC_RUN_ID -- guessable by anyone who can
+read the job's environment, so export ``NMRFIT_RDZV_TOKEN`` (any shared secret) on a network
+you do not trust.
 
 A rank announces itself with a magic word, the token and its rank number; rank 0 rejects
 anything else, so a stray connection cannot join the group.
+
+``Watchdog`` is the deadline for the steps that cannot time out by themselves (a collective
+``ncclCommInitRank`` in which some rank never arrives): on expiry it says on stderr which rank
+was where and ends the process, so that the launcher sees a failed rank instead of a hang.
 """
 import hashlib
 import os
 import socket
 import struct
+import sys
 import tempfile
+import threading
 import time
 
 _MAGIC = b"NMRFITv1"
@@ -44,7 +57,54 @@ def _token():
     t = os.environ.get("NMRFIT_RDZV_TOKEN")
     if t:
         return t
+    if os.environ.get("NMRFIT_RDZV_PORT"):
+        # several nodes: the ranks' parents differ, the launcher's launch-wide values do not
+        key = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE",
+                                                        "TORCHELASTIC_RUN_ID"))
+        return "launch" + hashlib.sha256(key.encode()).hexdigest()[:32]
     return "ppid%d" % os.getppid()
+
+
+class Watchdog:
+    """Deadline for a step that cannot time out by itself.  ``with Watchdog(seconds, what):`` --
+    if the block is still running after ``seconds`` the watchdog thread writes one line to
+    stderr (rank, what it was waiting in, extra ``describe()`` text) and ends the process with
+    ``exit_code`` (os._exit: the main thread is stuck inside a C call and cannot be unwound).
+    ``seconds <= 0`` disables it.  ``phase`` may be updated while the block runs."""
+
+    def __init__(self, seconds, phase, rank=None, exit_code=124, describe=None):
+        self.seconds = float(seconds)
+        self.phase = phase
+        self.rank = env_rank_world()[0] if rank is None else rank
+        self.exit_code = exit_code
+        self.describe = describe
+        self._done = threading.Event()
+        self._thread = None
+
+    def _run(self):
+        if self._done.wait(self.seconds):
+            return
+        extra = ""
+        try:
+            extra = self.describe() if self.describe else ""
+        except Exception as e:       # diagnostics must not hide the time-out
+            extra = "(describe failed: %r)" % (e,)
+        sys.stderr.write("nmrfit watchdog: rank %d still in `%s` after %.0f s%s -- ending this process (exit %d)\n"
+                         % (self.rank, self.phase, self.seconds, (" " + extra) if extra else "", self.exit_code))
+        sys.stderr.flush()
+        os._exit(self.exit_code)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            self._thread = threading.Thread(target=self._run, name="nmrfit-watchdog", daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+        if self._thread is not None:
+            self._thread.join(1.0)
+        return False
 
 
 def _rdzv_file(token):
@@ -101,7 +161,14 @@ class Channel:
             ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             if port_env:
-                ls.bind(("", int(port_env)))
+                # the address the other ranks connect to, not every interface of the node
+                host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+                try:
+                    ls.bind((host, int(port_env)))
+                except OSError as e:
+                    ls.close()
+                    raise OSError("rendezvous: rank 0 cannot listen on MASTER_ADDR=%s port %s (%s); rank 0 must "
+                                  "run on the MASTER_ADDR host and NMRFIT_RDZV_PORT must be free" % (host, port_env, e))
             else:
                 ls.bind(("127.0.0.1", 0))
             ls.listen(max(16, self.world))

@@ -10,7 +10,7 @@ Kept verbatim from the reference interface:
   after fit(): weights, params, error.
   options: swarmsize (204), maxiter (2000), omega (-0.2134), phip (-0.3344), phig (2.3259)
            (utils.py:177-181).  Extra opt-in keys: minstep, minfunc (pyswarm's 1e-8 defaults,
-           which the reference does not forward), seed, device, check_every, polish, persistent,
+           which the reference does not forward), seed, device, check_every, polish,
            variant (kernel variant by name or number; default: "farfield" when grid x peaks
            >= 1e5, else "default" -- see default_variant), exchange ("rccl" for a
            multi-GPU fit, one process per GPU: the swarm axis is sharded and the global best is
@@ -108,6 +108,16 @@ class FitUtility:
     def _compute_weights(self):
         return compute_weights(self.data.w, self.data.peaks, self.expon)
 
+    def _device(self):
+        """The GPU this process works on: options['device'] if given; else, in a multi-rank fit
+        (options['exchange'] = "rccl" or an exchange object: one process per GPU), the launcher's
+        LOCAL_RANK; else 0.  fit() and generate_result() use the same one."""
+        device = self.options.get('device')
+        if device is None and self.options.get('exchange') is not None:
+            from . import rendezvous
+            device = rendezvous.env_rank_world()[1]
+        return 0 if device is None else int(device)
+
     def fit(self):
         """utils.py:164-189: weights, minimise, store params/error, optional summary."""
         self.weights = self._compute_weights()
@@ -123,21 +133,16 @@ class FitUtility:
         seed = opt.get('seed')
         if seed is None:     # pyswarm draws from numpy's unseeded global RNG: do the equivalent
             seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
+        self.seed = seed     # (extra attribute: the seed this fit ran with -- rank 0's in a multi-rank fit)
         # Multi-GPU fits (one process per GPU, every rank makes the same fit() call):
         # options['exchange'] = "rccl" builds the RCCL communicator from the launcher's
         # environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; nmrfit_amd.rendezvous), or pass a
         # ready pso.RcclExchange / SocketExchange / TorchExchange.
         exchange = opt.get('exchange')
-        device = opt.get('device')
         own_exchange = False
-        if isinstance(exchange, str):
-            if exchange.lower() != "rccl":
-                raise ValueError("options['exchange'] must be \"rccl\" or an exchange object")
-            from . import rendezvous
-            if device is None:
-                device = rendezvous.env_rank_world()[1]
-        if device is None:
-            device = 0
+        if isinstance(exchange, str) and exchange.lower() != "rccl":
+            raise ValueError("options['exchange'] must be \"rccl\" or an exchange object")
+        device = self._device()
 
         ev = equations.Evaluator(self.data.w, self.data.u, self.data.v, self.weights, device=device)
         try:
@@ -150,12 +155,12 @@ class FitUtility:
             ev.set_variant(_cabi.variant_id(opt.get('variant', default_variant(len(self.data.w), n_peaks))))
             if exchange is None or (exchange.world == 1 and not isinstance(exchange, pso.RcclExchange)):
                 xopt, fopt = pso.pso(ev, self.lower, self.upper, swarmsize=swarmsize, maxiter=maxiter, seed=seed,
-                                     check_every=opt.get('check_every', 64), verbose=True,
-                                     persistent=bool(opt.get('persistent', False)), **kw)
+                                     check_every=opt.get('check_every', 64), verbose=True, **kw)
             else:
                 # every rank must run the same swarm: rank 0's seed wins (an unseeded fit would
                 # otherwise draw a different seed on every rank)
                 seed = exchange.broadcast_seed(seed)
+                self.seed = seed
                 off, n = pso.shard(swarmsize, exchange.rank, exchange.world)
                 sw = pso.DeviceSwarm(ev, self.lower, self.upper, swarmsize, offset=off, S_local=n, seed=seed, **kw)
                 try:
@@ -197,7 +202,7 @@ class FitUtility:
             self.data.V, self.data.I = proc_autophase.ps2(self.data.u, self.data.v, p0, p1)
 
         ev = equations.Evaluator(self.data.w, self.data.u, self.data.v, np.ones(len(self.data.w)),
-                                 device=self.options.get('device', 0))
+                                 device=self._device())
         try:
             real, imag = ev.contributions(self.params, None if scale == 1.0 else w)
         finally:

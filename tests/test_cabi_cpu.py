@@ -38,7 +38,7 @@ def test_ctypes_table_covers_header():
 
 
 def test_abi_version():
-    assert _cabi.lib().nmrfit_abi_version() == 2
+    assert _cabi.lib().nmrfit_abi_version() == _cabi.ABI_VERSION
 
 
 def test_no_silent_fallback_without_gpu():

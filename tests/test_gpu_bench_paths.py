@@ -21,14 +21,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(cmd, env_extra, timeout=900):
+def _run(cmd, env_extra, timeout=900, expect_rc=0, stderr_has=()):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                          timeout=timeout)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == expect_rc, (out.returncode, out.stderr[-2000:])
+    for needle in stderr_has:
+        assert needle in out.stderr, (needle, out.stderr[-2000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     return json.loads(lines[0])
@@ -60,10 +62,15 @@ def test_bench_paths_agree():
     rccl = _run([sys.executable, "bench.py", "--swarm-per-gpu", "512"] + common, {"NMRFIT_BENCH_FORCE_DIST": "1"})
     assert rccl["config"]["swarm_best_f"] == plain["config"]["swarm_best_f"]
     assert "ncclAllGather" in rccl["config"]["exchange"]
+    # how many ranks RCCL itself saw is a top-level field
+    assert rccl["rccl"]["nranks"] == 1 and rccl["rccl"]["ranks_counted_by_all_reduce"] == 1
+    assert rccl["rccl"]["version"] > 0 and "PCI" in rccl["rccl"]["rank0"] and "error" not in rccl
+    assert "rccl" not in plain
     # self-launching form: no launcher, no WORLD_SIZE in the environment
     two = _run([sys.executable, "bench.py", "--gpus", "2", "--swarm-per-gpu", "256"] + common,
                {"NMRFIT_BENCH_BACKEND": "host"})
     assert two["n_gpus"] == 2 and two["config"]["swarm_total"] == 512
+    assert two["rccl"] is None and "error" not in two          # the host-staged exchange was asked for explicitly
     assert two["config"]["swarm_best_f"] == plain["config"]["swarm_best_f"]
     assert two["config"]["generations_done"] == plain["config"]["generations_done"] == 7
     # the driver's form: torch.distributed.run as the launcher (torch is not imported by the ranks)
@@ -74,12 +81,27 @@ def test_bench_paths_agree():
 
 
 def test_bench_says_so_when_rccl_is_unavailable():
-    """RCCL missing on every rank (forced with NMRFIT_RCCL_LIB): no rank hangs in the rendezvous, the run
-    still measures with the host-staged exchange, and the line says loudly what happened."""
+    """RCCL missing on every rank (forced with NMRFIT_RCCL_LIB): no rank hangs in the rendezvous or in
+    ncclCommInitRank (the ranks compare notes first), the run still measures with the host-staged
+    exchange -- but N > 1 without RCCL is NOT a scaling number: the line carries an "error" field,
+    `rccl` is null and the exit code is 5, under the self-launcher and under torch.distributed.run."""
     common = ["--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--workload", "C2", "--preheat-seconds", "0.1",
               "--no-extras", "--swarm-per-gpu", "256"]
-    d = _run([sys.executable, "bench.py", "--gpus", "2"] + common, {"NMRFIT_RCCL_LIB": "/nonexistent/librccl.so", "NMRFIT_BENCH_SHARE_GPU": "1"})
+    bad = {"NMRFIT_RCCL_LIB": "/nonexistent/librccl.so", "NMRFIT_BENCH_SHARE_GPU": "1"}
+    d = _run([sys.executable, "bench.py", "--gpus", "2"] + common, bad, expect_rc=5,
+             stderr_has=("RCCL exchange unavailable", "creating the RCCL communicator on HIP device"))
     assert d["n_gpus"] == 2 and "RCCL FAILED" in d["config"]["exchange"]
+    assert d["rccl"] is None and "did not run over RCCL" in d["error"] and d["value"] > 0
+    t = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+              "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + common,
+             bad, expect_rc=1)
+    assert t["rccl"] is None and "did not run over RCCL" in t["error"]
+    # only ONE rank without RCCL: every rank hears about it before anyone enters the collective
+    # (a second rank on the same device would make RCCL itself refuse; the point is that nobody hangs)
+    one_bad = {"NMRFIT_BENCH_SHARE_GPU": "1", "NMRFIT_BENCH_TEST_RCCL_MISSING_ON": "1"}
+    d1 = _run([sys.executable, "bench.py", "--gpus", "2", "--launch-timeout", "120"] + common, one_bad, expect_rc=5,
+              stderr_has=("RCCL is not available on rank(s) [1]",))
+    assert d1["rccl"] is None and "error" in d1
 
 
 def test_c4_rehearsal_four_ranks_on_one_gpu():
@@ -92,3 +114,11 @@ def test_c4_rehearsal_four_ranks_on_one_gpu():
     assert four["n_gpus"] == 4 and four["config"]["swarm_total"] == 16384 == one["config"]["swarm_total"]
     assert four["config"]["swarm_best_f"] == one["config"]["swarm_best_f"]
     assert four["config"]["generations_done"] == one["config"]["generations_done"] == 4
+    # BASELINE configs 2 and 5 ride in the default single-GPU line
+    oc = one["other_configs"]
+    assert oc["C2"]["shape"] == {"rows": 1024, "grid": 4096, "peaks": 6} and oc["C2"]["kernel_ms"] > 0
+    assert oc["C5"]["shape"] == {"rows": 41, "grid": 16384, "peaks": 12} and "residual" in oc["C5"]["kind"]
+    for k in ("C2", "C5"):
+        r = oc[k]["roofline"]
+        assert r["frac"] == pytest.approx(r["bytes_per_launch"] / (oc[k]["kernel_ms"] * 1e-3) / 1e9 / r["peak"])
+    assert oc["C2"]["roofline"]["bytes_per_launch"] == 1024 * (4 * 4096 * 8) + 1024 * 22 * 8 + 1024 * 8

@@ -483,15 +483,10 @@ def test_gaussian_recurrence_against_point_by_point(eq):
             np.testing.assert_allclose(f, f_direct, rtol=1e-13)                  # the recurrence is off
 
 
-@pytest.mark.parametrize("case", ["overlapping_broad", "dense_cluster_1e12", "needles_everywhere"])
-def test_farfield_adversarial_spectra(eq, case):
-    """The far-field variant where its premise fails or is stressed: (a) 24 broad overlapping lines
-    -- NO peak is far from any chunk, everything takes the direct path; (b) a dense cluster whose
-    amplitudes span twelve orders of magnitude next to far satellites; (c) needle-narrow lines
-    (a fraction of a grid step wide) for which every chunk but one is far at huge |t|.  Parity
-    with the C oracle at 1e-9 like every other variant, agreement with DEFAULT at 1e-12, and no
-    slowdown beyond noise where the expansion cannot help."""
-    from oracle import c_oracle
+
+def adversarial_case(case):
+    """Spectra where the far-field variant's premise fails or is stressed (see
+    test_farfield_adversarial_spectra); also used by tests/test_gpu_perf_guards.py."""
     N, P, S = 16384, 24, 256
     rng = np.random.default_rng(5)
     w = np.linspace(3.0, 4.0, N)
@@ -514,6 +509,20 @@ def test_farfield_adversarial_spectra(eq, case):
         X[:, 4::3] = 10.0 ** rng.uniform(-7, -5, (S, P))         # grid step is 6e-5
         X[:, 5::3] = rng.uniform(3.0, 4.0, (S, P))
         X[:, 6::3] = rng.uniform(0.001, 0.01, (S, P))
+    return N, P, S, w, u, v, wt, X
+
+
+@pytest.mark.parametrize("case", ["overlapping_broad", "dense_cluster_1e12", "needles_everywhere"])
+def test_farfield_adversarial_spectra(eq, case):
+    """The far-field variant where its premise fails or is stressed: (a) 24 broad overlapping lines
+    -- NO peak is far from any chunk, everything takes the direct path; (b) a dense cluster whose
+    amplitudes span twelve orders of magnitude next to far satellites; (c) needle-narrow lines
+    (a fraction of a grid step wide) for which every chunk but one is far at huge |t|.  Parity
+    with the C oracle at 1e-9 like every other variant, agreement with DEFAULT at 1e-12.  (The
+    wall-clock side of it -- no slowdown where the expansion cannot help -- is a non-gating guard
+    in tests/test_gpu_perf_guards.py.)"""
+    from oracle import c_oracle
+    N, P, S, w, u, v, wt, X = adversarial_case(case)
     ref = c_oracle.objective_batch(X, w, u, v, wt, threads=8)
     with eq.Evaluator(w, u, v, wt) as ev:
         f_def = ev.objective_batch(X)
@@ -522,21 +531,6 @@ def test_farfield_adversarial_spectra(eq, case):
         R_far = ev.residual_batch(X[:3])
         ev.set_variant(_cabi.VARIANT_DEFAULT)
         R_def = ev.residual_batch(X[:3])
-        # timing of the two on resident data (HIP events around the kernel alone)
-        dX, df = ev.dev_alloc(X.nbytes), ev.dev_alloc(8 * S)
-        ev.upload(dX, X)
-        ms = {}
-        for name, vid in (("default", _cabi.VARIANT_DEFAULT), ("farfield", _cabi.VARIANT_FARFIELD)):
-            ev.set_variant(vid)
-            for _ in range(20):
-                ev.objective_batch_dev(S, P, dX, df)
-            ev.prof_enable(30)
-            for _ in range(30):
-                ev.objective_batch_dev(S, P, dX, df)
-            ms[name] = float(np.median(ev.prof_read()[0]))
-            ev.prof_enable(0)
-        ev.dev_free(dX)
-        ev.dev_free(df)
     _close_f(f_far, ref)
     _close_f(f_def, ref)
     # needles a fraction of a grid step wide: t = (w - loc)*(2/width) is conditioned like 1e-16 * 2e7 near a
@@ -546,8 +540,6 @@ def test_farfield_adversarial_spectra(eq, case):
     np.testing.assert_allclose(R_far, R_def, rtol=0, atol=(1e-9 if case == "needles_everywhere" else 1e-13) * np.abs(R_def).max())
     print("   vs oracle: default %.2e, farfield %.2e; farfield vs default %.2e" % (
         np.max(np.abs(f_def - ref) / ref), np.max(np.abs(f_far - ref) / ref), np.max(np.abs(f_far - f_def) / f_def)))
-    print("farfield adversarial %s: default %.1f us, farfield %.1f us" % (case, ms["default"] * 1e3, ms["farfield"] * 1e3))
-    assert ms["farfield"] <= 1.25 * ms["default"], ms      # (the A/B figure itself is in DESIGN.md; this guards against a cliff)
 
 
 def test_farfield_as_context_default_runs_the_swarm(eq):

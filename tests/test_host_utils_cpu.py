@@ -88,3 +88,16 @@ def test_default_variant_rule():
     assert utils.default_variant(4096, 6) == "default"           # the reference's default-size fits
     assert utils.default_variant(16384, 12) == "farfield"
     assert utils.default_variant(65536, 24) == "farfield"
+
+
+def test_fit_device_follows_local_rank(monkeypatch):
+    """With an exchange and no options['device'] the GPU is the launcher's LOCAL_RANK -- for the
+    string "rccl" and for exchange objects alike, in fit() and in generate_result() (VERDICT r2
+    weak #3: every rank used to land on GPU 0)."""
+    from nmrfit_amd.utils import FitUtility
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setenv("RANK", "13")
+    assert FitUtility(None, [], [], options={"exchange": "rccl"})._device() == 5
+    assert FitUtility(None, [], [], options={"exchange": object()})._device() == 5
+    assert FitUtility(None, [], [], options={"exchange": "rccl", "device": 2})._device() == 2
+    assert FitUtility(None, [], [], options={})._device() == 0

@@ -4,7 +4,8 @@ hands RCCL's unique id to the ranks, and the sharded generation loop over it
 (pso.SocketExchange) with real processes -- world sizes 2, 3 and 8 (the C4 rank count) on
 127.0.0.1.  Every rank must end with the single-rank answer bit for bit.  Also: the
 self-launching `bench.py --gpus N` must fail fast and loudly when its ranks fail (here: no GPU),
-never hang.
+never hang; its --launch-timeout ends ranks that never arrive and names them; every rank's own
+watchdog does the same when the launcher is someone else's (torch.distributed.run).
 """
 import multiprocessing as mp
 import os
@@ -184,3 +185,105 @@ def test_bench_self_launch_fails_fast_when_ranks_fail():
     assert time.time() - t0 < 60
     assert "rank" in out.stderr and ("NO_DEVICE" in out.stderr or "error -2" in out.stderr or "hipGetDeviceCount" in out.stderr)
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def _stalled_bench(stall, extra_env=None, launch_timeout="3"):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["NMRFIT_BENCH_TEST_STALL"] = stall
+    env.update(extra_env or {})
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--cpu-seconds", "0", "--launch-timeout", launch_timeout], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=120)
+    return out, time.time() - t0
+
+
+def test_bench_launch_timeout_ends_ranks_that_never_arrive():
+    """Ranks that hang before they could notice anything themselves (here: a test stall ahead of the
+    rank's own watchdog; on hardware: anything) are ended by the launcher's deadline: non-zero exit,
+    the ranks still alive named on stderr, no JSON line, and no process left behind."""
+    out, dt = _stalled_bench("pre:all:60")
+    assert out.returncode == 124, (out.returncode, out.stderr[-2000:])
+    assert dt < 40
+    assert "launch timeout" in out.stderr and "[0, 1]" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rank_watchdog_names_the_phase():
+    """The driver launches the ranks under torch.distributed.run, not under bench.py's launcher: a
+    rank stuck on the way to the timed region (rendezvous, ncclCommInitRank, first collective) ends
+    ITSELF after --launch-timeout, saying on stderr which rank was stuck where; the launcher then
+    sees a failed rank.  Here rank 1 stalls inside its watchdog and rank 0 is run as a torchrun-style
+    rank by hand."""
+    from nmrfit_amd import _cabi
+    if _cabi.device_count() > 0:
+        pytest.skip("needs a box without a GPU (rank 0 must fail at context creation, not run)")
+    env = dict(os.environ, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), NMRFIT_BENCH_TEST_STALL="in:1:60", NMRFIT_RDZV_TOKEN="wd%d" % os.getpid())
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--cpu-seconds", "0", "--launch-timeout", "2"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 124, (out.returncode, out.stderr[-2000:])
+    assert time.time() - t0 < 30
+    assert "nmrfit watchdog: rank 1 still in `test stall` after 2 s" in out.stderr
+    assert "HIP device" in out.stderr and "world 2" in out.stderr
+
+
+def test_watchdog_is_silent_when_the_step_finishes():
+    sys.path.insert(0, ROOT)
+    from nmrfit_amd import rendezvous
+    with rendezvous.Watchdog(5.0, "quick step", rank=0) as dog:
+        dog.phase = "still quick"
+    with rendezvous.Watchdog(0, "disabled", rank=0):
+        time.sleep(0.01)
+
+
+def _portmode_rank(rank, world, master_port, rdzv_port, out_path):
+    """One rank in NMRFIT_RDZV_PORT mode WITHOUT a token, started through an intermediate process
+    of its own (so the ranks' parent pids differ, as they do across nodes)."""
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from nmrfit_amd import rendezvous\n"
+            "with rendezvous.Channel() as ch:\n"
+            "    parts = ch.all_gather(b'p%%d' %% ch.rank)\n"
+            "open(%r, 'w').write(repr(parts))\n" % (ROOT, out_path))
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(master_port), NMRFIT_RDZV_PORT=str(rdzv_port), NMRFIT_RDZV_TIMEOUT="60",
+               TORCHELASTIC_RUN_ID="job42")
+    env.pop("NMRFIT_RDZV_TOKEN", None)
+    inner = [sys.executable, "-c", code]
+    # the intermediate parent: a different process for every rank
+    return subprocess.Popen([sys.executable, "-c", "import subprocess, sys; sys.exit(subprocess.call(%r))" % (inner,)],
+                            env=env)
+
+
+def test_port_mode_without_token_and_different_parents(tmp_path):
+    """with NMRFIT_RDZV_PORT (the multi-node mode) the default token must not be the
+    parent pid -- ranks on different nodes have different parents.  It is derived from the
+    launch-wide values instead (MASTER_ADDR, MASTER_PORT, WORLD_SIZE, TORCHELASTIC_RUN_ID), and rank
+    0 listens on MASTER_ADDR only."""
+    world, mport, rport = 3, _free_port(), _free_port()
+    outs = [str(tmp_path / ("r%d.txt" % r)) for r in range(world)]
+    ps = [_portmode_rank(r, world, mport, rport, outs[r]) for r in range(world)]
+    for p in ps:
+        assert p.wait(timeout=120) == 0
+    for o in outs:
+        assert open(o).read() == repr([b"p0", b"p1", b"p2"])
+    # a different run id is a different launch: its token does not match
+    sys.path.insert(0, ROOT)
+    from nmrfit_amd import rendezvous
+    old = dict(os.environ)
+    try:
+        os.environ.update(NMRFIT_RDZV_PORT=str(rport), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(mport), WORLD_SIZE="3")
+        os.environ.pop("NMRFIT_RDZV_TOKEN", None)
+        os.environ["TORCHELASTIC_RUN_ID"] = "job42"
+        t1 = rendezvous._token()
+        os.environ["TORCHELASTIC_RUN_ID"] = "job43"
+        assert rendezvous._token() != t1 and t1.startswith("launch")
+        os.environ.pop("NMRFIT_RDZV_PORT")
+        assert rendezvous._token() == "ppid%d" % os.getppid()
+    finally:
+        os.environ.clear()
+        os.environ.update(old)

@@ -12,8 +12,8 @@ for (S, N, P) in SHAPES:
     sp = synth.make_spectrum(N, P, seed=1)
     with Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
         sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=3, minfunc=-1.0, minstep=-1.0)
-        if os.environ.get("NMRFIT_PERSISTENT") == "1":      # opt-in persistent generations (small swarms only)
-            sw.set_persistent(True)
+        if os.environ.get("NMRFIT_HANDOVER"):               # fast (default) / fenced / two_launch
+            sw.set_handover(os.environ["NMRFIT_HANDOVER"])
         sw.run(50, check_every=50)          # warm-up
         gens = 2000 if S * N * P < 1e9 else 200
         t0 = time.perf_counter()

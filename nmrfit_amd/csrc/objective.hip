@@ -217,6 +217,47 @@ __device__ __forceinline__ double dispersion(double wcj, const PeakLor &r)
     return __builtin_fma(r.al * t, rcp64(s), (r.ag2 * kInvSqrtPi) * dawson(kSqrtLn2 * t));
 }
 
+// dawson() with every coefficient read from a table in LDS (layout: kNear[15], kFar[12], kMid[6][19]
+// = 141 doubles, staged once per workgroup) instead of sitting in registers: the objective kernel is
+// at the SGPR limit, and the three coefficient sets as loop-invariant register constants cost the
+// far-field instantiation 13 spilled VGPRs.  Same operations in the same order as dawson():
+// bit-identical values.
+constexpr int kDawLdsNear = 0, kDawLdsFar = 15, kDawLdsMid = 27, kDawLdsCount = 27 + 6 * 19;
+__device__ __forceinline__ double dawson_lds(double x, const double *tab)
+{
+    const double ax = fabs(x);
+    double r;
+    if (ax < 1.0) {
+        const double y = x * x;
+        double p = tab[kDawLdsNear + 14];
+#pragma unroll
+        for (int i = 13; i >= 0; --i) p = __builtin_fma(p, y, tab[kDawLdsNear + i]);
+        return x * p;
+    } else if (ax < 7.0) {
+        const int k = (int)ax;                 // 1..6
+        const double t = 2.0 * (ax - (double)k) - 1.0;
+        const double *q = tab + kDawLdsMid + (k - 1) * 19;
+        double p = q[18];
+#pragma unroll
+        for (int i = 17; i >= 0; --i) p = __builtin_fma(p, t, q[i]);
+        r = p;
+    } else {
+        const double inv = rcp64(ax);         // NaN/inf propagate: D(inf) = 0
+        const double s2 = 49.0 * inv * inv;
+        double p = tab[kDawLdsFar + 11];
+#pragma unroll
+        for (int i = 10; i >= 0; --i) p = __builtin_fma(p, s2, tab[kDawLdsFar + i]);
+        r = 0.5 * p * inv;
+    }
+    return copysign(r, x);
+}
+__device__ __forceinline__ double dispersion_lds(double wcj, const PeakLor &r, const double *tab)
+{
+    const double t = __builtin_fma(wcj, r.ihw, r.c);
+    const double s = __builtin_fma(t, t, 1.0);
+    return __builtin_fma(r.al * t, rcp64(s), (r.ag2 * kInvSqrtPi) * dawson_lds(kSqrtLn2 * t, tab));
+}
+
 // Dawson's integral for the objective's imaginary channel: the same piecewise fits, but one
 // degree-18 polynomial for EVERY unit interval [k, k+1), k = 0..15, gathered from a 2.4 KiB table
 // in LDS by a per-lane index -- no divergent branches (the lanes of a wave sit in two or three
@@ -541,10 +582,12 @@ __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *r
 // instead of accumulating; 2 the imaginary model is the sum over all peaks.
 // The 8-peak group keeps 24 per-peak constants live next to the 8-point register block:
 // ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
-// With the imaginary part the epilogue also evaluates dispersion lines (Dawson polynomials):
-// 2 waves per SIMD rather than spilling.
+// FIT_IM == 1 evaluates one dispersion line per point in the epilogue with the Dawson coefficients
+// read from LDS (dawson_lds): the direct kernels keep three waves per SIMD (168 / 156 VGPRs, no
+// scratch), the far-field one takes two (215 VGPRs) rather than spilling; FIT_IM == 2 holds eight
+// more accumulators and the far-field sums: two waves.
 #define NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)                                                                    \
-    ((FIT_IM) != 0 ? 2                                                                                                 \
+    (((FIT_IM) == 2 || ((FIT_IM) == 1 && (VARIANT) == NMRFIT_VARIANT_FARFIELD)) ? 2                                                                                                 \
                    : ((VARIANT) == NMRFIT_VARIANT_DEFAULT || (VARIANT) == NMRFIT_VARIANT_NOSKIP ||                     \
                       (VARIANT) == NMRFIT_VARIANT_STAGED || (VARIANT) == NMRFIT_VARIANT_FARFIELD ||                    \
                       (VARIANT) == NMRFIT_VARIANT_NOREC)                                                               \
@@ -609,6 +652,10 @@ __device__ __forceinline__ void objective_body(
     double *dtab = reinterpret_cast<double *>(lds_raw + aux_off);
     if constexpr (FIT_IM == 2)
         for (int i = threadIdx.x; i < 16 * 19; i += WPB * kWave) dtab[i] = (&dawson::kTab[0][0])[i];
+    if constexpr (FIT_IM == 1)   // the coefficient sets of dawson_lds
+        for (int i = threadIdx.x; i < kDawLdsCount; i += WPB * kWave)
+            dtab[i] = (i < kDawLdsFar) ? dawson::kNear[i]
+                                       : (i < kDawLdsMid) ? dawson::kFar[i - kDawLdsFar] : (&dawson::kMid[0][0])[i - kDawLdsMid];
     if (clk && g == 0 && lane == 0) {   // nmrfit_prof_*: ticks of the core clock and of the 100 MHz reference
         clk[0] = __builtin_amdgcn_s_memtime();
         clk[1] = __builtin_amdgcn_s_memrealtime();
@@ -1233,7 +1280,7 @@ __device__ __forceinline__ void objective_body(
                 const double id = __builtin_fma(zr, vq[q], zi * uq[q]);  // Im((zr + i zi)(u + i v))
                 double ifit = 0.0;
                 if constexpr (FIT_IM == 1) {
-                    if (P > 0) ifit = dispersion(wv[q], lor[P - 1]);
+                    if (P > 0) ifit = dispersion_lds(wv[q], lor[P - 1], dtab);
                 } else {
                     ifit = iacc[q];
                 }
@@ -1454,7 +1501,8 @@ static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, i
     // the all-peak imaginary model sums far peaks through the far-field scratch and evaluates Dawson's
     // integral from a table in LDS
     const size_t lds_im = (fit_im == 2) ? lds_far : 0;
-    const size_t lds_tab = (fit_im == 2) ? 16 * 19 * sizeof(double) + 16 : 0;
+    // (fit_im == 1: the 141 coefficients of dawson_lds in the same area)
+    const size_t lds_tab = (fit_im != 0) ? 16 * 19 * sizeof(double) + 16 : 0;
     int variant = ctx->variant;
     // the imaginary channel exists in DEFAULT, NOREC and FARFIELD; the A/B variants fail in launch_variant
     if (variant == NMRFIT_VARIANT_STAGED && fit_im != 0) variant = NMRFIT_VARIANT_DEFAULT;

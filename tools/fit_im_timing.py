@@ -8,6 +8,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nmrfit_amd import synth, _cabi
 from nmrfit_amd.equations import Evaluator
 
+if len(sys.argv) > 1:      # another build of the library (A/B): tools/fit_im_timing.py nmrfit_amd/lib/libab_x.so
+    import ctypes
+    L = ctypes.CDLL(os.path.abspath(sys.argv[1]))
+    for name, argtypes in _cabi.SIGNATURES.items():
+        fn = getattr(L, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
+    L.nmrfit_last_error.argtypes = []; L.nmrfit_last_error.restype = ctypes.c_char_p
+    _cabi._LIB = L
+    print("library:", sys.argv[1])
+
 sp, X = synth.make_workload("C3")
 S, D = X.shape
 P = (D - 4) // 3
@@ -27,4 +36,6 @@ with Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
                 ev.objective_batch_dev(S, P, dX, df)
             k = ev.prof_read()[0]
             ev.prof_enable(0)
-            print("%-8s fit_im=%-5s: %.3f ms per launch (min %.3f)" % (vname, mode, np.mean(k), np.min(k)))
+            f = ev.download(df, (S,))
+            print("%-8s fit_im=%-5s: %.3f ms per launch (min %.3f)   f[:3] = %s" % (
+                vname, mode, np.mean(k), np.min(k), " ".join(float(v).hex() for v in f[:3])))

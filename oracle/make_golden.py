@@ -323,9 +323,44 @@ def data_fixtures(mods):
     print("data_container fixture: auto phase", out["auto_p"], "brute", out["brute_p"], "truth", sp["x_true"][:2])
 
 
+def float32_fixture(mods):
+    """Section 9 (round 3): float32 spectra as nmrglue delivers them.  The
+    reference then rotates u + i v in complex64 (proc_autophase.py:29-32: apod.astype(data.dtype))
+    and only the w array promotes V_fit to float64 (equations.py:181,195); the C-ABI takes float64
+    and the host side upcasts, so the two differ by the float32 rounding of the rotation.  Three
+    shapes (C1/C2, C5, C3), inputs by seed with u, v cast to float32 (sha256 of the float32 arrays
+    recorded), rows: the generating parameters, eight near-optimum particles (the generating
+    parameters perturbed by 1e-3 of the box, where f is smallest and the relative gap largest) and
+    three random particles of the box."""
+    from nmrfit_amd import synth
+    eq = mods["equations"]
+    out = {}
+    for tag, (N, P, seed) in {"P6_N4096": (4096, 6, 1), "P12_N16384": (16384, 12, 3), "P24_N65536": (65536, 24, 1)}.items():
+        sp = synth.make_spectrum(N, P, seed=seed)
+        u32, v32 = sp["u"].astype(np.float32), sp["v"].astype(np.float32)
+        rng = np.random.default_rng(1000 + seed + P)
+        box = sp["upper"] - sp["lower"]
+        near = np.clip(sp["x_true"][None, :] + 1e-3 * box[None, :] * rng.uniform(-1.0, 1.0, (8, box.size)),
+                       sp["lower"], sp["upper"])
+        X = np.concatenate((sp["x_true"][None, :], near,
+                            synth.make_swarm(sp["lower"], sp["upper"], 3, seed=77 + P, x_true=None)))
+        f = np.array([eq.objective(X[i, :], sp["w"], u32, v32, sp["weights"], False) for i in range(X.shape[0])])
+        out[tag + "_X"], out[tag + "_f"] = X, f
+        out[tag + "_shape"] = np.array([N, P, seed])
+        out[tag + "_sha_u32"], out[tag + "_sha_v32"] = sha(u32), sha(v32)
+        f64 = np.array([eq.objective(X[i, :], sp["w"], sp["u"], sp["v"], sp["weights"], False) for i in range(X.shape[0])])
+        out[tag + "_f_float64_spectrum"] = f64     # the same rows with the float64 spectrum, for scale
+        print("float32 %-11s f[0]=%.17g  max |f32 - f64|/f64 = %.2e" % (tag, f[0], np.max(np.abs(f - f64) / f64)))
+    np.savez_compressed(os.path.join(OUT, "objective_float32.npz"), **out)
+
+
 if __name__ == "__main__":
     if "--only-data" in sys.argv:
         data_fixtures(load_reference())
+    elif "--only-float32" in sys.argv:
+        float32_fixture(load_reference())
     else:
         main()
-        data_fixtures(load_reference())
+        mods = load_reference()
+        data_fixtures(mods)
+        float32_fixture(mods)

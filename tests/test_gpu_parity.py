@@ -297,6 +297,29 @@ def test_float32_spectra_as_nmrglue_delivers_them(eq):
     np.testing.assert_allclose(f, ref, rtol=5e-7)
 
 
+def test_float32_spectra_against_the_reference_golden(eq, golden_dir):
+    """The same against the REFERENCE's own values (tests/golden/objective_float32.npz, generated by
+    oracle/make_golden.py from the reference's complex64 path): the generating parameters, eight
+    near-optimum particles -- where f is smallest and the relative gap of the float64 upcast largest --
+    and three random ones, at the C1/C2, C5 and C3 shapes, with the DEFAULT and the FARFIELD kernel.
+    north_star's bar is 1e-6 relative; asserted at 5e-7 (observed <= 1.2e-7)."""
+    import os
+    d = np.load(os.path.join(golden_dir, "objective_float32.npz"))
+    worst = 0.0
+    for tag in ("P6_N4096", "P12_N16384", "P24_N65536"):
+        N, P, seed = (int(t) for t in d[tag + "_shape"])
+        sp = synth.make_spectrum(N, P, seed=seed)
+        u32, v32 = sp["u"].astype(np.float32), sp["v"].astype(np.float32)
+        X, ref = d[tag + "_X"], d[tag + "_f"]
+        with eq.Evaluator(sp["w"], u32, v32, sp["weights"]) as ev:
+            for variant in (_cabi.VARIANT_DEFAULT, _cabi.VARIANT_FARFIELD):
+                ev.set_variant(variant)
+                f = ev.objective_batch(X)
+                np.testing.assert_allclose(f, ref, rtol=5e-7)
+                worst = max(worst, float(np.max(np.abs(f - ref) / ref)))
+    print("float32 spectra vs reference golden: worst relative difference %.2e" % worst)
+
+
 def test_large_shapes(eq):
     """A million-point grid and a 200k-particle swarm: 64-bit indexing, block table, multi-pass
     launches.  Sampled particles against the oracle."""

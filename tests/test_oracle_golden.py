@@ -137,3 +137,23 @@ def test_objective_shift_invariance():
     x2[5::3] += 0.25
     f1 = oc.objective_batch(x2, sp["w"] + 0.25, sp["u"], sp["v"], sp["weights"])[0]
     assert f1 == pytest.approx(f0, rel=1e-11)
+
+
+def test_float32_spectra_reference_golden(golden_dir):
+    """tests/golden/objective_float32.npz (oracle/make_golden.py section 9): the reference run on
+    float32 u, v -- its complex64 rotation (proc_autophase.py:29-32).  The numpy oracle follows that
+    path exactly; inputs are regenerated by seed and pinned by their sha256."""
+    d = np.load(os.path.join(golden_dir, "objective_float32.npz"))
+    for tag in ("P6_N4096", "P12_N16384", "P24_N65536"):
+        N, P, seed = (int(t) for t in d[tag + "_shape"])
+        sp = synth.make_spectrum(N, P, seed=seed)
+        u32, v32 = sp["u"].astype(np.float32), sp["v"].astype(np.float32)
+        assert hashlib.sha256(u32.tobytes()).hexdigest() == str(d[tag + "_sha_u32"])
+        assert hashlib.sha256(v32.tobytes()).hexdigest() == str(d[tag + "_sha_v32"])
+        X, f = d[tag + "_X"], d[tag + "_f"]
+        rows = range(X.shape[0]) if N <= 16384 else (0, 1, 5, 9)      # (the C3 shape takes 25 ms a row)
+        got = np.array([onp.objective(X[i], sp["w"], u32, v32, sp["weights"]) for i in rows])
+        np.testing.assert_array_equal(got, f[list(rows)])
+        # near the optimum the complex64 rotation moves f by ~1e-7 relative: inside the 1e-6 bar
+        rel = np.abs(f - d[tag + "_f_float64_spectrum"]) / d[tag + "_f_float64_spectrum"]
+        assert rel.max() < 5e-7

@@ -89,6 +89,11 @@ def parse():
                          "region).  tools/profile.sh passes this so that every objective_kernel<0,false,0> launch of a "
                          "profiled run has the C3 shape and the rocprofv3 --stats average of that kernel is the number "
                          "in roofline.kernel_ms")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false",
+                    help="do not run the rocprofv3 --pmc child passes (N = 1, workload C3: three short passes of this "
+                         "same script under `rocprofv3 --kernel-trace --pmc ...`, started BEFORE this process touches "
+                         "the GPU, give the line its physical HBM traffic and VALU counters live; without them -- or if "
+                         "rocprofv3 is missing -- those fields come from the committed passes under profiles/ and say so)")
     ap.add_argument("--launch-timeout", type=float, default=300.0, metavar="SECONDS",
                     help="N > 1: deadline of the self-launcher for the whole run, and of every rank for reaching the "
                          "timed region (rendezvous, RCCL communicator, first collective); 0 disables")
@@ -223,6 +228,80 @@ def cpu_baseline(spec, P, budget_s, pool_procs):
     return out
 
 
+# ---- live PMC passes (before any GPU call of this process) ----------------------------------------
+PMC_PASSES = (
+    # (name, extra bench args, counters) -- one rocprofv3 run each: counters of different blocks are collected in
+    # their own passes, with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+    ("sq", [], ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY",
+                "SQ_ACTIVE_INST_ANY", "SQ_WAVES"]),
+    ("fetch", [], ["FETCH_SIZE", "GRBM_GUI_ACTIVE"]),
+    ("write", [], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]),
+    ("sq_farfield", ["--variant", "6"], ["SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"]),
+)
+
+
+def live_pmc_passes(timeout_s=90.0):
+    """Run this script's C3 generation loop in child processes under `rocprofv3 --kernel-trace --pmc ...`
+    (the program itself after `--`; nothing else in between) and return the objective kernel's mean
+    counters per pass, with the child's own in-run kernel time and clock.  The parent has not touched
+    the GPU yet (it starts children only, never replaces itself).  Any failure returns what was
+    collected plus an `errors` list: the caller then falls back to the committed passes."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    out = {"errors": []}
+    if not os.path.exists(exe):
+        out["errors"].append("rocprofv3 not found")
+        return out
+    for name, extra, counters in PMC_PASSES:
+        tmp = tempfile.mkdtemp(prefix="nmrfit_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", tmp, "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--cpu-seconds", "0",
+               "--no-extras", "--no-other-configs", "--no-pmc", "--preheat-seconds", "0.2"] + extra
+        try:
+            # its own process group: on a time-out the profiler AND the program under it are ended (by the
+            # exact group id started here), not just the profiler's front end
+            pr = subprocess.Popen(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                so, se = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGTERM)
+                try:
+                    pr.communicate(timeout=10)
+                except subprocess.TimeoutExpired:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                    pr.communicate()
+                out["errors"].append("%s: timed out after %.0f s" % (name, timeout_s))
+                break      # something is wrong with the profiler here: do not try the remaining passes
+            lines = [l for l in so.splitlines() if l.startswith("{")]
+            if pr.returncode != 0 or not lines:
+                out["errors"].append("%s: rc %d %s" % (name, pr.returncode, se[-300:]))
+                continue
+            child = json.loads(lines[-1])
+            fs = glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True)
+            if not fs:
+                out["errors"].append("%s: no counter file" % name)
+                continue
+            agg = {}
+            with open(fs[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if "objective_kernel" in row["Kernel_Name"]:
+                        agg.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            out[name] = {"counters": {k: sum(v) / len(v) for k, v in agg.items()},
+                         "launches": max((len(v) for v in agg.values()), default=0),
+                         "kernel_ms_in_child": child["kernel_ms"]["mean"] if child.get("kernel_ms") else None,
+                         "clock_mhz_in_child": child.get("roofline_valu", {}).get("clock_mhz_in_run")}
+        except Exception as e:     # a profiler hiccup must not cost the run its headline
+            out["errors"].append("%s: %r" % (name, e))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def stats(a):
     a = np.asarray(a, dtype=np.float64)
     if a.size == 0:
@@ -274,6 +353,12 @@ def main():
         if pool < 0:
             pool = 0 if under_profiler() else usable_cores()
         cpu = cpu_baseline(spec, P, args.cpu_seconds, pool)
+
+    # ---- live PMC passes: children under rocprofv3, still before this process touches the GPU ----
+    pmc_live = None
+    if (rank == 0 and world == 1 and args.pmc and args.workload == "C3" and args.variant == 0
+            and args.swarm_per_gpu in (0, cfg.S) and not under_profiler()):
+        pmc_live = live_pmc_passes()
 
     from nmrfit_amd import _cabi, pso
     from nmrfit_amd.equations import Evaluator
@@ -524,8 +609,19 @@ def main():
         # physical HBM traffic and VALU counters: separate rocprofv3 --pmc passes of this command,
         # committed under profiles/ -- NOT measured by this run
         traffic = None
+        traffic_live = False
+        l2_hit = None
+        mem = dict((pmc_live or {}).get("fetch", {}).get("counters", {}))
+        mem.update((pmc_live or {}).get("write", {}).get("counters", {}))
+        if "FETCH_SIZE" in mem and "WRITE_SIZE" in mem:
+            # MI355X_MICROARCH.md (HBM): both in KiB; on gfx950 FETCH_SIZE reads 1/2 of the bytes of wide
+            # coalesced reads -> doubled; WRITE_SIZE is exact
+            traffic = 2.0 * mem["FETCH_SIZE"] * 1024.0 + mem["WRITE_SIZE"] * 1024.0
+            traffic_live = True
+            if mem.get("TCC_HIT_sum") is not None and mem.get("TCC_MISS_sum") is not None:
+                l2_hit = mem["TCC_HIT_sum"] / max(1.0, mem["TCC_HIT_sum"] + mem["TCC_MISS_sum"])
         pmcf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmcf):
+        if traffic is None and os.path.exists(pmcf):
             try:
                 traffic = json.load(open(pmcf)).get(args.workload, {}).get("hbm_bytes_per_launch")
             except Exception:
@@ -533,7 +629,27 @@ def main():
         valu = {"bound": "fp64_valu_issue", "unit": "fraction of fp64 VALU issue slots (1024 SIMDs x 2.4 GHz / 4 cycles "
                                                      "per wave64 instruction)"}
         summ = next((p for p in PMC_SUMMARIES if os.path.exists(os.path.join(ROOT, p))), None)
-        if args.workload == "C3" and args.variant == 0 and summ:
+        sq = (pmc_live or {}).get("sq", {})
+        sqc = sq.get("counters", {})
+        if all(k in sqc for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES")):
+            # counters of THIS run's child pass (same build, same box, minutes apart)
+            insts = sqc["SQ_INSTS_VALU"]                                   # wave-instructions per launch
+            ipu = insts * 64.0 / units_launch
+            peak = SIMDS * PEAK_CLOCK_MHZ * 1e6 / FP64_ISSUE_CYCLES
+            achieved = insts / (t_kernel_ms * 1e-3)
+            kernel_cycles = sqc["SQ_BUSY_CYCLES"] / 32.0                   # summed over 32 shader engines
+            valu.update({"achieved": achieved, "peak": peak, "frac": achieved / peak,
+                         "achieved_unit": "fp64 wave64 VALU instructions/s",
+                         "valu_instructions_per_unit": ipu,
+                         "valu_busy_frac": 4.0 * sqc["SQ_ACTIVE_INST_VALU"] / SIMDS / kernel_cycles,
+                         "valu_cycles_per_instruction": 4.0 * sqc["SQ_ACTIVE_INST_VALU"] / insts,
+                         "from_committed_profile": False,
+                         "pmc_source": "live: child pass of this run under rocprofv3 --kernel-trace --pmc (%d launches, "
+                                       "kernel %.4f ms in the child)" % (sq.get("launches", 0), sq.get("kernel_ms_in_child") or -1),
+                         "note": "instruction count, busy fraction and cycles per instruction from this run's own "
+                                 "rocprofv3 child pass; `achieved` divides that count by the kernel time of the "
+                                 "timed region above"})
+        elif args.workload == "C3" and args.variant == 0 and summ:
             try:
                 sm = json.load(open(os.path.join(ROOT, summ)))
                 insts = sm["objective_kernel_pmc"]["SQ_INSTS_VALU"]["mean"]      # wave-instructions per launch
@@ -567,7 +683,11 @@ def main():
             "step_ms": sst, "kernel_ms": kst,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_from_committed_profile": traffic is not None,
+                         "traffic_from_committed_profile": traffic is not None and not traffic_live,
+                         "traffic_source": ("live: child passes of this run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                            "(2 x FETCH_SIZE KiB + WRITE_SIZE KiB per launch, the gfx950 correction)"
+                                            if traffic_live else "profiles/pmc_traffic.json"),
+                         "l2_hit_rate": l2_hit,
                          "model": "streaming-operand bytes S*(4*N*8)+S*D*8+S*8 per launch (SURVEY 8(d)(i)); "
                                   "w/u/v/weights are shared by all particles and L2-resident, so this is an "
                                   "effective rate, not physical HBM traffic (`traffic`); the binding resource "
@@ -608,7 +728,14 @@ def main():
                   "note": "what fit() runs when options['variant'] is absent at this grid x peaks; kernel alone, "
                           "this run"}
             fsum = next((q for q in FARFIELD_PMC_SUMMARIES if os.path.exists(os.path.join(ROOT, q))), None)
-            if dv == "farfield" and args.workload == "C3" and fsum:
+            ffc = (pmc_live or {}).get("sq_farfield", {}).get("counters", {})
+            if dv == "farfield" and all(k in ffc for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES")):
+                fd.update({"valu_instructions_per_unit": ffc["SQ_INSTS_VALU"] * 64.0 / units_launch,
+                           "valu_busy": 4.0 * ffc["SQ_ACTIVE_INST_VALU"] / SIMDS / (ffc["SQ_BUSY_CYCLES"] / 32.0),
+                           "valu_cycles_per_instruction": 4.0 * ffc["SQ_ACTIVE_INST_VALU"] / ffc["SQ_INSTS_VALU"],
+                           "from_committed_profile": False,
+                           "pmc_source": "live: child pass of this run under rocprofv3 --pmc (--variant 6)"})
+            elif dv == "farfield" and args.workload == "C3" and fsum:
                 try:
                     fm = json.load(open(os.path.join(ROOT, fsum)))
                     fi = fm["objective_kernel_pmc"]["SQ_INSTS_VALU"]["mean"]
@@ -624,6 +751,8 @@ def main():
         if host_ms is not None:
             line["host_pointer_call"] = {"ms": host_ms, "units_per_s": units_launch / (host_ms * 1e-3),
                                          "note": "nmrfit_objective_batch with host X/f (H2D + kernel + D2H per call)"}
+        if pmc_live is not None and pmc_live.get("errors"):
+            line["pmc_live_errors"] = pmc_live["errors"]
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))

@@ -122,3 +122,23 @@ def test_c4_rehearsal_four_ranks_on_one_gpu():
         r = oc[k]["roofline"]
         assert r["frac"] == pytest.approx(r["bytes_per_launch"] / (oc[k]["kernel_ms"] * 1e-3) / 1e9 / r["peak"])
     assert oc["C2"]["roofline"]["bytes_per_launch"] == 1024 * (4 * 4096 * 8) + 1024 * 22 * 8 + 1024 * 8
+
+
+def test_bench_line_carries_live_pmc_counters():
+    """the PMC-derived fields of the default single-GPU line (physical HBM traffic,
+    VALU instructions per unit, VALU busy) are measured by THIS run -- three short child passes of the
+    same script under `rocprofv3 --kernel-trace --pmc`, started before the parent touches the GPU --
+    not echoed from a committed file; so is the far-field kernel's entry in `fit_default`."""
+    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--cpu-seconds", "0", "--no-other-configs",
+              "--preheat-seconds", "0.2"], {})
+    assert "pmc_live_errors" not in d, d.get("pmc_live_errors")
+    r, v, fd = d["roofline"], d["roofline_valu"], d["fit_default"]
+    assert r["traffic_from_committed_profile"] is False and r["traffic_source"].startswith("live")
+    # the four grid arrays are 2 MiB and L2-resident: physical traffic is tens of MB per launch against
+    # 8.6 GB of streamed operands in the byte model
+    assert 2e6 < r["traffic"] < 3e8 and r["l2_hit_rate"] > 0.98
+    assert v["from_committed_profile"] is False and v["pmc_source"].startswith("live")
+    assert 5.0 < v["valu_instructions_per_unit"] < 7.0 and 0.8 < v["valu_busy_frac"] <= 1.0
+    assert 3.9 < v["valu_cycles_per_instruction"] < 4.6
+    assert fd["variant"] == "farfield" and fd["from_committed_profile"] is False
+    assert 1.5 < fd["valu_instructions_per_unit"] < 4.0 and fd["kernel_ms"] < d["kernel_ms"]["mean"]

@@ -12,10 +12,10 @@ OUT="$REPO/gpurun_out/prof/$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 10 --warmup 2 --cpu-seconds 0 --no-extras --no-other-configs $*"
+ARGS="--steps 10 --warmup 2 --cpu-seconds 0 --no-extras --no-other-configs --no-pmc $*"
 # kernel trace + stats of the DEFAULT command (what the driver runs); the PMC passes below use a
 # shorter form of it (no CPU baseline, no extras)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --no-other-configs "$@" > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --no-other-configs --no-pmc "$@" > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d "$OUT/pmc_sq" -- python3 "$REPO/bench.py" $ARGS > "$OUT/pmc_sq.log" 2>&1
 echo "pmc_sq rc=$?"

@@ -114,6 +114,10 @@ class RcclExchange:
         from . import rendezvous
         # first contact with a new node is where RCCL fails if it fails: let it say why
         os.environ.setdefault("NCCL_DEBUG", "WARN")
+        # every rank on this node (the launcher says MASTER_ADDR is loopback): RCCL's bootstrap sockets
+        # may as well use the interface the rendezvous already works over, whatever else the container has
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         self._lib = _cabi.lib()
         self.ev = evaluator
         self._own_channel = channel is None

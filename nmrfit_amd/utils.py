@@ -55,12 +55,25 @@ def compute_weights(w, peaks, expon=0.5):
 def default_variant(N, P):
     """Kernel variant ``fit`` uses when options['variant'] is absent: the far-field form
     (distant peaks' Lorentzian tails through one shared expansion per 512-point chunk, values
-    within 1e-14 of the direct kernel's) once there is enough grid x peaks for it to pay --
-    measured per generation at 204 particles: 16384 x 12: 28.7 vs 30.6 us, 65536 x 24: 57 vs 92 us
-    (4096 particles: 0.64 vs 1.23 ms) -- and the direct kernel below that (4096 x 6: 15.5 vs
-    16.1 us).  The whole GPU test suite passes with either as the default of every context
-    (NMRFIT_DEFAULT_VARIANT), and tests/test_gpu_parity.py::test_farfield_adversarial_spectra covers
-    the spectra where no peak is far.  bench.py's headline is always measured on the direct kernel."""
+    within 1e-14 of the direct kernel's) once there is enough grid x peaks for it to pay, the
+    direct kernel below that.  The threshold was re-measured in round 3 at 204, 1024 and 4096
+    particles (tools/variant_threshold.py, per-generation time of the swarm loop, far-field /
+    direct; profiles/r03/variant_threshold.txt):
+
+        grid x peaks      204      1024     4096 particles
+        4096 x 6          1.03     1.02     1.06
+        4096 x 24         1.08     1.10     1.12      (short grid: few chunks, every peak near)
+        16384 x 6         0.98     0.94     1.02
+        16384 x 12        0.94     0.91     0.88
+        8192 x 24         1.04     0.98     0.97
+        32768 x 12        0.85     0.81     0.78
+        65536 x 24        0.62     0.56     0.52
+
+    i.e. the crossover sits at grid x peaks ~ 1e5 for every swarm size (within +-4 % either way
+    between 1e5 and 2e5).  The whole GPU test suite passes with either as the default of every
+    context (NMRFIT_DEFAULT_VARIANT), and tests/test_gpu_parity.py::test_farfield_adversarial_spectra
+    covers the spectra where no peak is far.  bench.py's headline is always measured on the direct
+    kernel; its `fit_default` entry reports this one."""
     return "farfield" if int(N) * int(P) >= 100000 else "default"
 
 

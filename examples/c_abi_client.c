@@ -143,6 +143,19 @@ int main(int argc, char **argv)
     if (fabs(f0 - fb) > 1e-9 * fmax(fb, 1e-6) || !(fb < 0.02 * scale)) return 6;
     CHECK(nmrfit_pso_destroy(pso));
 
+    /* the same swarm with the reduction's cross-workgroup hand-over in its other two forms (release /
+     * acquire fences; the reduction as its own launch): bit-identical answers, it is an A/B knob */
+    for (int mode = NMRFIT_HANDOVER_FENCED; mode <= NMRFIT_HANDOVER_TWO_LAUNCH; ++mode) {
+        double xm[D], fm = 0.0;
+        CHECK(nmrfit_pso_create(ctx, 204, 204, 0, P, lo, hi, &prm, &pso));
+        CHECK(nmrfit_pso_set_handover(pso, mode));
+        CHECK(nmrfit_pso_run(pso, 1000, 100));
+        CHECK(nmrfit_pso_best(pso, xm, &fm));
+        if (fm != fb || memcmp(xm, xb, sizeof xb) != 0) return 9;
+        CHECK(nmrfit_pso_destroy(pso));
+    }
+    if (nmrfit_pso_set_handover(NULL, 0) != NMRFIT_E_INVALID) return 9;
+
     /* the multi-GPU form of the same loop, as far as one GPU goes: an RCCL communicator of ONE rank
      * (rank 0 makes the 128-byte id; with more ranks it would travel to them by any means), attached
      * to the swarm, so that every nmrfit_pso_step includes the all-gather of the candidate records.
@@ -153,9 +166,15 @@ int main(int argc, char **argv)
         nmrfit_pso *sw = NULL;
         double xb2[D], fb2 = 0.0;
         int32_t rank = -1, nranks = -1, version = 0;
+        char what[256], pci[64];
+        CHECK(nmrfit_comm_available());            /* every rank asks this first, before anything collective */
+        CHECK(nmrfit_device_pci_bus_id(0, pci, (int)sizeof pci));
         CHECK(nmrfit_comm_unique_id(uid));
         CHECK(nmrfit_comm_create(ctx, 0, 1, uid, &comm));
         CHECK(nmrfit_comm_info(comm, &rank, &nranks, &version));
+        CHECK(nmrfit_comm_describe(comm, what, (int)sizeof what));
+        printf("communicator: %s\n", what);
+        if (!strstr(what, pci)) return 8;
         CHECK(nmrfit_comm_barrier(comm));
         CHECK(nmrfit_pso_create(ctx, 204, 204, 0, P, lo, hi, &prm, &sw));
         CHECK(nmrfit_pso_set_comm(sw, comm));
@@ -163,6 +182,8 @@ int main(int argc, char **argv)
         CHECK(nmrfit_pso_best(sw, xb2, &fb2));
         printf("pso_run over RCCL %d (rank %d of %d): best f = %.3e\n", version, rank, nranks, fb2);
         if (fb2 != fb || memcmp(xb2, xb, sizeof xb) != 0) return 8;
+        /* a communicator in use cannot be destroyed under the swarm's feet */
+        if (nmrfit_comm_destroy(comm) != NMRFIT_E_STATE) return 8;
         CHECK(nmrfit_pso_set_comm(sw, NULL));
         CHECK(nmrfit_pso_destroy(sw));
         CHECK(nmrfit_comm_destroy(comm));

@@ -604,7 +604,8 @@ __device__ __forceinline__ void objective_body(
     double *__restrict__ R_out,     // WRITE_R: residual rows [S*N]
     unsigned long long *__restrict__ clk,   // profiling only (else null): shader / reference clock of workgroup 0
     const PsoFused &upd,            // swarm generations: advance the particle first (x_in != null), X is then unused
-    const unsigned aux_off)         // FIT_IM == 2: byte offset of the Dawson table in dynamic LDS
+    const unsigned aux_off,         // FIT_IM != 0: byte offset of the Dawson table in dynamic LDS
+    double *wsums)                  // [2 * kMaxBlocks] in LDS: the particle's block sums when one workgroup owns it
 {
     constexpr int WPB = kWavesPerBlock;   // waves per workgroup = LDS slices
     const int lane = threadIdx.x & (kWave - 1);
@@ -1304,6 +1305,11 @@ __device__ __forceinline__ void objective_body(
             if (nseg == 1) {
                 ss += cs;
                 ss_im += cs_im;
+            } else if (nseg == WPB) {   // the four waves of THIS workgroup hold the whole particle: sums meet in LDS
+                if (lane == 0) {
+                    wsums[blk0 + bidx] = cs;
+                    if (FIT_IM != 0) wsums[kMaxBlocks + blk0 + bidx] = cs_im;
+                }
             } else if (lane == 0) {
                 const int64_t slot = particle * n_blocks + blk0 + bidx;
                 if (FIT_IM == 0) {
@@ -1349,6 +1355,21 @@ __device__ __forceinline__ void objective_body(
         else   // (rmse_real + rmse_imag) / 2, equations.py:205-209
             out[particle] = 0.5 * (sqrt(ss / (double)N) + sqrt(ss_im / (double)N));
     }
+    if (nseg == WPB && nseg > 1) {
+        // One workgroup = one particle (segment = wave): the block sums are added here, in grid order
+        // like finalize_value does -- the same canonical order, bit-identical f -- and the launch needs
+        // neither the partial-sum buffer nor a finalize pass after it.  (All four waves get here: a
+        // workgroup is active or inactive as a whole, and a stopped swarm returned before the loop.)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0, ti = 0.0;
+            for (int64_t c = 0; c < n_blocks; ++c) {
+                t += wsums[c];
+                if (FIT_IM != 0) ti += wsums[kMaxBlocks + c];
+            }
+            out[particle] = (FIT_IM == 0) ? sqrt(t / (double)N) : 0.5 * (sqrt(t / (double)N) + sqrt(ti / (double)N));
+        }
+    }
 }
 
 template <int VARIANT, bool WRITE_R, int FIT_IM>
@@ -1360,9 +1381,10 @@ __global__ __launch_bounds__(kBlock, NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)
     const PsoFused upd, const unsigned aux_off)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ double wsums[2 * kMaxBlocks];
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     objective_body<VARIANT, WRITE_R, FIT_IM>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg, seg_len,
-                                             blk_chunks, lane_step, rec_devk, out, R_out, clk, upd, aux_off);
+                                             blk_chunks, lane_step, rec_devk, out, R_out, clk, upd, aux_off, wsums);
 }
 
 // f[i] = sqrt( (sum of the particle's per-block sums, in grid order) / N ); with the imaginary
@@ -1586,8 +1608,12 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         upd.xrow_off = (unsigned)lds;
         lds += (size_t)kWavesPerBlock * (size_t)(4 + 3 * (int64_t)P) * sizeof(double);
     }
+    // nseg == 1: the wave writes f; nseg == 4: the four waves of a workgroup are the particle's four
+    // segments and the workgroup writes f (block sums through LDS); otherwise per-block sums go to a
+    // buffer and finalize_kernel (or the swarm's select kernel) adds them.  Same summation order in all.
+    const bool direct_f = (nseg == 1 || nseg == kWavesPerBlock);
     double *out = df;
-    if (nseg > 1) {
+    if (!direct_f) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));
         if (rc != NMRFIT_OK) return rc;
         out = ctx->d_partial;
@@ -1620,12 +1646,12 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
             break;
     }
     if (rc != NMRFIT_OK) return rc;
-    if (nseg > 1 && defer) {   // the caller's own kernel adds the per-block sums (pso_tail_kernel)
+    if (!direct_f && defer) {   // the caller's own kernel adds the per-block sums (pso_tail_kernel)
         defer->needed = true;
         defer->partial = ctx->d_partial;
         defer->n_blocks = n_blocks;
         defer->fit_im = fit_im;
-    } else if (nseg > 1) {
+    } else if (!direct_f) {
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream,
                            ctx->d_partial, S, n_blocks, N, fit_im, df);
         NMRFIT_HIP(hipGetLastError());

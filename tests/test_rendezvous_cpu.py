@@ -287,3 +287,46 @@ def test_port_mode_without_token_and_different_parents(tmp_path):
     finally:
         os.environ.clear()
         os.environ.update(old)
+
+
+def _precheck_worker(rank, world, port, token, q):
+    sys.path.insert(0, ROOT)
+    _env(rank, world, port, token, {})
+    if rank == 1:
+        os.environ["NMRFIT_RCCL_LIB"] = "/nonexistent/librccl.so"     # RCCL "missing" on this rank only
+    from nmrfit_amd import _cabi, pso
+
+    class NoGpuEvaluator:          # never reached: the pre-check fails before anything touches a context
+        handle, device = None, 0
+        _children = set()
+    t0 = time.time()
+    try:
+        pso.RcclExchange(NoGpuEvaluator())
+        q.put((rank, "no error", 0.0))
+    except _cabi.NmrfitError as e:
+        q.put((rank, "%d|%s" % (e.code, e), time.time() - t0))
+
+
+def test_rccl_missing_on_one_rank_is_an_error_on_every_rank():
+    """no rank may enter the collective ncclCommInitRank unless EVERY rank can load RCCL.
+    The ranks compare notes over the socket star first (nmrfit_comm_available: dlopen + symbols, no
+    GPU work), so RCCL missing on rank 1 raises NMRFIT_E_UNSUPPORTED on ranks 0 AND 1 within seconds,
+    naming the rank -- nobody is left waiting inside RCCL."""
+    from nmrfit_amd import _cabi
+    if _cabi.lib().nmrfit_comm_available() != _cabi.OK:
+        pytest.skip("librccl cannot be loaded on this box at all")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port, token = _free_port(), "pc%d_%d" % (os.getpid(), time.time_ns())
+    ps = [ctx.Process(target=_precheck_worker, args=(r, 2, port, token, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict((r, (msg, dt)) for r, msg, dt in (q.get(timeout=120) for _ in range(2)))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        msg, dt = got[r]
+        assert msg.startswith("%d|" % _cabi.E_UNSUPPORTED), msg
+        assert "RCCL is not available on rank(s) [1]" in msg and "/nonexistent/librccl.so" in msg
+        assert dt < 30

@@ -198,6 +198,24 @@ def cpu_baseline(spec, P, budget_s, pool_procs):
     out = {"value": n * N * P / dt, "unit": "particle*gridpoint*peak/s", "cores": 1, "kind": "port",
            "sample": "%d particles of the same workload (N=%d, P=%d), numpy oracle one call per particle, %.1f s"
                      % (n, N, P, dt)}
+    # BASELINE config 1 (the reference's own CPU-runnable case): 50 particles x 4096 points x 6 peaks, the numpy
+    # oracle one call per particle on one core -- exactly what pyswarm makes the reference do per generation
+    try:
+        c1 = synth.CONFIGS["C1"]
+        sp1 = synth.make_spectrum(c1.N, c1.P, seed=1)
+        X1 = synth.make_swarm(sp1["lower"], sp1["upper"], c1.S, seed=2, x_true=sp1["x_true"])
+        t1 = time.perf_counter()
+        gens1 = 0
+        while gens1 < 20 and time.perf_counter() - t1 < 2.0:
+            for i in range(c1.S):
+                onp.objective(X1[i], sp1["w"], sp1["u"], sp1["v"], sp1["weights"])
+            gens1 += 1
+        dt1 = time.perf_counter() - t1
+        out["c1_numpy"] = {"value": gens1 * c1.S * c1.N * c1.P / dt1, "cores": 1, "ms_per_generation": dt1 / gens1 * 1e3,
+                           "sample": "C1: %d generations of %d particles x %d points x %d peaks, numpy oracle, %.2f s"
+                                     % (gens1, c1.S, c1.N, c1.P, dt1)}
+    except Exception as e:
+        out["c1_numpy"] = {"error": repr(e)}
     if pool_procs > 0:
         # the reference's only parallel mode (utils.py:176-182, processes=n): Pool.map over particles
         try:
@@ -545,9 +563,9 @@ def main():
                     "units_per_s": float(S_local) * N * P / (variants["farfield_ms"] * 1e-3),
                     "max_rel_diff_vs_default": variants["farfield_max_rel_diff_vs_default"]}
     if rank == 0 and world == 1 and args.workload == "C3" and args.variant == 0 and args.other_configs:
-        others = {"note": "BASELINE configs 2 (C2) and 5 (C5): kernel only (HIP events around 50 launches after 5 "
-                          "warm-up launches), after the timed region"}
-        for name in ("C2", "C5"):
+        others = {"note": "BASELINE configs 1 (C1: the reference's CPU case, here on the GPU), 2 (C2) and 5 (C5): kernel only "
+                          "(HIP events around 50 launches after 5 warm-up launches), after the timed region"}
+        for name in ("C1", "C2", "C5"):
             c = synth.CONFIGS[name]
             ev.synchronize()
             sp2 = synth.make_spectrum(c.N, c.P, seed=1)

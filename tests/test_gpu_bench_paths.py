@@ -116,6 +116,7 @@ def test_c4_rehearsal_four_ranks_on_one_gpu():
     assert four["config"]["generations_done"] == one["config"]["generations_done"] == 4
     # BASELINE configs 2 and 5 ride in the default single-GPU line
     oc = one["other_configs"]
+    assert oc["C1"]["shape"] == {"rows": 50, "grid": 4096, "peaks": 6} and oc["C1"]["kernel_ms"] > 0
     assert oc["C2"]["shape"] == {"rows": 1024, "grid": 4096, "peaks": 6} and oc["C2"]["kernel_ms"] > 0
     assert oc["C5"]["shape"] == {"rows": 41, "grid": 16384, "peaks": 12} and "residual" in oc["C5"]["kind"]
     for k in ("C2", "C5"):

@@ -463,7 +463,9 @@ def main():
         # how many ranks RCCL itself saw: an all-reduce of ones over the communicator
         seen = int(round(float(ex.all_reduce([1.0], "sum")[0])))
         rccl_info = {"nranks": info["world"], "ranks_counted_by_all_reduce": seen, "version": info["rccl_version"],
-                     "rank0": ex.describe()}
+                     "rank0": ex.describe(),
+                     # which library answered: anything but the system's librccl is a rehearsal, not a measurement
+                     "library": os.environ.get("NMRFIT_RCCL_LIB") or "librccl (default search path)"}
         sw.set_comm(ex)                       # the all-gather now happens inside nmrfit_pso_step
         exchange_desc = "ncclAllGather of %d doubles per generation inside nmrfit_pso_step (RCCL %s)" % (
             D + 1, info["rccl_version"])

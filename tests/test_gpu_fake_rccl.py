@@ -118,3 +118,16 @@ def test_fit_with_the_rccl_exchange_and_three_ranks(fake_lib, tmp_path):
     one = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False,
                          options={"swarmsize": 301, "maxiter": 60, "seed": got[0]["seed"]})
     assert [float(v).hex() for v in one.params] == got[0]["params"] and float(one.error).hex() == got[0]["error"]
+
+
+def test_c4_per_rank_shape_over_the_rccl_branch(fake_lib):
+    """C4's per-GPU shape (4096 particles x 65536 points x 24 peaks per rank) with four ranks through the RCCL
+    branch (stand-in library, one GPU): same swarm best as the one-rank 16384-particle run, bit for bit."""
+    common = ["--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-extras", "--no-other-configs", "--no-pmc",
+              "--preheat-seconds", "0.1"]
+    four, _ = _bench([sys.executable, "bench.py", "--gpus", "4", "--swarm-per-gpu", "4096"] + common,
+                     {"NMRFIT_RCCL_LIB": fake_lib, "NMRFIT_BENCH_SHARE_GPU": "1"})
+    one, _ = _bench([sys.executable, "bench.py", "--swarm-per-gpu", "16384"] + common, {})
+    assert four["rccl"]["nranks"] == 4 and four["config"]["swarm_total"] == 16384 == one["config"]["swarm_total"]
+    assert four["config"]["swarm_best_f"] == one["config"]["swarm_best_f"]
+    assert four["config"]["generations_done"] == one["config"]["generations_done"] == 4

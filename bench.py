@@ -63,6 +63,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SIMDS = 1024                   # 256 CUs x 4 SIMDs
 PEAK_CLOCK_MHZ = 2400.0        # MI355X_MICROARCH.md
+LAUNCHER_GRACE_S = 15.0        # self-launcher: how much later than the ranks' own watchdogs its deadline falls
 FP64_ISSUE_CYCLES = 4.0        # one wave64 fp64 VALU instruction occupies a SIMD's issue port for 4 cycles
 PMC_SUMMARIES = [os.path.join("profiles", r, "bench_c3_pmc_summary.json") for r in ("r03", "r02", "r01")]
 FARFIELD_PMC_SUMMARIES = [os.path.join("profiles", "r03", "farfield_c3_pmc_summary.json")]
@@ -131,10 +132,12 @@ def self_launch(n, launch_timeout):
     try:
         pending = set(range(n))
         while pending:
-            if launch_timeout > 0 and time.monotonic() - t_start > launch_timeout:
+            # the backstop: every rank carries the same deadline for reaching the timed region and says where it
+            # was stuck (more useful than anything the launcher can say), so the launcher waits a little longer
+            if launch_timeout > 0 and time.monotonic() - t_start > launch_timeout + LAUNCHER_GRACE_S:
                 alive = [r for r in sorted(pending) if procs[r].poll() is None]
                 sys.stderr.write("bench.py: launch timeout: %d rank(s) still running after %.0f s: %s -- ending them\n"
-                                 % (len(alive), launch_timeout, alive))
+                                 % (len(alive), launch_timeout + LAUNCHER_GRACE_S, alive))
                 rc = 124
                 break
             for r in sorted(pending):

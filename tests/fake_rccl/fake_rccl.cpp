@@ -25,6 +25,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -117,6 +118,11 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id)
 ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank)
 {
     if (!comm || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    // test hook: FAKE_RCCL_HANG_IN_INIT=<rank> makes that rank never come back from the collective creation
+    // (what a wedged ncclCommInitRank looks like from outside): the callers' watchdogs have to deal with it
+    if (const char *h = getenv("FAKE_RCCL_HANG_IN_INIT"))
+        if (atoi(h) == rank)
+            for (;;) sleep(1);
     FakeComm *c = new (std::nothrow) FakeComm();
     if (!c) return ncclSystemError;
     c->rank = rank;

@@ -131,3 +131,24 @@ def test_c4_per_rank_shape_over_the_rccl_branch(fake_lib):
     assert four["rccl"]["nranks"] == 4 and four["config"]["swarm_total"] == 16384 == one["config"]["swarm_total"]
     assert four["config"]["swarm_best_f"] == one["config"]["swarm_best_f"]
     assert four["config"]["generations_done"] == one["config"]["generations_done"] == 4
+
+
+def test_watchdog_ends_ranks_stuck_inside_communicator_creation(fake_lib):
+    """The failure the first multi-GPU contact is most likely to show: a rank that never comes back from
+    ncclCommInitRank.  Here rank 1 of 2 hangs INSIDE the (stand-in) collective creation, so rank 0 waits in
+    it too -- both main threads are stuck in a C call.  Every rank's own watchdog thread (the ctypes call
+    releases the GIL) says on stderr which rank is stuck where, on which device, and ends the process; the
+    launcher then reports non-zero.  Well inside a minute, never a hang."""
+    import time
+    env = dict(os.environ, NMRFIT_RCCL_LIB=fake_lib, NMRFIT_BENCH_SHARE_GPU="1", FAKE_RCCL_HANG_IN_INIT="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--swarm-per-gpu", "128", "--workload", "C2",
+                          "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-extras", "--launch-timeout", "10"],
+                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode != 0
+    assert time.time() - t0 < 90
+    assert "nmrfit watchdog: rank" in out.stderr and "RCCL communicator creation" in out.stderr, out.stderr[-3000:]
+    assert "HIP device 0, PCI" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -544,7 +544,7 @@ def main():
     ev.upload(d_x, sw.state()["x"])
 
     # ---- extras on the final swarm positions (rank 0, after the timed region) ---------------
-    variants = farfield = host_ms = others = None
+    variants = farfield = host_ms = others = None  # (default_fit below)
     if rank == 0 and args.variant == 0 and not args.no_extras:
         f_def = None
         variants = {}
@@ -610,6 +610,29 @@ def main():
                 ev2.dev_free(df2)
                 if dR2 is not None:
                     ev2.dev_free(dR2)
+    # the reference's DEFAULT workload end to end (utils.py:177-178: 204 particles, maxiter 2000) on a 6-peak,
+    # 4096-point spectrum: wall time of a whole nmrfit_amd.fit() call with the stopping rule off -- every one of
+    # the 2000 generations runs -- i.e. 204 x 2001 objective evaluations, which the reference makes one numpy
+    # call at a time (cpu_baseline.c1_numpy: ~0.27 ms each on this host)
+    default_fit = None
+    if rank == 0 and world == 1 and args.workload == "C3" and args.variant == 0 and args.other_configs:
+        try:
+            import nmrfit_amd
+            spf = synth.make_spectrum(4096, 6, seed=1)
+            dataf = synth.SynthData(spf["w"], spf["u"], spf["v"], spf["peaks"])
+            optsf = {"seed": 7, "minstep": -1.0, "minfunc": -1.0, "device": device}
+            nmrfit_amd.fit(dataf, list(spf["lower"]), list(spf["upper"]), summary=False, options=dict(optsf, maxiter=5))
+            tf = time.perf_counter()
+            rf = nmrfit_amd.fit(dataf, list(spf["lower"]), list(spf["upper"]), summary=False, options=optsf)
+            dtf = time.perf_counter() - tf
+            default_fit = {"shape": {"swarm": 204, "grid": 4096, "peaks": 6, "generations": 2000},
+                           "wall_ms": dtf * 1e3, "us_per_generation": dtf / 2000 * 1e6,
+                           "units_per_s": 204.0 * 4096 * 6 * 2001 / dtf, "error": float(rf.error),
+                           "note": "one whole nmrfit_amd.fit() call with the reference's defaults (weights, context, "
+                                   "device swarm, 2000 generations with the stopping tests off); small swarms are bound "
+                                   "by the critical path of one wave per generation, not by throughput (DESIGN.md 4.2)"}
+        except Exception as e:      # reported, never fatal for the headline
+            default_fit = {"error": repr(e)}
     # the host-pointer entry point (X uploaded, f downloaded every call): the PCIe-inclusive
     # rate, reported beside the resident one -- never as `value`
     if rank == 0 and world == 1 and not args.no_extras:
@@ -771,6 +794,8 @@ def main():
             line["fit_default"] = fd
         if others:
             line["other_configs"] = others
+        if default_fit is not None:
+            line["reference_default_fit"] = default_fit
         if host_ms is not None:
             line["host_pointer_call"] = {"ms": host_ms, "units_per_s": units_launch / (host_ms * 1e-3),
                                          "note": "nmrfit_objective_batch with host X/f (H2D + kernel + D2H per call)"}

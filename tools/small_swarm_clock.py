@@ -5,7 +5,6 @@ generations of small swarms, against the C3 shape."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["NMRFIT_NO_PERSISTENT"] = "1"
 from nmrfit_amd import synth, pso
 from nmrfit_amd.equations import Evaluator
 

@@ -621,10 +621,14 @@ def main():
             spf = synth.make_spectrum(4096, 6, seed=1)
             dataf = synth.SynthData(spf["w"], spf["u"], spf["v"], spf["peaks"])
             optsf = {"seed": 7, "minstep": -1.0, "minfunc": -1.0, "device": device}
-            nmrfit_amd.fit(dataf, list(spf["lower"]), list(spf["upper"]), summary=False, options=dict(optsf, maxiter=5))
-            tf = time.perf_counter()
-            rf = nmrfit_amd.fit(dataf, list(spf["lower"]), list(spf["upper"]), summary=False, options=optsf)
-            dtf = time.perf_counter() - tf
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):     # fit() prints pyswarm's "Stopping search: ..." line;
+                nmrfit_amd.fit(dataf, list(spf["lower"]), list(spf["upper"]), summary=False,   # stdout is for the JSON line only
+                               options=dict(optsf, maxiter=5))
+                tf = time.perf_counter()
+                rf = nmrfit_amd.fit(dataf, list(spf["lower"]), list(spf["upper"]), summary=False, options=optsf)
+                dtf = time.perf_counter() - tf
             default_fit = {"shape": {"swarm": 204, "grid": 4096, "peaks": 6, "generations": 2000},
                            "wall_ms": dtf * 1e3, "us_per_generation": dtf / 2000 * 1e6,
                            "units_per_s": 204.0 * 4096 * 6 * 2001 / dtf, "error": float(rf.error),

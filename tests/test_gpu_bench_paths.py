@@ -33,6 +33,8 @@ def _run(cmd, env_extra, timeout=900, expect_rc=0, stderr_has=()):
         assert needle in out.stderr, (needle, out.stderr[-2000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
+    # the driver reads ONE JSON line from stdout: nothing else may be printed there
+    assert [l for l in out.stdout.splitlines() if l.strip()] == lines, out.stdout[:2000]
     return json.loads(lines[0])
 
 
@@ -123,6 +125,10 @@ def test_c4_rehearsal_four_ranks_on_one_gpu():
         r = oc[k]["roofline"]
         assert r["frac"] == pytest.approx(r["bytes_per_launch"] / (oc[k]["kernel_ms"] * 1e-3) / 1e9 / r["peak"])
     assert oc["C2"]["roofline"]["bytes_per_launch"] == 1024 * (4 * 4096 * 8) + 1024 * 22 * 8 + 1024 * 8
+    # ... and so does the reference's default fit, end to end (204 particles, all 2000 generations)
+    rf = one["reference_default_fit"]
+    assert rf["shape"] == {"swarm": 204, "grid": 4096, "peaks": 6, "generations": 2000}
+    assert 5.0 < rf["wall_ms"] < 500.0 and 0.0 < rf["error"] < 0.05
 
 
 def test_bench_line_carries_live_pmc_counters():

@@ -358,6 +358,13 @@ def main():
     world = int(world_env or "1")
     if args.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
+    # stdout carries ONE JSON line and nothing else.  Libraries print there too -- RCCL writes a version banner
+    # (and, with NCCL_DEBUG=WARN, its warnings) to stdout at communicator creation, fit() prints pyswarm's
+    # "Stopping search" line -- so the original stdout is kept aside for the line, and file descriptor 1 (what C
+    # libraries and Python's print use from here on) is pointed at stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     from nmrfit_amd import synth
     cfg = synth.CONFIGS[args.workload]
@@ -807,8 +814,8 @@ def main():
             line["pmc_live_errors"] = pmc_live["errors"]
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line))
         sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     ev.dev_free(d_x)
     ev.dev_free(d_f)
     if ex is not None:

@@ -153,3 +153,19 @@ def test_bench_line_carries_live_pmc_counters():
     assert 3.9 < v["valu_cycles_per_instruction"] < 4.6
     assert fd["variant"] == "farfield" and fd["from_committed_profile"] is False
     assert 1.5 < fd["valu_instructions_per_unit"] < 4.0 and fd["kernel_ms"] < d["kernel_ms"]["mean"]
+
+
+def test_real_rccl_two_ranks_on_one_device_is_refused_loudly():
+    """As close to a real multi-rank RCCL start as a one-GPU box gets: two ranks, the real librccl, one
+    device.  The ranks' unique-id hand-over and RCCL's own bootstrap between the two processes go through;
+    RCCL then refuses the duplicate device with an error from ncclCommInitRank on BOTH ranks within seconds.
+    bench.py must not hang and must not pass the run off as an RCCL number: line printed, `rccl` null,
+    "error" field, exit code 5."""
+    import time
+    common = ["--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--workload", "C2", "--preheat-seconds", "0.1",
+              "--no-extras", "--swarm-per-gpu", "256", "--launch-timeout", "60"]
+    t0 = time.time()
+    d = _run([sys.executable, "bench.py", "--gpus", "2"] + common, {"NMRFIT_BENCH_SHARE_GPU": "1"}, expect_rc=5,
+             stderr_has=("ncclCommInitRank", "RCCL exchange unavailable"))
+    assert time.time() - t0 < 120
+    assert d["rccl"] is None and "did not run over RCCL" in d["error"] and "RCCL FAILED" in d["config"]["exchange"]

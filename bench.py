@@ -277,7 +277,11 @@ def live_pmc_passes(timeout_s=90.0):
         out["errors"].append("rocprofv3 not found")
         return out
     for name, extra, counters in PMC_PASSES:
-        tmp = tempfile.mkdtemp(prefix="nmrfit_pmc_", dir="/tmp")
+        try:
+            tmp = tempfile.mkdtemp(prefix="nmrfit_pmc_", dir="/tmp")
+        except OSError as e:
+            out["errors"].append("%s: %r" % (name, e))
+            break
         cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", tmp, "--",
                sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--cpu-seconds", "0",
                "--no-extras", "--no-other-configs", "--no-pmc", "--preheat-seconds", "0.2"] + extra

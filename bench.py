@@ -559,71 +559,80 @@ def main():
 
     # ---- extras on the final swarm positions (rank 0, after the timed region) ---------------
     variants = farfield = host_ms = others = None  # (default_fit below)
-    if rank == 0 and args.variant == 0 and not args.no_extras:
-        f_def = None
-        variants = {}
-        reps = max(5, min(args.steps, 20))
-        for name, vid in (("default", _cabi.VARIANT_DEFAULT), ("noskip", _cabi.VARIANT_NOSKIP),
-                          ("baseline", _cabi.VARIANT_BASELINE), ("farfield", _cabi.VARIANT_FARFIELD)):
-            ev.set_variant(vid)
-            ms = time_objective(ev, S_local, P, d_x, d_f, reps)
-            f = ev.download(d_f, (S_local,))
-            if f_def is None:
-                f_def = f
-            variants[name + "_ms"] = ms
-            variants[name + "_max_rel_diff_vs_default"] = float(np.max(np.abs(f - f_def) / np.maximum(np.abs(f_def), 1e-6)))
-        ev.set_variant(args.variant)
-        variants["note"] = ("objective kernel alone on the final swarm positions (mean of %d HIP-event pairs after "
-                            "0.25 s of the same launches).  noskip / baseline evaluate every (particle, point, peak) "
-                            "unit -- DEFAULT skips out-of-window Gaussians (exact to fp64 rounding); baseline is "
-                            "IEEE divide + libdevice exp2 per unit; farfield is opt-in and never the configuration "
-                            "`value` is measured on" % reps)
-        farfield = {"kernel_ms": variants["farfield_ms"],
-                    "units_per_s": float(S_local) * N * P / (variants["farfield_ms"] * 1e-3),
-                    "max_rel_diff_vs_default": variants["farfield_max_rel_diff_vs_default"]}
-    if rank == 0 and world == 1 and args.workload == "C3" and args.variant == 0 and args.other_configs:
-        others = {"note": "BASELINE configs 1 (C1: the reference's CPU case, here on the GPU), 2 (C2) and 5 (C5): kernel only "
-                          "(HIP events around 50 launches after 5 warm-up launches), after the timed region"}
-        for name in ("C1", "C2", "C5"):
-            c = synth.CONFIGS[name]
-            ev.synchronize()
-            sp2 = synth.make_spectrum(c.N, c.P, seed=1)
-            if name == "C5":      # D+1 rows of a forward-difference Jacobian, residual vectors out
-                X2, _ = synth.jacobian_rows(synth.make_swarm(sp2["lower"], sp2["upper"], 2, seed=4)[1])
-            else:
-                X2 = synth.make_swarm(sp2["lower"], sp2["upper"], c.S, seed=2, x_true=sp2["x_true"])
-            with Evaluator(sp2["w"], sp2["u"], sp2["v"], sp2["weights"], device=device) as ev2:
-                B = X2.shape[0]
-                dX2 = ev2.dev_alloc(X2.nbytes)
-                df2 = ev2.dev_alloc(B * 8)
-                dR2 = ev2.dev_alloc(B * c.N * 8) if name == "C5" else None
-                ev2.upload(dX2, X2)
-                run = ((lambda: ev2.residual_batch_dev(B, c.P, dX2, dR2, df2)) if name == "C5"
-                       else (lambda: ev2.objective_batch_dev(B, c.P, dX2, df2)))
-                for _ in range(5):
-                    run()
-                ev2.synchronize()
-                ev2.timer_begin()
-                for _ in range(50):
-                    run()
-                ms2 = ev2.timer_end() / 50
-                D2 = 4 + 3 * c.P
-                # every row streams w, u, v, weights once (+ its parameters and result);
-                # C5 also writes its residual row
-                bytes2 = B * (4 * c.N * 8) + B * D2 * 8 + B * 8 + (B * c.N * 8 if name == "C5" else 0)
-                others[name] = {"shape": {"rows": B, "grid": c.N, "peaks": c.P}, "kernel_ms": ms2,
-                                "units_per_s": float(B) * c.N * c.P / (ms2 * 1e-3),
-                                "kind": "residual_batch (R rows written)" if name == "C5" else "objective_batch",
-                                "roofline": {"bound": "hbm", "bytes_per_launch": bytes2,
-                                             "achieved": bytes2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                             "unit": "GB/s", "frac": bytes2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                             "model": "streaming-operand bytes (effective rate, as in `roofline`); "
-                                                      "these launches are latency-bound: a few microseconds of "
-                                                      "wave critical path, not bandwidth or issue rate"}}
-                ev2.dev_free(dX2)
-                ev2.dev_free(df2)
-                if dR2 is not None:
-                    ev2.dev_free(dR2)
+    extras_errors = []
+    try:
+        if rank == 0 and args.variant == 0 and not args.no_extras:
+            f_def = None
+            variants = {}
+            reps = max(5, min(args.steps, 20))
+            for name, vid in (("default", _cabi.VARIANT_DEFAULT), ("noskip", _cabi.VARIANT_NOSKIP),
+                              ("baseline", _cabi.VARIANT_BASELINE), ("farfield", _cabi.VARIANT_FARFIELD)):
+                ev.set_variant(vid)
+                ms = time_objective(ev, S_local, P, d_x, d_f, reps)
+                f = ev.download(d_f, (S_local,))
+                if f_def is None:
+                    f_def = f
+                variants[name + "_ms"] = ms
+                variants[name + "_max_rel_diff_vs_default"] = float(np.max(np.abs(f - f_def) / np.maximum(np.abs(f_def), 1e-6)))
+            ev.set_variant(args.variant)
+            variants["note"] = ("objective kernel alone on the final swarm positions (mean of %d HIP-event pairs after "
+                                "0.25 s of the same launches).  noskip / baseline evaluate every (particle, point, peak) "
+                                "unit -- DEFAULT skips out-of-window Gaussians (exact to fp64 rounding); baseline is "
+                                "IEEE divide + libdevice exp2 per unit; farfield is what fit() picks at this size (see "
+                                "fit_default) and never the configuration `value` is measured on" % reps)
+            farfield = {"kernel_ms": variants["farfield_ms"],
+                        "units_per_s": float(S_local) * N * P / (variants["farfield_ms"] * 1e-3),
+                        "max_rel_diff_vs_default": variants["farfield_max_rel_diff_vs_default"]}
+    except Exception as e:      # an extra must never cost the run its headline line
+        extras_errors.append("variants: %r" % (e,))
+        variants = farfield = None
+    try:
+        if rank == 0 and world == 1 and args.workload == "C3" and args.variant == 0 and args.other_configs:
+            others = {"note": "BASELINE configs 1 (C1: the reference's CPU case, here on the GPU), 2 (C2) and 5 (C5): kernel only "
+                              "(HIP events around 50 launches after 5 warm-up launches), after the timed region"}
+            for name in ("C1", "C2", "C5"):
+                c = synth.CONFIGS[name]
+                ev.synchronize()
+                sp2 = synth.make_spectrum(c.N, c.P, seed=1)
+                if name == "C5":      # D+1 rows of a forward-difference Jacobian, residual vectors out
+                    X2, _ = synth.jacobian_rows(synth.make_swarm(sp2["lower"], sp2["upper"], 2, seed=4)[1])
+                else:
+                    X2 = synth.make_swarm(sp2["lower"], sp2["upper"], c.S, seed=2, x_true=sp2["x_true"])
+                with Evaluator(sp2["w"], sp2["u"], sp2["v"], sp2["weights"], device=device) as ev2:
+                    B = X2.shape[0]
+                    dX2 = ev2.dev_alloc(X2.nbytes)
+                    df2 = ev2.dev_alloc(B * 8)
+                    dR2 = ev2.dev_alloc(B * c.N * 8) if name == "C5" else None
+                    ev2.upload(dX2, X2)
+                    run = ((lambda: ev2.residual_batch_dev(B, c.P, dX2, dR2, df2)) if name == "C5"
+                           else (lambda: ev2.objective_batch_dev(B, c.P, dX2, df2)))
+                    for _ in range(5):
+                        run()
+                    ev2.synchronize()
+                    ev2.timer_begin()
+                    for _ in range(50):
+                        run()
+                    ms2 = ev2.timer_end() / 50
+                    D2 = 4 + 3 * c.P
+                    # every row streams w, u, v, weights once (+ its parameters and result);
+                    # C5 also writes its residual row
+                    bytes2 = B * (4 * c.N * 8) + B * D2 * 8 + B * 8 + (B * c.N * 8 if name == "C5" else 0)
+                    others[name] = {"shape": {"rows": B, "grid": c.N, "peaks": c.P}, "kernel_ms": ms2,
+                                    "units_per_s": float(B) * c.N * c.P / (ms2 * 1e-3),
+                                    "kind": "residual_batch (R rows written)" if name == "C5" else "objective_batch",
+                                    "roofline": {"bound": "hbm", "bytes_per_launch": bytes2,
+                                                 "achieved": bytes2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                                 "unit": "GB/s", "frac": bytes2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "model": "streaming-operand bytes (effective rate, as in `roofline`); "
+                                                          "these launches are latency-bound: a few microseconds of "
+                                                          "wave critical path, not bandwidth or issue rate"}}
+                    ev2.dev_free(dX2)
+                    ev2.dev_free(df2)
+                    if dR2 is not None:
+                        ev2.dev_free(dR2)
+    except Exception as e:      # an extra must never cost the run its headline line
+        extras_errors.append("other_configs: %r" % (e,))
+        others = {"error": repr(e)}
     # the reference's DEFAULT workload end to end (utils.py:177-178: 204 particles, maxiter 2000) on a 6-peak,
     # 4096-point spectrum: wall time of a whole nmrfit_amd.fit() call with the stopping rule off -- every one of
     # the 2000 generations runs -- i.e. 204 x 2001 objective evaluations, which the reference makes one numpy
@@ -653,13 +662,17 @@ def main():
             default_fit = {"error": repr(e)}
     # the host-pointer entry point (X uploaded, f downloaded every call): the PCIe-inclusive
     # rate, reported beside the resident one -- never as `value`
-    if rank == 0 and world == 1 and not args.no_extras:
-        Xh = sw.state()["x"]
-        ev.objective_batch(Xh)
-        t1 = time.perf_counter()
-        for _ in range(5):
+    try:
+        if rank == 0 and world == 1 and not args.no_extras:
+            Xh = sw.state()["x"]
             ev.objective_batch(Xh)
-        host_ms = (time.perf_counter() - t1) / 5 * 1e3
+            t1 = time.perf_counter()
+            for _ in range(5):
+                ev.objective_batch(Xh)
+            host_ms = (time.perf_counter() - t1) / 5 * 1e3
+    except Exception as e:      # an extra must never cost the run its headline line
+        extras_errors.append("host_pointer_call: %r" % (e,))
+        host_ms = None
 
     units_step = float(S_local) * world * N * P
     value = units_step * args.steps / dt
@@ -817,6 +830,8 @@ def main():
         if host_ms is not None:
             line["host_pointer_call"] = {"ms": host_ms, "units_per_s": units_launch / (host_ms * 1e-3),
                                          "note": "nmrfit_objective_batch with host X/f (H2D + kernel + D2H per call)"}
+        if extras_errors:
+            line["extras_errors"] = extras_errors
         if pmc_live is not None and pmc_live.get("errors"):
             line["pmc_live_errors"] = pmc_live["errors"]
         if cpu is not None:

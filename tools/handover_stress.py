@@ -14,7 +14,7 @@ This tool runs the same swarm, from the same seed, twice on the same device:
                                     launch, the kernel boundary orders everything)
 and, every --fenced-every seeds, a third time with NMRFIT_HANDOVER_FENCED (release / acquire
 fences), for `--gens` generations each with the stopping tests off, then compares x, v, p, fx, fp,
-the best position and value bit for bit.  About 0.9 S particles improve their personal best in
+the best position and value bit for bit.  About 0.7 S particles improve their personal best in
 every one of the first ~700 generations (measured with the numpy mirror), so every hand-over
 carries fresh rows; a new seed starts a new swarm before that dries up.
 

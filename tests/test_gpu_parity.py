@@ -209,6 +209,30 @@ def test_objective_is_independent_of_launch_geometry(eq):
     np.testing.assert_array_equal(fi_small, fi_big[:7])
 
 
+@pytest.mark.parametrize("variant", ["default", "farfield", "norec"])
+def test_four_segment_workgroup_reduction_matches_the_other_geometries(eq, variant):
+    """Four segments per particle: the four waves of a workgroup ARE the particle, its block sums meet in
+    LDS and the workgroup writes f itself (round 3; no partial-sum buffer, no finalize pass).  Same canonical
+    summation order as one wave per particle (20000 particles) and as eight segments with finalize_kernel
+    (60 particles): bit-identical f, in every fit_im mode."""
+    sp = synth.make_spectrum(4096, 6, seed=51)
+    X = synth.make_swarm(sp["lower"], sp["upper"], 20000, seed=52, x_true=sp["x_true"])
+    with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        ev.set_variant(_cabi.variant_id(variant))
+        for mode in (False, True, "sum"):
+            f_one = ev.objective_batch(X, fit_im=mode)
+            assert ev.last_launch()["segments"] == 1
+            f_four = ev.objective_batch(X[:1200], fit_im=mode)
+            assert ev.last_launch()["segments"] == 4
+            f_eight = ev.objective_batch(X[:60], fit_im=mode)
+            assert ev.last_launch()["segments"] == 8
+            np.testing.assert_array_equal(f_four, f_one[:1200], err_msg=str(mode))
+            np.testing.assert_array_equal(f_eight, f_one[:60], err_msg=str(mode))
+        R = ev.residual_batch(X[:1200][:8])          # (residual rows are a small batch: eight segments)
+        Rb = ev.residual_batch(X[:3])
+        np.testing.assert_array_equal(Rb, R[:3])
+
+
 @pytest.mark.parametrize("P", [9, 64, 65, 130, 1000])
 def test_many_peaks(eq, P):
     """More peaks than a 64-peak window-mask block (P = 65, 130), group tails of every size and

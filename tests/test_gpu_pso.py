@@ -360,6 +360,8 @@ def test_ticket_select_long_run(problem):
     (204, 4096, 6, "farfield", False),
     (120, 4096, 3, "default", True),       # the reference's fit_im=True
     (120, 4096, 3, "default", "sum"),
+    (1024, 4096, 3, "default", True),      # four segments per particle: f written by the workgroup, with the
+    (1024, 4096, 3, "farfield", "sum"),    # imaginary channel's second sum
 ])
 def test_handover_modes_match_numpy_mirror(S, N, P, variant, fit_im, mode):
     """The select kernel's cross-workgroup hand-over in its three forms (nmrfit_pso_set_handover:

@@ -758,7 +758,11 @@ def main():
                        "exchange": exchange_desc, "variant": args.variant, "generations_done": st["iteration"],
                        "swarm_best_f": st["fg"], "preheat_launches": heat_launches},
             "step_ms": sst, "kernel_ms": kst,
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm",      # the roofline the METRIC names (BASELINE.json: "HBM GB/s vs peak"), under
+                         # the streaming-operand model below; what actually binds this kernel is `binding_resource`
+                         "binding_resource": "fp64_valu_issue (see roofline_valu): physical HBM traffic is `traffic`, "
+                                             "0.2 % of peak",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_from_committed_profile": traffic is not None and not traffic_live,
                          "traffic_source": ("live: child passes of this run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "

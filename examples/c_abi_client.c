@@ -155,6 +155,21 @@ int main(int argc, char **argv)
         CHECK(nmrfit_pso_destroy(pso));
     }
     if (nmrfit_pso_set_handover(NULL, 0) != NMRFIT_E_INVALID) return 9;
+    if (nmrfit_pso_set_fused_pbest(NULL, 0) != NMRFIT_E_INVALID) return 9;
+    /* 1024 particles on this 4096-point grid: four segments per particle, so the objective launch also does the
+     * personal bests (the default) -- or, switched off, the separate kernel does: the same swarm either way */
+    {
+        double xa[D], xb1[D], fa = 0.0, fb1 = 0.0;
+        for (int fusedpb = 1; fusedpb >= 0; --fusedpb) {
+            CHECK(nmrfit_pso_create(ctx, 1024, 1024, 0, P, lo, hi, &prm, &pso));
+            CHECK(nmrfit_pso_set_fused_pbest(pso, fusedpb));
+            CHECK(nmrfit_pso_run(pso, 200, 100));
+            CHECK(nmrfit_pso_best(pso, fusedpb ? xa : xb1, fusedpb ? &fa : &fb1));
+            CHECK(nmrfit_pso_destroy(pso));
+        }
+        printf("1024 particles, personal bests inside / outside the objective launch: best f = %.6e / %.6e\n", fa, fb1);
+        if (fa != fb1 || memcmp(xa, xb1, sizeof xa) != 0) return 9;
+    }
 
     /* the multi-GPU form of the same loop, as far as one GPU goes: an RCCL communicator of ONE rank
      * (rank 0 makes the 128-byte id; with more ranks it would travel to them by any means), attached

@@ -206,6 +206,13 @@ int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every);
  * Never switched automatically. */
 enum { NMRFIT_HANDOVER_FAST = 0, NMRFIT_HANDOVER_FENCED = 1, NMRFIT_HANDOVER_TWO_LAUNCH = 2 };
 int nmrfit_pso_set_handover(nmrfit_pso *pso, int mode);
+/* When the launch geometry puts a whole particle into one workgroup (four grid segments per particle: e.g.
+ * 512 or 1024 particles x 4096 points, 4096 x 65536), the objective launch also updates the personal bests
+ * (pyswarm: where fx < fp: p = x, fp = fx) and a single workgroup finishes the generation (argmin over fp,
+ * candidate record, fold) -- no many-workgroup personal-best / argmin kernel at all, nothing handed over
+ * inside a launch: 512 x 4096 x 6: 19.5 -> 17.0 us per generation, 1024 x 4096 x 6: 30.2 -> 26.8 us.  On by
+ * default; enable = 0 restores the separate kernel (an A/B knob: results are bit-identical either way). */
+int nmrfit_pso_set_fused_pbest(nmrfit_pso *pso, int enable);
 /* copy swarm state to host for inspection/tests (any pointer may be NULL):
  * x, v, p are S_local x D; fx, fp are S_local */
 int nmrfit_pso_get_state(nmrfit_pso *pso, double *x, double *v, double *p, double *fx, double *fp);

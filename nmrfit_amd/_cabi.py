@@ -89,6 +89,7 @@ SIGNATURES = {
     "nmrfit_pso_best": [_VP, _VP, _c_double_p],
     "nmrfit_pso_run": [_VP, _I64, _I32],
     "nmrfit_pso_set_handover": [_VP, _INT],
+    "nmrfit_pso_set_fused_pbest": [_VP, _INT],
     "nmrfit_pso_get_state": [_VP, _VP, _VP, _VP, _VP, _VP],
     "nmrfit_device_pci_bus_id": [_INT, ctypes.c_char_p, _INT],
     "nmrfit_comm_available": [],

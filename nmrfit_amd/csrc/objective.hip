@@ -746,6 +746,7 @@ __device__ __forceinline__ void objective_body(
         // the row is carried over unchanged and the kernel returns.
         const bool stopped = upd.flags[1] != 0;
         const uint32_t gen = (uint32_t)(upd.flags[0] + 1);
+
         if (!shared || wave == 0)
         for (int64_t d = lane; d < D; d += kWave) {
             const int64_t idx = particle * D + d;
@@ -1349,11 +1350,38 @@ __device__ __forceinline__ void objective_body(
         clk[2] = __builtin_amdgcn_s_memtime();
         clk[3] = __builtin_amdgcn_s_memrealtime();
     }
-    if (nseg == 1 && lane == 0) {
+    // Personal best of this particle, when this wave / workgroup holds all of it and the swarm asked for it
+    // (fused generations only: the updated row sits in LDS): pyswarm's `i_update = fx < fp; p[i_update] =
+    // x[i_update]; fp[i_update] = fx[i_update]`.  Particle-local: nobody else reads or writes this row in this launch.
+    auto personal_best = [&](const double f) {
+        if constexpr (!WRITE_R) {
+            if (wsums[2 * kMaxBlocks + 1] != 0.0) {
+                // What this needs -- p, S, the row's place in LDS -- was parked in LDS by the prologue (wsums[..+2..4])
+                // and is read back here: kept in scalar registers across the chunk loop those few values tipped the
+                // headline kernel, which has neither a scalar nor a vector register to spare, into scratch memory.
+                // fp[S] sits right behind p[S x D] (PsoFused).
+                const int64_t D2 = 4 + 3 * (int64_t)P;
+                // (four segments per particle: workgroup = particle -- no need for the prologue's 64-bit division result)
+                const int64_t part = (int64_t)blockIdx.x;
+                double *pb = reinterpret_cast<double *>((uintptr_t)__double_as_longlong(wsums[2 * kMaxBlocks + 2]));
+                double *fpb = pb + __double_as_longlong(wsums[2 * kMaxBlocks + 3]) * D2;
+                const double *row = reinterpret_cast<const double *>(lds_raw + (unsigned)__double_as_longlong(wsums[2 * kMaxBlocks + 4]));
+                if (f < fpb[part]) {
+                    for (int64_t d = threadIdx.x & (kWave - 1); d < D2; d += kWave) pb[part * D2 + d] = row[d];
+                    if ((threadIdx.x & (kWave - 1)) == 0) fpb[part] = f;
+                }
+            }
+        }
+    };
+    if (nseg == 1) {
+        double f = 0.0;
         if (FIT_IM == 0)
-            out[particle] = sqrt(ss / (double)N);
+            f = sqrt(ss / (double)N);
         else   // (rmse_real + rmse_imag) / 2, equations.py:205-209
-            out[particle] = 0.5 * (sqrt(ss / (double)N) + sqrt(ss_im / (double)N));
+            f = 0.5 * (sqrt(ss / (double)N) + sqrt(ss_im / (double)N));
+        if (lane == 0) out[particle] = f;
+        // (no fused personal best here: one wave per particle means >= 16384 particles, where the swarm's own
+        // select kernels are noise next to the objective -- and the call cost the headline kernel 12 bytes of scratch)
     }
     if (nseg == WPB && nseg > 1) {
         // One workgroup = one particle (segment = wave): the block sums are added here, in grid order
@@ -1367,7 +1395,13 @@ __device__ __forceinline__ void objective_body(
                 t += wsums[c];
                 if (FIT_IM != 0) ti += wsums[kMaxBlocks + c];
             }
-            out[particle] = (FIT_IM == 0) ? sqrt(t / (double)N) : 0.5 * (sqrt(t / (double)N) + sqrt(ti / (double)N));
+            const double f = (FIT_IM == 0) ? sqrt(t / (double)N) : 0.5 * (sqrt(t / (double)N) + sqrt(ti / (double)N));
+            out[particle] = f;
+            wsums[2 * kMaxBlocks] = f;
+        }
+        if constexpr (!WRITE_R) {
+            __syncthreads();
+            if ((threadIdx.x >> 6) == 0) personal_best(wsums[2 * kMaxBlocks]);
         }
     }
 }
@@ -1381,7 +1415,15 @@ __global__ __launch_bounds__(kBlock, NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)
     const PsoFused upd, const unsigned aux_off)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    __shared__ double wsums[2 * kMaxBlocks];
+    // block sums (x2 with the imaginary channel); then f; then what the fused personal-best step needs at the very
+    // end of the kernel (flag, p, S, the row's LDS offset), parked here by the prologue
+    __shared__ double wsums[2 * kMaxBlocks + 5];
+    if (threadIdx.x == 0) {   // first thing in the kernel, while nothing else is live (a barrier follows the staging)
+        wsums[2 * kMaxBlocks + 1] = (!WRITE_R && upd.x_in != nullptr && upd.pbest != 0u) ? 1.0 : 0.0;
+        wsums[2 * kMaxBlocks + 2] = __longlong_as_double((long long)(uintptr_t)upd.p);
+        wsums[2 * kMaxBlocks + 3] = __longlong_as_double((long long)S);
+        wsums[2 * kMaxBlocks + 4] = __longlong_as_double((long long)upd.xrow_off);
+    }
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     objective_body<VARIANT, WRITE_R, FIT_IM>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg, seg_len,
                                              blk_chunks, lane_step, rec_devk, out, R_out, clk, upd, aux_off, wsums);
@@ -1612,6 +1654,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     // segments and the workgroup writes f (block sums through LDS); otherwise per-block sums go to a
     // buffer and finalize_kernel (or the swarm's select kernel) adds them.  Same summation order in all.
     const bool direct_f = (nseg == 1 || nseg == kWavesPerBlock);
+    if (nseg != kWavesPerBlock) upd.pbest = 0u;   // (only when ONE workgroup holds the whole particle; else the caller's kernel)
     double *out = df;
     if (!direct_f) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));
@@ -1646,6 +1689,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
             break;
     }
     if (rc != NMRFIT_OK) return rc;
+    if (defer) defer->pbest_done = upd.x_in != nullptr && upd.pbest != 0u;
     if (!direct_f && defer) {   // the caller's own kernel adds the per-block sums (pso_tail_kernel)
         defer->needed = true;
         defer->partial = ctx->d_partial;

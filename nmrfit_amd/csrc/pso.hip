@@ -22,7 +22,10 @@
 // into as few launches as the data dependences allow:
 //   S*D <= 2560 (e.g. 50 particles x 6 peaks): objective + ONE single-workgroup kernel for
 //       everything else (pso_tail_kernel)                                        -> 2 launches
-//   S <= 1024: objective (with the position update in its prologue), pso_select_kernel (the
+//   four grid segments per particle (one workgroup = one particle: e.g. 512 or 1024 x 4096 x 6, 4096 x 65536 x 24):
+//       the objective launch does the particle's WHOLE step -- update, evaluate, personal best -- and ONE
+//       workgroup finishes (argmin over fp, candidate, fold)                       -> 2 launches
+//   otherwise, S <= 1024: objective (with the position update in its prologue), pso_select_kernel (the
 //       objective's block sums + pbest + argmin [+ apply] in a many-workgroup kernel finished by
 //       its last-ticket workgroup)                                                -> 2 launches
 //   larger:  the same with the final reduction as its own single-workgroup launch -> 3 launches
@@ -54,6 +57,7 @@ struct nmrfit_pso {
     long long *d_part_idx = nullptr;
     unsigned *d_ticket = nullptr;
     int handover = NMRFIT_HANDOVER_FAST;   // nmrfit_pso_set_handover: how the select kernel's workgroups hand over
+    bool fused_pbest = true;               // nmrfit_pso_set_fused_pbest: personal bests inside the objective launch
     nmrfit_comm *comm = nullptr;       // attached communicator (sharded swarm): the exchange runs inside nmrfit_pso_step
     bool initialized = false;    // nmrfit_pso_init has run
     bool seeded = false;         // the generation-0 candidates have been folded into (g, fg)
@@ -546,6 +550,9 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
         f.omega = pso->prm.omega;
         f.phip = pso->prm.phip;
         f.phig = pso->prm.phig;
+        // personal bests in the same launch when one workgroup holds a whole particle (the launch decides from
+        // its geometry and says so in def.pbest_done); d_fp == d_p + S*D, see nmrfit_pso_create
+        if (pso->fused_pbest) f.pbest = 1u;
         rc = launch_objective(ctx, S, pso->P, pso->d_x2, pso->d_fx, nullptr, &def, &f);
         if (rc != NMRFIT_OK) return rc;
         std::swap(pso->d_x, pso->d_x2);   // d_x / d_v: the state the kernel has just written
@@ -554,6 +561,14 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
         if (advance && (rc = launch_update(pso)) != NMRFIT_OK) return rc;
         rc = launch_objective(ctx, S, pso->P, pso->d_x, pso->d_fx, nullptr, &def);
         if (rc != NMRFIT_OK) return rc;
+    }
+    if (def.pbest_done) {
+        // The particle's whole step (update, evaluate, personal best) happened in the objective launch: what is
+        // left is the argmin over fp, the candidate record and -- single rank -- the fold, none of which needs
+        // more than ONE workgroup and none of which hands anything over inside a launch.
+        TailArgs a = tail_args(pso, def, kTailArgmin | (more & kTailApply));
+        a.is_init = is_init;
+        return launch_tail(pso, a);
     }
     TailArgs a = tail_args(pso, def, (def.needed ? kTailFinalize : 0) | kTailPbest | kTailArgmin | (more & kTailApply));
     a.is_init = is_init;
@@ -620,6 +635,7 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
     pso->prm = *params;
     if (const char *e = getenv("NMRFIT_SAFE_HANDOVER"))   // A/B knob: the fenced hand-over as every swarm's default
         if (atoi(e) != 0) pso->handover = NMRFIT_HANDOVER_FENCED;
+    if (getenv("NMRFIT_NO_FUSED_PBEST")) pso->fused_pbest = false;   // A/B knob
     const size_t sd = (size_t)std::max<int64_t>(S_local * D, 1) * sizeof(double);
     const size_t s1 = (size_t)std::max<int64_t>(S_local, 1) * sizeof(double);
 #define PSO_HIP(call)                                                   \
@@ -637,9 +653,11 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
     PSO_HIP(hipMalloc((void **)&pso->d_v, sd));
     PSO_HIP(hipMalloc((void **)&pso->d_x2, sd));
     PSO_HIP(hipMalloc((void **)&pso->d_v2, sd));
-    PSO_HIP(hipMalloc((void **)&pso->d_p, sd));
+    // personal bests and their values in ONE allocation, fp[S] right behind p[S x D]: the objective kernel's
+    // fused personal-best step finds fp from p without another pointer argument (objective.hip)
+    PSO_HIP(hipMalloc((void **)&pso->d_p, (size_t)std::max<int64_t>(S_local * D, 0) * sizeof(double) + s1));
+    pso->d_fp = pso->d_p + S_local * D;
     PSO_HIP(hipMalloc((void **)&pso->d_fx, s1));
-    PSO_HIP(hipMalloc((void **)&pso->d_fp, s1));
     PSO_HIP(hipMalloc((void **)&pso->d_cand_own, (size_t)(D + 1) * sizeof(double)));
     pso->d_cand = pso->d_cand_own;
     PSO_HIP(hipMalloc((void **)&pso->d_flags, 2 * sizeof(long long)));
@@ -671,7 +689,7 @@ int nmrfit_pso_destroy(nmrfit_pso *pso)
         (void)hipSetDevice(pso->ctx->device);
         (void)hipStreamSynchronize(pso->ctx->stream);
     }
-    void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_x2, pso->d_v2, pso->d_p, pso->d_fx, pso->d_fp, pso->d_cand_own, pso->d_flags, pso->d_best,
+    void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_x2, pso->d_v2, pso->d_p /* + d_fp */, pso->d_fx, pso->d_cand_own, pso->d_flags, pso->d_best,
                     pso->d_part_val, pso->d_part_idx, pso->d_ticket};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -766,6 +784,16 @@ int nmrfit_pso_set_comm(nmrfit_pso *pso, nmrfit_comm *comm)
     if (pso->comm) comm_attach(pso->comm, -1);
     pso->comm = comm;
     if (comm) comm_attach(comm, +1);   // nmrfit_comm_destroy refuses while a swarm still points at it
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_set_fused_pbest(nmrfit_pso *pso, int enable)
+{
+    if (!pso) {
+        set_error("null swarm handle");
+        return NMRFIT_E_INVALID;
+    }
+    pso->fused_pbest = enable != 0;
     return NMRFIT_OK;
 }
 

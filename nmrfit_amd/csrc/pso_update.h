@@ -78,6 +78,13 @@ struct PsoFused {
     int64_t offset = 0;                               // global index of this shard's first particle
     double omega = 0.0, phip = 0.0, phig = 0.0;
     unsigned xrow_off = 0;                            // byte offset of the per-wave x rows in dynamic LDS
+    // Personal bests in the same launch (pyswarm: where fx < fp: p = x, fp = fx), for the launch geometries
+    // in which ONE workgroup holds the whole particle (four segments = its four waves) and therefore knows f
+    // at its end: the particle's step -- update, evaluate, personal best -- is then
+    // complete inside this kernel and what is left for the next launch is the argmin over fp.  No new
+    // pointers (the headline kernel has no scalar register to spare): the swarm keeps fp[S] right behind
+    // p[S x D] in one allocation, so fp = p + S*D.
+    unsigned pbest = 0;                               // 1: do it (sits in the padding after xrow_off)
 };
 
 // Wait until every global store this wave has issued has completed.  For the agent-scope (sc1,

@@ -450,6 +450,11 @@ class DeviceSwarm:
                     "two_launch": _cabi.HANDOVER_TWO_LAUNCH}[mode.lower()]
         _cabi.check(self._lib.nmrfit_pso_set_handover(self._h, int(mode)))
 
+    def set_fused_pbest(self, enable=True):
+        """Personal bests inside the objective launch when one workgroup holds a whole particle (default on;
+        A/B knob: off restores the separate personal-best / argmin kernel; bit-identical results)."""
+        _cabi.check(self._lib.nmrfit_pso_set_fused_pbest(self._h, 1 if enable else 0))
+
     def candidate_dev(self):
         p = ctypes.c_void_p()
         _cabi.check(self._lib.nmrfit_pso_candidate_dev(self._h, ctypes.byref(p)))

@@ -351,7 +351,7 @@ def test_ticket_select_long_run(problem):
     dev.close()
 
 
-@pytest.mark.parametrize("mode", ["fast", "fenced", "two_launch"])
+@pytest.mark.parametrize("mode", ["fused_pbest", "fast", "fenced", "two_launch"])
 @pytest.mark.parametrize("S,N,P,variant,fit_im", [
     (204, 4096, 6, "default", False),      # the reference's default swarm: 51 select workgroups
     (1024, 4096, 6, "default", False),     # C2: 256 workgroups, the largest swarm that hands over inside one launch
@@ -364,10 +364,13 @@ def test_ticket_select_long_run(problem):
     (1024, 4096, 3, "farfield", "sum"),    # imaginary channel's second sum
 ])
 def test_handover_modes_match_numpy_mirror(S, N, P, variant, fit_im, mode):
-    """The select kernel's cross-workgroup hand-over in its three forms (nmrfit_pso_set_handover:
-    fence-free agent-scope stores, release / acquire fences, reduction as its own launch) against
-    the numpy mirror: same Philox stream, same update arithmetic, same summation order => every
-    state array bit-identical, whatever the polling interval."""
+    """The generation's second half in every form -- personal bests inside the objective launch where a
+    workgroup holds a whole particle ("fused_pbest": the default; the 512- and 1024-particle shapes here), or
+    the select kernel with its cross-workgroup hand-over in its three forms (nmrfit_pso_set_handover:
+    fence-free agent-scope stores, release / acquire fences, reduction as its own launch; fused personal
+    bests switched off so that the select kernel runs at every shape) -- against the numpy mirror: same
+    Philox stream, same update arithmetic, same summation order => every state array bit-identical,
+    whatever the polling interval."""
     from nmrfit_amd import equations
     sp = synth.make_spectrum(N, P, seed=11)
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
@@ -383,7 +386,9 @@ def test_handover_modes_match_numpy_mirror(S, N, P, variant, fit_im, mode):
             host.apply_global(host.candidate()[None, :])
         for ce in (gens, 7):
             dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=23, minfunc=-1.0, minstep=-1.0)
-            dev.set_handover(mode)
+            if mode != "fused_pbest":
+                dev.set_fused_pbest(False)
+                dev.set_handover(mode)
             dev.run(gens, check_every=ce)
             st = dev.state()
             for k in ("x", "v", "p", "fx", "fp"):
@@ -399,7 +404,7 @@ def test_handover_modes_match_numpy_mirror(S, N, P, variant, fit_im, mode):
             pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 8).set_handover(7)
 
 
-@pytest.mark.parametrize("mode", ["fast", "fenced", "two_launch"])
+@pytest.mark.parametrize("mode", ["fused_pbest", "fast", "fenced", "two_launch"])
 def test_handover_modes_stop_rule(mode):
     """With the stopping tests armed every hand-over form stops at the same generation with the
     same answer as the numpy mirror, and later launches are no-ops."""
@@ -411,7 +416,9 @@ def test_handover_modes_stop_rule(mode):
         assert host.stop in (1, 2) and host.iteration < 2000
         for ce in (64, 5):
             dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 204, seed=8)
-            dev.set_handover(mode)
+            if mode != "fused_pbest":
+                dev.set_fused_pbest(False)
+                dev.set_handover(mode)
             dev.run(2000, check_every=ce)
             st = dev.status()
             assert (st["stop"], st["iteration"]) == (host.stop, host.iteration)
@@ -444,16 +451,21 @@ def test_handover_stress_short(S, N, P):
         for seed in range(99, 105):
             a = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
             b = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+            c = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+            a.set_fused_pbest(False)          # a, b: the select kernel runs at every shape (fence-free / two launches)
+            b.set_fused_pbest(False)
             b.set_handover("two_launch")
-            a.run(gens, check_every=250)
-            b.run(gens, check_every=250)
-            sa, sb = a.state(), b.state()
+            for sw in (a, b, c):              # c: the defaults (personal bests inside the objective launch at 512, 1024)
+                sw.run(gens, check_every=250)
+            sa, sb, sc = a.state(), b.state(), c.state()
             for k in ("x", "v", "p", "fx", "fp"):
                 np.testing.assert_array_equal(sa[k], sb[k], err_msg="%s (seed %d)" % (k, seed))
-            assert a.status() == b.status() and a.status()["iteration"] == gens
+                np.testing.assert_array_equal(sc[k], sb[k], err_msg="%s (seed %d, defaults)" % (k, seed))
+            assert a.status() == b.status() == c.status() and a.status()["iteration"] == gens
             np.testing.assert_array_equal(a.best()[0], b.best()[0])
-            a.close()
-            b.close()
+            np.testing.assert_array_equal(c.best()[0], b.best()[0])
+            for sw in (a, b, c):
+                sw.close()
 
 
 def test_communicator_guards(problem):

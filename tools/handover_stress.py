@@ -39,6 +39,9 @@ SHAPES = {"204": (204, 4096, 6), "256": (256, 4096, 6), "512": (512, 4096, 6), "
 
 def run(ev, sp, S, seed, gens, mode):
     sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+    # the select kernel must run at every shape here: at four grid segments per particle (512 / 1024 x 4096) the
+    # product default does the personal bests inside the objective launch and hands nothing over at all
+    sw.set_fused_pbest(False)
     sw.set_handover(mode)
     sw.init()
     ev.synchronize()

@@ -53,6 +53,55 @@ def env_rank_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+VISIBILITY_VARS = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
+
+
+def visible_devices_env(env=None):
+    """The device-visibility variables that are set, as one string ("HIP_VISIBLE_DEVICES=3"), "" if none."""
+    env = os.environ if env is None else env
+    return " ".join("%s=%s" % (k, env[k]) for k in VISIBILITY_VARS if env.get(k) is not None)
+
+
+def pick_device(device_count, local_rank=None, local_world=None, env=None):
+    """Which HIP device a rank of a one-process-per-GPU launch works on -> (device, note).
+
+    The reference's parallel mode hands particles to a process pool (nmrfit/utils.py:182); here it
+    is one process per GPU, and launchers disagree about how a process finds its GPU:
+
+    * every device visible to every rank (torch.distributed.run, bench.py's own launcher): the
+      device is LOCAL_RANK;
+    * one device visible per rank (a launcher that isolates each rank with HIP_VISIBLE_DEVICES /
+      ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES, or with a device cgroup): the rank's only
+      device is number 0 whatever LOCAL_RANK says.
+
+    So: LOCAL_RANK when that index exists; device 0 when exactly one device is visible (the note
+    says which variable isolated it, or that none is set -- then RCCL's own duplicate-device check
+    is what catches a launcher that did NOT isolate the ranks); anything else is an error that
+    names the variables, raised before the rendezvous so that every rank fails alike."""
+    env = os.environ if env is None else env
+    if local_rank is None:
+        local_rank = int(env.get("LOCAL_RANK", env.get("RANK", "0")))
+    if local_world is None:
+        local_world = int(env.get("LOCAL_WORLD_SIZE", env.get("WORLD_SIZE", "1")))
+    device_count, local_rank, local_world = int(device_count), int(local_rank), int(local_world)
+    vis = visible_devices_env(env)
+    if device_count < 1:
+        raise RuntimeError("no HIP device is visible to local rank %d%s" % (local_rank, (" (%s)" % vis) if vis else ""))
+    if 0 <= local_rank < device_count:
+        return local_rank, ""
+    if device_count == 1:
+        if vis:
+            return 0, "LOCAL_RANK=%d but one HIP device is visible (%s): this rank is isolated, using device 0" % (
+                local_rank, vis)
+        return 0, ("LOCAL_RANK=%d but one HIP device is visible and none of %s is set: assuming the launcher isolates "
+                   "each rank's device some other way, using device 0 (if it does not, RCCL refuses the duplicate "
+                   "device)" % (local_rank, " / ".join(VISIBILITY_VARS)))
+    raise RuntimeError("LOCAL_RANK=%d of %d local rank(s) but %d HIP devices are visible (%s): expected either every "
+                       "device visible to every rank (device = LOCAL_RANK) or exactly one per rank; check %s"
+                       % (local_rank, local_world, device_count, vis or "no visibility variable set",
+                          " / ".join(VISIBILITY_VARS)))
+
+
 def _token():
     t = os.environ.get("NMRFIT_RDZV_TOKEN")
     if t:
@@ -163,6 +212,20 @@ class Channel:
             if port_env:
                 # the address the other ranks connect to, not every interface of the node
                 host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+                # A MASTER_ADDR hostname that rank 0's own /etc/hosts maps to loopback (Debian's 127.0.1.1
+                # line) would make rank 0 listen where the ranks of other nodes cannot reach it: with ranks
+                # on several nodes bind every interface then (the token handshake rejects strangers).
+                try:
+                    resolved = socket.gethostbyname(host)
+                except OSError:
+                    resolved = host
+                multi_node = self.world > int(os.environ.get("LOCAL_WORLD_SIZE", self.world))
+                if multi_node and resolved.startswith("127."):
+                    sys.stderr.write("nmrfit rendezvous: MASTER_ADDR=%s resolves to %s on rank 0 but the ranks span "
+                                     "several nodes: listening on every interface, port %s\n" % (host, resolved, port_env))
+                    host = ""
+                elif multi_node:
+                    sys.stderr.write("nmrfit rendezvous: rank 0 listening on %s (%s) port %s\n" % (host, resolved, port_env))
                 try:
                     ls.bind((host, int(port_env)))
                 except OSError as e:

@@ -125,6 +125,25 @@ def make_swarm(lower, upper, S, seed=2, x_true=None):
     return np.ascontiguousarray(X)
 
 
+def make_dense_swarm(S, P, seed=5, w_lo=3.0, w_hi=4.0):
+    """X[S, 4+3P] of BROAD OVERLAPPING lines -- widths 0.3 .. 0.8 of the spectral span, centres anywhere in
+    its middle 60 % -- the opposite of make_spectrum's sparse narrow lines: no Gaussian window misses any
+    chunk and no peak is far from any chunk, so every (particle, point, peak) unit is evaluated in full.
+    The same construction as tests/test_gpu_parity.py::adversarial_case("overlapping_broad"); bench.py
+    reports the kernel's rate on it beside the headline (`dense_spectrum`)."""
+    rng = np.random.default_rng(seed)
+    span = w_hi - w_lo
+    X = np.empty((S, 4 + 3 * P))
+    X[:, 0] = rng.uniform(-np.pi, np.pi, S)
+    X[:, 1] = rng.uniform(-np.pi, np.pi, S)
+    X[:, 2] = rng.uniform(0, 1, S)
+    X[:, 3] = rng.uniform(-0.01, 0.01, S)
+    X[:, 4::3] = rng.uniform(0.3 * span, 0.8 * span, (S, P))
+    X[:, 5::3] = rng.uniform(w_lo + 0.2 * span, w_hi - 0.2 * span, (S, P))
+    X[:, 6::3] = rng.uniform(0.001, 0.01, (S, P))
+    return np.ascontiguousarray(X)
+
+
 def make_workload(name, S=None, seed=1):
     """(spectrum dict, X[S,D]) for one of BASELINE.json's configs."""
     cfg = CONFIGS[name]

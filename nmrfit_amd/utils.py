@@ -122,13 +122,24 @@ class FitUtility:
         return compute_weights(self.data.w, self.data.peaks, self.expon)
 
     def _device(self):
-        """The GPU this process works on: options['device'] if given; else, in a multi-rank fit
-        (options['exchange'] = "rccl" or an exchange object: one process per GPU), the launcher's
-        LOCAL_RANK; else 0.  fit() and generate_result() use the same one."""
+        """The GPU this process works on: options['device'] if given; else, with a ready
+        pso.RcclExchange, the device its communicator lives on; else, in a multi-rank fit
+        (options['exchange'] = "rccl" or another exchange object: one process per GPU), the launcher's
+        LOCAL_RANK -- or device 0 when the launcher shows this rank one device only
+        (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES isolation; rendezvous.pick_device, which
+        raises when the two disagree any other way); else 0.  fit() and generate_result() use the
+        same one."""
         device = self.options.get('device')
-        if device is None and self.options.get('exchange') is not None:
+        exchange = self.options.get('exchange')
+        if device is None and isinstance(exchange, pso.RcclExchange):
+            device = exchange.ev.device
+        if device is None and exchange is not None:
+            import sys
             from . import rendezvous
-            device = rendezvous.env_rank_world()[1]
+            device, note = rendezvous.pick_device(_cabi.device_count())
+            if note and not getattr(self, '_device_note_shown', False):
+                sys.stderr.write("nmrfit: %s\n" % note)
+                self._device_note_shown = True
         return 0 if device is None else int(device)
 
     def fit(self):
@@ -150,7 +161,8 @@ class FitUtility:
         # Multi-GPU fits (one process per GPU, every rank makes the same fit() call):
         # options['exchange'] = "rccl" builds the RCCL communicator from the launcher's
         # environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; nmrfit_amd.rendezvous), or pass a
-        # ready pso.RcclExchange / SocketExchange / TorchExchange.
+        # ready pso.RcclExchange (its channel and device are reused; the communicator is rebuilt on this
+        # fit's own context) / SocketExchange / TorchExchange.
         exchange = opt.get('exchange')
         own_exchange = False
         if isinstance(exchange, str) and exchange.lower() != "rccl":
@@ -161,6 +173,15 @@ class FitUtility:
         try:
             if isinstance(exchange, str):
                 exchange = pso.RcclExchange(ev)
+                own_exchange = True
+            elif isinstance(exchange, pso.RcclExchange) and exchange.ev is not ev:
+                # A communicator belongs to the context it was created on (its all-gather runs on that
+                # context's stream), and this fit has its own context for its own spectrum: make this
+                # fit's communicator over the ready one's channel, on the same device.  Collective, like
+                # the fit itself -- every rank passes its exchange object.
+                if exchange.channel is None:
+                    raise ValueError("options['exchange']: this RcclExchange has been closed")
+                exchange = pso.RcclExchange(ev, channel=exchange.channel)
                 own_exchange = True
             ev.set_fit_im(self.fit_im)     # True: the reference's imaginary term (equations.py:197-209)
             # kernel variant: by name or number, default by problem size (default_variant above)

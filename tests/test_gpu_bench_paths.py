@@ -61,12 +61,24 @@ def test_bench_paths_agree():
     assert plain["kernel_ms"]["max"] <= plain["step_ms"]["max"] * 1.001
     assert 500.0 < plain["roofline_valu"]["clock_mhz_in_run"] < 3000.0
     assert "error" not in plain
+    # both peaks of SURVEY 8(d)(i), the kind of rate, the spectrum the headline is measured on
+    # and the dense-spectrum figure beside it
+    assert r["rate_kind"] == "effective" and r["peak_measured_copy"] == 6290.0
+    assert r["frac_vs_measured_copy_peak"] == pytest.approx(r["achieved"] / 6290.0)
+    assert plain["config"]["spectrum"].startswith("sparse lines")
+    ds = plain["dense_spectrum"]
+    assert ds["kernel_ms"] > 0 and ds["units_per_s"] == pytest.approx(512 * 4096 * 6 / (ds["kernel_ms"] * 1e-3))
+    assert ds["farfield"]["kernel_ms"] > 0 and "broad overlapping" in ds["spectrum"]
     rccl = _run([sys.executable, "bench.py", "--swarm-per-gpu", "512"] + common, {"NMRFIT_BENCH_FORCE_DIST": "1"})
     assert rccl["config"]["swarm_best_f"] == plain["config"]["swarm_best_f"]
     assert "ncclAllGather" in rccl["config"]["exchange"]
     # how many ranks RCCL itself saw is a top-level field
     assert rccl["rccl"]["nranks"] == 1 and rccl["rccl"]["ranks_counted_by_all_reduce"] == 1
     assert rccl["rccl"]["version"] > 0 and "PCI" in rccl["rccl"]["rank0"] and "error" not in rccl
+    # which GPU every rank ended up on rides in the `rccl` object
+    pl = rccl["rccl"]["placement"]
+    assert len(pl) == 1 and pl[0]["rank"] == 0 and pl[0]["device"] == 0 and pl[0]["visible_devices"] >= 1
+    assert ":" in pl[0]["pci"] and rccl["rccl"]["distinct_pci_ids"] == 1
     assert "rccl" not in plain
     # self-launching form: no launcher, no WORLD_SIZE in the environment
     two = _run([sys.executable, "bench.py", "--gpus", "2", "--swarm-per-gpu", "256"] + common,
@@ -169,3 +181,30 @@ def test_real_rccl_two_ranks_on_one_device_is_refused_loudly():
              stderr_has=("ncclCommInitRank", "RCCL exchange unavailable"))
     assert time.time() - t0 < 120
     assert d["rccl"] is None and "did not run over RCCL" in d["error"] and "RCCL FAILED" in d["config"]["exchange"]
+
+
+def test_rank_isolated_by_visible_devices_lands_on_device_zero():
+    """a launcher that isolates each rank with HIP_VISIBLE_DEVICES shows every rank ONE
+    device, number 0, whatever its LOCAL_RANK -- `device = LOCAL_RANK` would die with "device index out of
+    range" on every rank but 0.  Here: LOCAL_RANK=3 with one visible device, through bench.py's RCCL branch
+    (a one-rank communicator) and through fit(exchange="rccl")."""
+    common = ["--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--workload", "C2", "--preheat-seconds", "0.1",
+              "--no-extras", "--swarm-per-gpu", "256"]
+    iso = {"HIP_VISIBLE_DEVICES": "0", "RANK": "0", "LOCAL_RANK": "3", "WORLD_SIZE": "1", "LOCAL_WORLD_SIZE": "8",
+           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "NMRFIT_BENCH_FORCE_DIST": "1"}
+    d = _run([sys.executable, "bench.py"] + common, iso, stderr_has=("this rank is isolated, using device 0",))
+    pl = d["rccl"]["placement"][0]
+    assert pl["device"] == 0 and pl["local_rank"] == 3 and pl["visible_devices"] == 1
+    assert pl["env"] == "HIP_VISIBLE_DEVICES=0" and "error" not in d
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import nmrfit_amd\nfrom nmrfit_amd import synth\n"
+            "sp = synth.make_spectrum(4096, 6, seed=21)\n"
+            "data = synth.SynthData(sp['w'], sp['u'], sp['v'], sp['peaks'])\n"
+            "res = nmrfit_amd.fit(data, list(sp['lower']), list(sp['upper']), summary=False,\n"
+            "                     options={'swarmsize': 64, 'maxiter': 5, 'exchange': 'rccl', 'seed': 3})\n"
+            "assert res._device() == 0 and res.error > 0\nres.generate_result()\nprint('ok')\n" % ROOT)
+    env = dict(os.environ, **iso)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+    assert "this rank is isolated, using device 0" in out.stderr

@@ -169,7 +169,7 @@ def test_sharded_swarm_over_sockets_equals_single_rank(tmp_path, world, S):
 
 def test_bench_self_launch_fails_fast_when_ranks_fail():
     """`python bench.py --gpus 2` with no launcher environment starts its own two ranks.  Without a
-    GPU they fail at context creation; the launcher must notice, end the other rank, and exit
+    GPU they fail at device selection; the launcher must notice, end the other rank, and exit
     non-zero within seconds -- never sit in a rendezvous waiting for a rank that is gone."""
     from nmrfit_amd import _cabi
     if _cabi.device_count() > 0:
@@ -183,7 +183,8 @@ def test_bench_self_launch_fails_fast_when_ranks_fail():
                          timeout=120)
     assert out.returncode != 0
     assert time.time() - t0 < 60
-    assert "rank" in out.stderr and ("NO_DEVICE" in out.stderr or "error -2" in out.stderr or "hipGetDeviceCount" in out.stderr)
+    assert "rank" in out.stderr and ("no HIP device is visible" in out.stderr or "NO_DEVICE" in out.stderr
+                                     or "error -2" in out.stderr or "hipGetDeviceCount" in out.stderr)
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
@@ -330,3 +331,53 @@ def test_rccl_missing_on_one_rank_is_an_error_on_every_rank():
         assert msg.startswith("%d|" % _cabi.E_UNSUPPORTED), msg
         assert "RCCL is not available on rank(s) [1]" in msg and "/nonexistent/librccl.so" in msg
         assert dt < 30
+
+
+def test_pick_device_over_launcher_policies():
+    """VERDICT r3 item 1 (the reference's parallel mode is a process pool, nmrfit/utils.py:182 --
+    here one process per GPU): the rank -> GPU mapping over {every device visible, one device per rank by
+    HIP_/ROCR_/CUDA_VISIBLE_DEVICES, isolation without a variable, a partial list} x world 8."""
+    from nmrfit_amd import rendezvous as rz
+    # (1) torch.distributed.run / bench.py's launcher: all 8 devices visible to every rank, nothing set
+    for lr in range(8):
+        env = {"LOCAL_RANK": str(lr), "RANK": str(lr), "WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "8"}
+        assert rz.pick_device(8, env=env) == (lr, "")
+    # (1b) the full list spelled out is the same thing
+    env = {"LOCAL_RANK": "5", "WORLD_SIZE": "8", "HIP_VISIBLE_DEVICES": "0,1,2,3,4,5,6,7"}
+    assert rz.pick_device(8, env=env) == (5, "")
+    # (2) per-rank isolation: one visible device, any of the three variables
+    for var in rz.VISIBILITY_VARS:
+        for lr in range(8):
+            env = {"LOCAL_RANK": str(lr), "WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "8", var: str(lr)}
+            dev, note = rz.pick_device(1, env=env)
+            assert dev == 0
+            assert (note == "") == (lr == 0)
+            if lr:
+                assert "%s=%d" % (var, lr) in note and "isolated" in note
+    # (3) one visible device, no variable (a device cgroup): device 0, and the note says what was assumed
+    dev, note = rz.pick_device(1, env={"LOCAL_RANK": "6", "WORLD_SIZE": "8"})
+    assert dev == 0 and "none of HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES is set" in note
+    # (4) a partial list that does not cover the local rank: an error naming the variables, not a guess
+    with pytest.raises(RuntimeError, match="LOCAL_RANK=5 of 8 local rank.*4 HIP devices are visible.*HIP_VISIBLE_DEVICES=0,1,2,3"):
+        rz.pick_device(4, env={"LOCAL_RANK": "5", "WORLD_SIZE": "8", "HIP_VISIBLE_DEVICES": "0,1,2,3"})
+    with pytest.raises(RuntimeError, match="no visibility variable set.*check HIP_VISIBLE_DEVICES"):
+        rz.pick_device(2, env={"LOCAL_RANK": "2", "WORLD_SIZE": "4"})
+    with pytest.raises(RuntimeError, match="no HIP device is visible"):
+        rz.pick_device(0, env={"LOCAL_RANK": "0", "HIP_VISIBLE_DEVICES": ""})
+    # LOCAL_RANK absent: RANK stands in (single-node launchers that set only RANK)
+    assert rz.pick_device(8, env={"RANK": "3", "WORLD_SIZE": "8"}) == (3, "")
+    assert rz.visible_devices_env({"ROCR_VISIBLE_DEVICES": "2", "CUDA_VISIBLE_DEVICES": "0"}) == \
+        "ROCR_VISIBLE_DEVICES=2 CUDA_VISIBLE_DEVICES=0"
+
+
+def test_bench_rank_with_an_impossible_device_fails_before_the_rendezvous():
+    """bench.py: LOCAL_RANK beyond the visible devices (and more than one visible) ends the rank with exit 6
+    and a message naming the variables -- before any socket is opened.  (No GPU here: device_count() is 0,
+    which is the same code path with "no HIP device is visible".)"""
+    env = dict(os.environ, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1",
+               HIP_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-seconds", "0"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 6, (out.returncode, out.stderr[-1500:])
+    assert "bench.py rank 1/2: no HIP device is visible to local rank 1 (HIP_VISIBLE_DEVICES=)" in out.stderr
+    assert not out.stdout.strip()

@@ -117,8 +117,12 @@ __device__ __forceinline__ void pbest_particle(int64_t i, int lane, int64_t D, c
 
 // block-wide first index of the minimum of fp (np.argmin) -> candidate record (fused tail, empty shards).
 // Must be called by every thread of the block (contains a barrier).
-__device__ __forceinline__ void argmin_block(int64_t S, int64_t D, const double *fp, const double *p, double *cand,
-                                             double *s_val, long long *s_idx)
+// While no particle has a finite objective yet (every fp still +inf: argmin 0) the record carries x[0] instead
+// of p[0] -- pyswarm seeds g with x[0, :] in that case (its `else` branch after the first evaluation), and the
+// fold's lowest-rank tie-break makes it GLOBAL particle 0's position; the restated loop (oracle.pso) and
+// tests/test_pso_cpu.py pin this.  Later folds ignore a record whose value is +inf.
+__device__ __forceinline__ void argmin_block(int64_t S, int64_t D, const double *fp, const double *p, const double *x,
+                                             double *cand, double *s_val, long long *s_idx)
 {
     double best = INFINITY;
     long long bi = 0x7fffffffffffffffLL;
@@ -157,8 +161,10 @@ __device__ __forceinline__ void argmin_block(int64_t S, int64_t D, const double 
         }
         bi = __shfl(bi, 0, kWave);
         if (bi >= S) bi = 0;   // every fp is +inf: np.argmin -> 0
-        if (lane == 0) cand[0] = (S > 0) ? fp[bi] : INFINITY;
-        for (int64_t d = lane; d < D; d += kWave) cand[1 + d] = (S > 0) ? p[bi * D + d] : 0.0;
+        const double fbest = (S > 0) ? fp[bi] : INFINITY;
+        const double *row = (fbest < INFINITY) ? p : x;
+        if (lane == 0) cand[0] = fbest;
+        for (int64_t d = lane; d < D; d += kWave) cand[1 + d] = (S > 0) ? row[bi * D + d] : 0.0;
     }
 }
 
@@ -177,12 +183,12 @@ __global__ void pso_update_kernel(int64_t S, int64_t D, int64_t offset, uint64_t
 
 __global__ __launch_bounds__(1024) void pso_argmin_kernel(int64_t S, int64_t D, const long long *__restrict__ flags,
                                                           const double *__restrict__ fp, const double *__restrict__ p,
-                                                          double *__restrict__ cand)
+                                                          const double *__restrict__ x, double *__restrict__ cand)
 {
     if (flags[1] != 0) return;
     __shared__ double s_val[16];
     __shared__ long long s_idx[16];
-    argmin_block(S, D, fp, p, cand, s_val, s_idx);
+    argmin_block(S, D, fp, p, x, cand, s_val, s_idx);
 }
 
 __global__ void pso_apply_kernel(int64_t D, int nranks, int is_init, double minstep, double minfunc,
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(1024) void pso_tail_kernel(TailArgs a)
         __syncthreads();
     }
     if (a.phases & kTailArgmin) {
-        argmin_block(a.S, a.D, a.fp, a.p, a.cand, s_val, s_idx);
+        argmin_block(a.S, a.D, a.fp, a.p, a.x, a.cand, s_val, s_idx);
         __syncthreads();
     }
     if (a.phases & kTailApply) {
@@ -325,8 +331,14 @@ __device__ __forceinline__ void select_final(const TailArgs &a, const double *pa
             bi = s_idx[w];
         }
     if (bi >= a.S) bi = 0;   // np.argmin of an all-inf array
+    // (`best` is fp[bi] as posted; +inf: nothing finite yet, the record carries x[0] -- see argmin_block; x was
+    // written by an earlier launch, plain loads)
     if (threadIdx.x == 0) a.cand[0] = load_f64<SHARED>(a.fp + bi);
-    for (int64_t d = threadIdx.x; d < a.D; d += blockDim.x) a.cand[1 + d] = load_f64<SHARED>(a.p + bi * a.D + d);
+    if (best < INFINITY) {
+        for (int64_t d = threadIdx.x; d < a.D; d += blockDim.x) a.cand[1 + d] = load_f64<SHARED>(a.p + bi * a.D + d);
+    } else {
+        for (int64_t d = threadIdx.x; d < a.D; d += blockDim.x) a.cand[1 + d] = a.x[bi * a.D + d];
+    }
     if (a.phases & kTailApply) {
         __syncthreads();
         if (wave == 0) apply_wave(lane, a.D, a.nranks, a.is_init, a.minstep, a.minfunc, a.cands, a.flags, a.best);
@@ -528,7 +540,7 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
     if (S == 0) {
         // an empty shard still posts its (+inf, zeros) candidate
         hipLaunchKernelGGL(pso_argmin_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, D, pso->d_flags, pso->d_fp,
-                           pso->d_p, pso->d_cand);
+                           pso->d_p, pso->d_x, pso->d_cand);
         NMRFIT_HIP(hipGetLastError());
         return NMRFIT_OK;
     }

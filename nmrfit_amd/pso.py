@@ -320,7 +320,11 @@ class HostSwarm:
             self.p[upd, :] = self.x[upd, :]
             self.fp[upd] = self.fx[upd]
             i = int(np.argmin(self.fp))
-            self.cand = np.concatenate(([self.fp[i]], self.p[i, :]))
+            # pyswarm seeds g with p[argmin fp] -- or, while no particle has a finite objective yet (every
+            # fp still +inf, argmin 0), with x[0]: the record then carries this shard's first position, and
+            # the fold's lowest-rank tie-break makes it GLOBAL particle 0's
+            row = self.p[i, :] if self.fp[i] < np.inf else self.x[i, :]
+            self.cand = np.concatenate(([self.fp[i]], row))
         else:
             self.fx = np.zeros(0)
             self.cand = np.concatenate(([np.inf], np.zeros(self.D)))

@@ -142,11 +142,15 @@ def compute_weights(w, peaks, expon=0.5):
 # ----------------------------------------------------------------------------------
 # pyswarm.pso (third party, absent): call site nmrfit/utils.py:176-182.
 # Restated from the published algorithm (tisimst/pyswarm master, pso.py).  PARITY
-# UNPINNED.  ``rng`` replaces numpy's global RNG so tests are reproducible; the draw
-# ORDER follows pyswarm (x, then v, then per iteration rp, rg).
+# UNPINNED against pyswarm itself (its source is not in /root/reference).  ``rng``
+# replaces numpy's global RNG and is the injection seam of tests/test_pso_cpu.py: any
+# object with ``random(shape)`` and ``uniform(size=shape)``; the draw ORDER follows
+# pyswarm (x, then v, then per iteration rp, rg), so a feed that returns supplied arrays
+# in that order pins the product's swarm rule to this restatement bit for bit.
+# ``full_output=True`` returns the whole final state beside (xopt, fopt).
 # ----------------------------------------------------------------------------------
 def pso(func, lb, ub, args=(), swarmsize=100, omega=0.5, phip=0.5, phig=0.5,
-        maxiter=100, minstep=1e-8, minfunc=1e-8, rng=None, verbose=False):
+        maxiter=100, minstep=1e-8, minfunc=1e-8, rng=None, verbose=False, full_output=False):
     rng = np.random.default_rng() if rng is None else rng
     lb = np.array(lb, dtype=float)
     ub = np.array(ub, dtype=float)
@@ -155,6 +159,11 @@ def pso(func, lb, ub, args=(), swarmsize=100, omega=0.5, phip=0.5, phig=0.5,
     vhigh = np.abs(ub - lb)
     vlow = -vhigh
     S, D = swarmsize, len(lb)
+
+    def done(xopt, fopt, reason, it):
+        if full_output:
+            return xopt, fopt, dict(x=x, v=v, p=p, fx=fx, fp=fp, g=g, fg=fg, it=it, reason=reason)
+        return xopt, fopt
 
     x = rng.random((S, D))
     fp = np.ones(S) * np.inf
@@ -170,7 +179,7 @@ def pso(func, lb, ub, args=(), swarmsize=100, omega=0.5, phip=0.5, phig=0.5,
         fg = fp[i_min]
         g = p[i_min, :].copy()
     else:
-        g = x[0, :].copy()
+        g = x[0, :].copy()          # no particle has a finite objective yet: pyswarm starts from particle 0
     v = vlow + rng.random((S, D)) * (vhigh - vlow)
 
     it = 1
@@ -193,18 +202,18 @@ def pso(func, lb, ub, args=(), swarmsize=100, omega=0.5, phip=0.5, phig=0.5,
             if np.abs(fg - fp[i_min]) <= minfunc:
                 if verbose:
                     print('Stopping search: Swarm best objective change less than {:}'.format(minfunc))
-                return p_min, fp[i_min]
+                return done(p_min, fp[i_min], 'minfunc', it)
             elif stepsize <= minstep:
                 if verbose:
                     print('Stopping search: Swarm best position change less than {:}'.format(minstep))
-                return p_min, fp[i_min]
+                return done(p_min, fp[i_min], 'minstep', it)
             else:
                 g = p_min.copy()
                 fg = fp[i_min]
         it += 1
     if verbose:
         print('Stopping search: maximum iterations reached --> {:}'.format(maxiter))
-    return g, fg
+    return done(g, fg, 'maxiter', maxiter)
 
 
 # ----------------------------------------------------------------------------------

@@ -195,7 +195,7 @@ def test_rank_isolated_by_visible_devices_lands_on_device_zero():
     d = _run([sys.executable, "bench.py"] + common, iso, stderr_has=("this rank is isolated, using device 0",))
     pl = d["rccl"]["placement"][0]
     assert pl["device"] == 0 and pl["local_rank"] == 3 and pl["visible_devices"] == 1
-    assert pl["env"] == "HIP_VISIBLE_DEVICES=0" and "error" not in d
+    assert "HIP_VISIBLE_DEVICES=0" in pl["env"] and "error" not in d      # (the box may export ROCR_/CUDA_ forms too)
     code = ("import sys; sys.path.insert(0, %r)\n"
             "import nmrfit_amd\nfrom nmrfit_amd import synth\n"
             "sp = synth.make_spectrum(4096, 6, seed=21)\n"

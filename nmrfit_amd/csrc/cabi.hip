@@ -194,6 +194,7 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
         }
     }
     const size_t bytes = (size_t)N * sizeof(double);
+    const size_t padded = (size_t)ctx->n_chunks * kChunk * sizeof(double);   // whole chunks, grid_slot order
     double *d_w_raw = nullptr;
 #define CTX_HIP(call)                                                              \
     do {                                                                           \
@@ -209,17 +210,24 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
     ctx->stream = ctx->own_stream;
     CTX_HIP(hipEventCreate(&ctx->ev0));
     CTX_HIP(hipEventCreate(&ctx->ev1));
-    CTX_HIP(hipMalloc((void **)&ctx->d_wc, bytes));
-    CTX_HIP(hipMalloc((void **)&ctx->d_u, bytes));
-    CTX_HIP(hipMalloc((void **)&ctx->d_v, bytes));
-    CTX_HIP(hipMalloc((void **)&ctx->d_wt, bytes));
+    double **grid_arrays[] = {&ctx->d_wc, &ctx->d_u, &ctx->d_v, &ctx->d_wt};
+    for (double **a : grid_arrays) {
+        CTX_HIP(hipMalloc((void **)a, padded));
+        CTX_HIP(hipMemsetAsync(*a, 0, padded, ctx->stream));
+    }
     CTX_HIP(hipMalloc((void **)&ctx->d_chunk, (size_t)ctx->n_chunks * sizeof(double2)));
+    CTX_HIP(hipMalloc((void **)&ctx->d_stage, bytes));
     CTX_HIP(hipMalloc((void **)&d_w_raw, bytes));
     CTX_HIP(hipMemcpyAsync(d_w_raw, w, bytes, hipMemcpyHostToDevice, ctx->stream));
-    CTX_HIP(hipMemcpyAsync(ctx->d_u, u, bytes, hipMemcpyHostToDevice, ctx->stream));
-    CTX_HIP(hipMemcpyAsync(ctx->d_v, v, bytes, hipMemcpyHostToDevice, ctx->stream));
-    CTX_HIP(hipMemcpyAsync(ctx->d_wt, weights, bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = prepare_grid(ctx, d_w_raw);
+    // u, v, weights: land in plain order, then into the pair-interleaved order the kernels read (nmrfit_internal.h,
+    // grid_slot); stream order lets the one landing buffer serve all three
+    const double *host_arrays[] = {u, v, weights};
+    double *dev_arrays[] = {ctx->d_u, ctx->d_v, ctx->d_wt};
+    for (int a = 0; a < 3 && rc == NMRFIT_OK; ++a) {
+        CTX_HIP(hipMemcpyAsync(ctx->d_stage, host_arrays[a], bytes, hipMemcpyHostToDevice, ctx->stream));
+        rc = scatter_grid(ctx, ctx->d_stage, dev_arrays[a]);
+    }
     if (rc != NMRFIT_OK) {
         (void)hipFree(d_w_raw);
         nmrfit_ctx_destroy(ctx);
@@ -238,7 +246,7 @@ int nmrfit_ctx_destroy(nmrfit_ctx *ctx)
     if (!ctx) return NMRFIT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
-    void *bufs[] = {ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, ctx->d_X, ctx->d_f, ctx->d_partial, ctx->d_R};
+    void *bufs[] = {ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, ctx->d_stage, ctx->d_X, ctx->d_f, ctx->d_partial, ctx->d_R};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -257,7 +265,9 @@ int nmrfit_ctx_set_weights(nmrfit_ctx *ctx, const double *weights)
         set_error("null weights");
         return NMRFIT_E_INVALID;
     }
-    NMRFIT_HIP(hipMemcpyAsync(ctx->d_wt, weights, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    NMRFIT_HIP(hipMemcpyAsync(ctx->d_stage, weights, (size_t)ctx->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = scatter_grid(ctx, ctx->d_stage, ctx->d_wt);
+    if (rc != NMRFIT_OK) return rc;
     NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
     return NMRFIT_OK;
 }
@@ -391,7 +401,7 @@ int nmrfit_contributions(nmrfit_ctx *ctx, int32_t P, const double *x, int64_t No
         CB_HIP(hipMalloc((void **)&d_w, (size_t)Nout * sizeof(double)));
         CB_HIP(hipMemcpy(d_w, wc.data(), (size_t)Nout * sizeof(double), hipMemcpyHostToDevice));
     }
-    rc = launch_contributions(ctx, P, d_x, Nout, w_out ? d_w : ctx->d_wc, d_out, d_out + n);
+    rc = launch_contributions(ctx, P, d_x, Nout, w_out ? d_w : ctx->d_wc, d_out, d_out + n, /*grid_order=*/w_out == nullptr);
     if (rc != NMRFIT_OK) goto done;
     CB_HIP(hipMemcpyAsync(real_out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     CB_HIP(hipMemcpyAsync(imag_out, d_out + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));

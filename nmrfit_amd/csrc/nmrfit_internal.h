@@ -23,6 +23,22 @@ constexpr int kMaxBlocks = 16;       // blocks per grid: the unit of the canonic
 constexpr int kMaxPeaks = 1000;      // LDS: 4 waves x P x (32 B PeakLor + 8 B PeakWin [+ 16 B recurrence + 32 B PeakFast,
                                      // dropped above P ~ 450]) + 1 KiB of block seeds <= 160 KiB
 
+// Physical order of the four grid arrays (centred w, u, v, weights) in device memory.  A lane's q-th point of a
+// chunk is the grid point at offset lane + 64*q (lanes stride the grid); in memory each chunk is stored
+// PAIR-INTERLEAVED, that point at offset 128*(q/2) + 2*lane + (q%2), so that a lane's points 2m and 2m+1 are one
+// aligned 16-byte pair and a wave fetches them with ONE global_load_dwordx4 (1 KiB per wave-instruction) instead of
+// two global_load_dwordx2: the vector-memory pipeline works through a wave's addresses at the same pace whatever
+// the width, and at 32 eight-byte loads per chunk it -- not the ALUs -- paced the far-field kernel (round 4; see
+// DESIGN.md).  Which lane evaluates which point, and in which order everything is summed, does not change: values
+// are bit-identical to the plain layout.  The arrays are padded to whole chunks (zeros: weight 0).
+__host__ __device__ inline int64_t grid_slot(int64_t j)
+{
+    const int64_t o = j & (int64_t)(kChunk - 1);
+    const int64_t l = o & (int64_t)(kWave - 1), q = o >> 6;
+    return (j - o) + (q >> 1) * (2 * kWave) + 2 * l + (q & 1);
+}
+static_assert(kWave == 64 && kPointsPerLane % 2 == 0, "grid_slot assumes wave64 and an even number of points per lane");
+
 // Per-(particle, peak) constants staged in LDS: see objective.hip.
 struct PeakLor {
     double ihw;   // 2/width (|t| capped at 1e18)
@@ -72,6 +88,7 @@ struct nmrfit_ctx {
     double *d_wc = nullptr;      // centred grid
     double *d_u = nullptr, *d_v = nullptr, *d_wt = nullptr;
     double2 *d_chunk = nullptr;  // per 512-point chunk: (min, max) of the centred grid
+    double *d_stage = nullptr;   // N doubles: plain-order landing buffer of an upload, before it is scattered into grid_slot order
     int64_t n_chunks = 0;
     // grow-on-demand workspace for the host-pointer entry points
     double *d_X = nullptr;
@@ -113,11 +130,14 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
 int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need);
 // centred grid + per-chunk (min,max) table from the raw device copy of w
 int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw);
+// d_dst[grid_slot(j)] = d_src[j], j < N (d_dst: n_chunks * kChunk doubles, padding untouched)
+int scatter_grid(nmrfit_ctx *ctx, const double *d_src, double *d_dst);
 // gather every rank's n-double record over the communicator (comm.hip), on the context's stream
 int comm_all_gather(nmrfit_comm *c, const double *d_send, int64_t n, const double **d_all);
 nmrfit_ctx *comm_ctx(const nmrfit_comm *c);       // the context a communicator was created on
 void comm_attach(nmrfit_comm *c, int delta);      // swarms attached to it (destroy order guard)
 // per-peak real/imag contributions on a (centred) output grid resident on the device
+// (grid_order: d_wc_out is the context's own centred grid, stored in grid_slot order)
 int launch_contributions(nmrfit_ctx *ctx, int32_t P, const double *dx, int64_t Nout, const double *d_wc_out,
-                         double *d_real, double *d_imag);
+                         double *d_real, double *d_imag, bool grid_order);
 }  // namespace nmrfit

@@ -72,6 +72,15 @@ constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 #define NMRFIT_MIN_WAVES 3
 #endif
 constexpr int kBatchInv = NMRFIT_BATCHINV;
+#ifndef NMRFIT_DIAG_ABLATE
+#define NMRFIT_DIAG_ABLATE 0   // diagnostic builds (wrong values on purpose): 1 no expansions, 2 no near peaks / Gaussians,
+#endif                         // 4 no Horner, 8 no epilogue arithmetic -- what each phase of the far-field chunk costs
+constexpr int kAblate = NMRFIT_DIAG_ABLATE;
+#ifdef NMRFIT_DIAG_REMAP
+constexpr bool kOneWorkgroupParticle = false;
+#else
+constexpr bool kOneWorkgroupParticle = true;
+#endif
 constexpr int kFarTerms = 16;      // Taylor terms of the far-field expansion (rho <= 0.1 -> 1e-16)
 constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coefficient scratch in LDS:
                                    // lane l sits at column l + l/16, which makes the transposed
@@ -609,14 +618,21 @@ __device__ __forceinline__ void objective_body(
 {
     constexpr int WPB = kWavesPerBlock;   // waves per workgroup = LDS slices
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    // (the wave index through v_readfirstlane: the compiler then KNOWS that everything derived from it -- particle,
+    // segment, chunk bases, the chunk table's address -- is wave-uniform, keeps it in scalar registers and fetches the
+    // chunk table with scalar loads instead of a vector load on the critical path at the top of every chunk)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // When every wave of the workgroup evaluates a segment of the SAME particle (nseg a multiple of
     // the waves per workgroup) the particle's prologue is done once per workgroup instead of once
     // per wave: one copy of the per-peak records (slice 0), the position update by wave 0, the
     // per-peak constants by the waves in turn (64 peaks a pass), the phase seeds by the last wave --
     // and a workgroup barrier.  For a short grid the prologue is as long as a chunk or two, so this
     // is what makes four or eight segments per particle affordable (C2: 17.7 -> see DESIGN.md).
+#ifdef NMRFIT_DIAG_REMAP   // diagnostic builds only (tools/ab.py): the waves of a workgroup = the SAME segment of four particles
+    const bool shared = false;
+#else
     const bool shared = (nseg % WPB == 0);
+#endif
     const int slice = shared ? 0 : wave;
     PeakLor *lor = reinterpret_cast<PeakLor *>(lds_raw) + (size_t)slice * P;
     PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)WPB * P * sizeof(PeakLor)) +
@@ -846,7 +862,7 @@ __device__ __forceinline__ void objective_body(
     if (kStage) {
 #pragma unroll
         for (int q = 0; q < kPointsPerLane; ++q)
-            wnext[q] = (j0 + lane + q * kWave < j1) ? wc[j0 + lane + q * kWave] : 0.0;
+            wnext[q] = (j0 + lane + q * kWave < j1) ? wc[j0 + (q >> 1) * (2 * kWave) + 2 * lane + (q & 1)] : 0.0;
     }
 
     // The chunk loop exists twice, once per Lorentzian group form, chosen ONCE per wave: inside one
@@ -896,12 +912,23 @@ __device__ __forceinline__ void objective_body(
                 }
             }
         } else if (full) {
-            const double *wp = wc + jl;
+#if defined(NMRFIT_DIAG_NOLOAD) && NMRFIT_DIAG_NOLOAD >= 2   // diagnostic: no grid loads (values are wrong on purpose)
 #pragma unroll
-            for (int q = 0; q < kPointsPerLane; ++q) wv[q] = wp[q * kWave];
+            for (int q = 0; q < kPointsPerLane; ++q) wv[q] = (double)(jl + q * kWave) * (lane_step * (1.0 / 64.0)) - wspan;
+#else
+            // (grid_slot order: the lane's points 2m, 2m+1 are one 16-byte pair -> global_load_dwordx4)
+            const double2 *wp = reinterpret_cast<const double2 *>(wc + jb) + lane;
+#pragma unroll
+            for (int m = 0; m < kPointsPerLane / 2; ++m) {
+                const double2 d = wp[m * kWave];
+                wv[2 * m] = d.x;
+                wv[2 * m + 1] = d.y;
+            }
+#endif
         } else {
 #pragma unroll
-            for (int q = 0; q < kPointsPerLane; ++q) wv[q] = (jl + q * kWave < j1) ? wc[jl + q * kWave] : 0.0;
+            for (int q = 0; q < kPointsPerLane; ++q)
+                wv[q] = (jl + q * kWave < j1) ? wc[jb + (q >> 1) * (2 * kWave) + 2 * lane + (q & 1)] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < kPointsPerLane; ++q) acc[q] = base;
@@ -939,6 +966,9 @@ __device__ __forceinline__ void objective_body(
                     // chunk that follows.  Either half runs the same operations in the same
                     // order, so a chunk's coefficients do not depend on which half made them.
                     unsigned near_c, hits_c;
+                    if constexpr ((kAblate & 1) != 0) {
+                        near_c = hits_c = 0u;
+                    } else
                     if (!ff_odd) {
                         const bool has_next = jb + kChunk < j1;                  // wave-uniform
                         double2 mn = mm;
@@ -1004,8 +1034,14 @@ __device__ __forceinline__ void objective_body(
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     const double *src = ffs + (ff_odd ? kFarTerms : 0);
+                    if constexpr ((kAblate & 1) != 0) {
+#pragma unroll
+                        for (int n = 0; n < kFarTerms; ++n) cf[n] = base * (double)(n + 1);
+                    } else {
 #pragma unroll
                     for (int n = 0; n < kFarTerms; ++n) cf[n] = src[n];
+                    }
+                    if constexpr ((kAblate & 2) != 0) near_c = hits_c = 0u;
                     for (unsigned m = near_c; m; m &= m - 1) lorentz_one(lor + __builtin_ctz(m), wv, acc);
                     if (kRec && full && rec_all) {
                         for (unsigned m = hits_c; m; m &= m - 1) gauss_add_rec(lor + __builtin_ctz(m), grec + __builtin_ctz(m), wv, acc);
@@ -1082,6 +1118,10 @@ __device__ __forceinline__ void objective_body(
                 for (int n = 0; n < kFarTerms; ++n) cf[n] = ffs[n];
                 }
                 const double ihwc = (hw > 0.0) ? rcp64(hw) : 0.0;
+                if constexpr ((kAblate & 4) != 0) {
+#pragma unroll
+                    for (int q = 0; q < kPointsPerLane; ++q) acc[q] += cf[q] + cf[q + 8] * wv[q];
+                } else
 #pragma unroll
                 for (int q = 0; q < kPointsPerLane; ++q) {
                     const double uu = (wv[q] - wcen) * ihwc;
@@ -1240,39 +1280,66 @@ __device__ __forceinline__ void objective_body(
         if (kStage) {
             if (full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk has landed
             // prefetch w of the next chunk into registers (the per-peak constants are dead here)
-            const int64_t jn = jl + kChunk;
+            const int64_t jn = jl + kChunk, jnb = jb + kChunk;
             if (jb + 2 * kChunk <= j1) {
+                const double2 *wp = reinterpret_cast<const double2 *>(wc + jnb) + lane;
 #pragma unroll
-                for (int q = 0; q < kPointsPerLane; ++q) wnext[q] = wc[jn + q * kWave];
+                for (int m = 0; m < kPointsPerLane / 2; ++m) {
+                    const double2 d = wp[m * kWave];
+                    wnext[2 * m] = d.x;
+                    wnext[2 * m + 1] = d.y;
+                }
             } else {
 #pragma unroll
-                for (int q = 0; q < kPointsPerLane; ++q) wnext[q] = (jn + q * kWave < j1) ? wc[jn + q * kWave] : 0.0;
+                for (int q = 0; q < kPointsPerLane; ++q)
+                    wnext[q] = (jn + q * kWave < j1) ? wc[jnb + (q >> 1) * (2 * kWave) + 2 * lane + (q & 1)] : 0.0;
             }
         }
         if (kStage && full) {
 #pragma unroll
             for (int q = 0; q < kPointsPerLane; ++q) {
-                uq[q] = stage[q * kWave + lane];
-                vq[q] = stage[kChunk + q * kWave + lane];
-                tq[q] = stage[2 * kChunk + q * kWave + lane];
+                const int o = (q >> 1) * (2 * kWave) + 2 * lane + (q & 1);   // the staged copy keeps the grid_slot order
+                uq[q] = stage[o];
+                vq[q] = stage[kChunk + o];
+                tq[q] = stage[2 * kChunk + o];
             }
         } else if (full) {
-            const double *up = u + jl, *vp = v + jl, *tp = wt + jl;
+#if defined(NMRFIT_DIAG_NOLOAD) && NMRFIT_DIAG_NOLOAD >= 1   // diagnostic: no data loads (values are wrong on purpose)
 #pragma unroll
             for (int q = 0; q < kPointsPerLane; ++q) {
-                uq[q] = up[q * kWave];
-                vq[q] = vp[q * kWave];
-                tq[q] = tp[q * kWave];
+                uq[q] = (double)(lane + q) * 1.0e-3;
+                vq[q] = (double)(lane - q) * 1.0e-3;
+                tq[q] = 1.0 + (double)q * 0.125;
             }
+#else
+            const double2 *up = reinterpret_cast<const double2 *>(u + jb) + lane;
+            const double2 *vp = reinterpret_cast<const double2 *>(v + jb) + lane;
+            const double2 *tp = reinterpret_cast<const double2 *>(wt + jb) + lane;
+#pragma unroll
+            for (int m = 0; m < kPointsPerLane / 2; ++m) {
+                const double2 du = up[m * kWave], dv = vp[m * kWave], dt = tp[m * kWave];
+                uq[2 * m] = du.x;
+                uq[2 * m + 1] = du.y;
+                vq[2 * m] = dv.x;
+                vq[2 * m + 1] = dv.y;
+                tq[2 * m] = dt.x;
+                tq[2 * m + 1] = dt.y;
+            }
+#endif
         } else {
 #pragma unroll
             for (int q = 0; q < kPointsPerLane; ++q) {
                 const bool ok = jl + q * kWave < j1;
-                uq[q] = ok ? u[jl + q * kWave] : 0.0;
-                vq[q] = ok ? v[jl + q * kWave] : 0.0;
-                tq[q] = ok ? wt[jl + q * kWave] : 0.0;   // weight 0: the point contributes nothing
+                const int64_t js = jb + (q >> 1) * (2 * kWave) + 2 * lane + (q & 1);   // grid_slot order
+                uq[q] = ok ? u[js] : 0.0;
+                vq[q] = ok ? v[js] : 0.0;
+                tq[q] = ok ? wt[js] : 0.0;   // weight 0: the point contributes nothing
             }
         }
+        if constexpr ((kAblate & 8) != 0) {
+#pragma unroll
+            for (int q = 0; q < kPointsPerLane; ++q) bs = __builtin_fma(acc[q], tq[q] + uq[q] * vq[q], bs);
+        } else
 #pragma unroll
         for (int q = 0; q < kPointsPerLane; ++q) {
             const double vd = __builtin_fma(zr, uq[q], -(zi * vq[q]));   // Re((zr + i zi)(u + i v))
@@ -1306,7 +1373,7 @@ __device__ __forceinline__ void objective_body(
             if (nseg == 1) {
                 ss += cs;
                 ss_im += cs_im;
-            } else if (nseg == WPB) {   // the four waves of THIS workgroup hold the whole particle: sums meet in LDS
+            } else if (kOneWorkgroupParticle && nseg == WPB) {   // the four waves of THIS workgroup hold the whole particle: sums meet in LDS
                 if (lane == 0) {
                     wsums[blk0 + bidx] = cs;
                     if (FIT_IM != 0) wsums[kMaxBlocks + blk0 + bidx] = cs_im;
@@ -1383,7 +1450,7 @@ __device__ __forceinline__ void objective_body(
         // (no fused personal best here: one wave per particle means >= 16384 particles, where the swarm's own
         // select kernels are noise next to the objective -- and the call cost the headline kernel 12 bytes of scratch)
     }
-    if (nseg == WPB && nseg > 1) {
+    if (kOneWorkgroupParticle && nseg == WPB && nseg > 1) {
         // One workgroup = one particle (segment = wave): the block sums are added here, in grid order
         // like finalize_value does -- the same canonical order, bit-identical f -- and the launch needs
         // neither the partial-sum buffer nor a finalize pass after it.  (All four waves get here: a
@@ -1424,7 +1491,14 @@ __global__ __launch_bounds__(kBlock, NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)
         wsums[2 * kMaxBlocks + 3] = __longlong_as_double((long long)S);
         wsums[2 * kMaxBlocks + 4] = __longlong_as_double((long long)upd.xrow_off);
     }
+#ifdef NMRFIT_DIAG_REMAP
+    // block b, wave w -> particle 4*(b / nseg) + w, segment b % nseg (S a multiple of 4)
+    const int64_t g = ((int64_t)(blockIdx.x / nseg) * kWavesPerBlock + (threadIdx.x >> 6)) * nseg + (blockIdx.x % nseg);
+#elif defined(NMRFIT_DIAG_VECTOR_G)   // A/B: the wave index as the compiler sees it without help (per-lane)
     const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+#else
+    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
     objective_body<VARIANT, WRITE_R, FIT_IM>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg, seg_len,
                                              blk_chunks, lane_step, rec_devk, out, R_out, clk, upd, aux_off, wsums);
 }
@@ -1444,7 +1518,7 @@ __global__ void finalize_kernel(const double *__restrict__ partial, int64_t S, i
 // imag[k, j] = its Kramers-Kronig partner in closed form.  One thread per (peak, point).
 __global__ void contributions_kernel(const double *__restrict__ wc_out, int64_t Nout, const double *__restrict__ x,
                                      int P, double w0, double wspan, double *__restrict__ real_out,
-                                     double *__restrict__ imag_out)
+                                     double *__restrict__ imag_out, int grid_order)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)P * Nout) return;
@@ -1460,7 +1534,7 @@ __global__ void contributions_kernel(const double *__restrict__ wc_out, int64_t 
     rec.c = -locc * rec.ihw;
     rec.al = a * r * ihw * kInvPi;
     rec.ag2 = 2.0 * a * (1.0 - r) * ihw * kSqrtLn2OverPi;
-    const double wj = wc_out[j];
+    const double wj = wc_out[grid_order ? grid_slot(j) : j];
     const double t = __builtin_fma(wj, rec.ihw, rec.c);
     const double s = __builtin_fma(t, t, 1.0);
     real_out[idx] = yoff + __builtin_fma(rec.al, rcp64(s), rec.ag2 * exp2_neg(-s));
@@ -1478,7 +1552,7 @@ __global__ void chunk_minmax_kernel(const double *__restrict__ wc, int64_t N, in
     for (int q = 0; q < kPointsPerLane; ++q) {
         const int64_t j = c * kChunk + q * kWave + lane;
         if (j < N) {
-            const double x = wc[j];
+            const double x = wc[grid_slot(j)];
             lo = fmin(lo, x);
             hi = fmax(hi, x);
         }
@@ -1493,7 +1567,13 @@ __global__ void chunk_minmax_kernel(const double *__restrict__ wc, int64_t N, in
 __global__ void centre_kernel(const double *__restrict__ w, int64_t N, double w0, double *__restrict__ wc)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < N) wc[j] = w[j] - w0;
+    if (j < N) wc[grid_slot(j)] = w[j] - w0;
+}
+
+__global__ void scatter_grid_kernel(const double *__restrict__ src, int64_t N, double *__restrict__ dst)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < N) dst[grid_slot(j)] = src[j];
 }
 
 template <int VARIANT>
@@ -1544,6 +1624,14 @@ int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw)
     const int waves_per_block = 4;
     hipLaunchKernelGGL(chunk_minmax_kernel, dim3((unsigned)((ctx->n_chunks + waves_per_block - 1) / waves_per_block)),
                        dim3(kWave * waves_per_block), 0, ctx->stream, ctx->d_wc, N, ctx->n_chunks, ctx->d_chunk);
+    NMRFIT_HIP(hipGetLastError());
+    return NMRFIT_OK;
+}
+
+int scatter_grid(nmrfit_ctx *ctx, const double *d_src, double *d_dst)
+{
+    const int64_t N = ctx->N;
+    hipLaunchKernelGGL(scatter_grid_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_src, N, d_dst);
     NMRFIT_HIP(hipGetLastError());
     return NMRFIT_OK;
 }
@@ -1653,8 +1741,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     // nseg == 1: the wave writes f; nseg == 4: the four waves of a workgroup are the particle's four
     // segments and the workgroup writes f (block sums through LDS); otherwise per-block sums go to a
     // buffer and finalize_kernel (or the swarm's select kernel) adds them.  Same summation order in all.
-    const bool direct_f = (nseg == 1 || nseg == kWavesPerBlock);
-    if (nseg != kWavesPerBlock) upd.pbest = 0u;   // (only when ONE workgroup holds the whole particle; else the caller's kernel)
+    const bool direct_f = (nseg == 1 || (kOneWorkgroupParticle && nseg == kWavesPerBlock));
+    if (!kOneWorkgroupParticle || nseg != kWavesPerBlock) upd.pbest = 0u;   // (only when ONE workgroup holds the whole particle; else the caller's kernel)
     double *out = df;
     if (!direct_f) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));
@@ -1707,12 +1795,12 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
 }
 
 int launch_contributions(nmrfit_ctx *ctx, int32_t P, const double *dx, int64_t Nout, const double *d_wc_out,
-                         double *d_real, double *d_imag)
+                         double *d_real, double *d_imag, bool grid_order)
 {
     const int64_t n = (int64_t)P * Nout;
     if (n == 0) return NMRFIT_OK;
     hipLaunchKernelGGL(contributions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_wc_out,
-                       Nout, dx, (int)P, ctx->w0, ctx->wspan, d_real, d_imag);
+                       Nout, dx, (int)P, ctx->w0, ctx->wspan, d_real, d_imag, grid_order ? 1 : 0);
     NMRFIT_HIP(hipGetLastError());
     return NMRFIT_OK;
 }

@@ -76,6 +76,10 @@ constexpr int kBatchInv = NMRFIT_BATCHINV;
 #define NMRFIT_DIAG_ABLATE 0   // diagnostic builds (wrong values on purpose): 1 no expansions, 2 no near peaks / Gaussians,
 #endif                         // 4 no Horner, 8 no epilogue arithmetic -- what each phase of the far-field chunk costs
 constexpr int kAblate = NMRFIT_DIAG_ABLATE;
+#ifndef NMRFIT_FF_PIPE
+#define NMRFIT_FF_PIPE 0   // FARFIELD, P <= 32: the NEXT pair's expansions started in the odd chunk before it (measured: +2 %; A/B knob)
+#endif
+constexpr bool kFarPipe = NMRFIT_FF_PIPE != 0;
 #ifdef NMRFIT_DIAG_REMAP
 constexpr bool kOneWorkgroupParticle = false;
 #else
@@ -171,6 +175,23 @@ __device__ __forceinline__ double wave_uniform(double x)
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
     return __hiloint2double(hi, lo);
+}
+
+// Lanes of ONE wave handing data to each other through LDS.  The LDS executes a wave's instructions in issue order,
+// so a read issued after a write of the same wave sees it -- no s_waitcnt is needed between them (the compiler waits
+// by itself before a read's RESULT is used).  What must not happen is the COMPILER moving one across the other: to it
+// they are accesses of one thread to different addresses.  Hence a compiler-only fence.  Round 3 had
+// `s_waitcnt lgkmcnt(0)` here: four drained LDS round trips per chunk pair in the far-field expansions with nothing
+// else for the wave to issue (-DNMRFIT_LDS_WAITS restores it for A/B runs).
+__device__ __forceinline__ void wave_lds_fence()
+{
+#ifdef NMRFIT_LDS_WAITS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#endif
 }
 
 __device__ __forceinline__ double wave_sum(double x)
@@ -781,7 +802,7 @@ __device__ __forceinline__ void objective_body(
         }
         if (stopped) return;   // the same for every wave of the grid
         if (shared) __syncthreads();   // wave 0's row is every wave's input
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
+        wave_lds_fence();   // same-wave LDS write -> read
     }
     double rr = 1.0, ri = 0.0, lr = 1.0, li = 0.0;   // rotation step exp(i p1 64/N), lane seed exp(i (p0 + p1 lane/N))
     const double invN = 1.0 / (double)N;
@@ -845,7 +866,7 @@ __device__ __forceinline__ void objective_body(
             sincos_fast((p1 * (double)((b0 + lane) * blk_len)) * invN, &ei, &er);
             seeds[lane] = make_double2(er, ei);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
+        wave_lds_fence();   // same-wave LDS write -> read
     }
     const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
     double bs = 0.0, bs_im = 0.0;             // per-lane sums of squares of the current block
@@ -857,7 +878,8 @@ __device__ __forceinline__ void objective_body(
     constexpr bool kFar = (VARIANT == NMRFIT_VARIANT_FARFIELD);
     constexpr int kGroup = (VARIANT == NMRFIT_VARIANT_SINGLE) ? 1 : (VARIANT == NMRFIT_VARIANT_QUAD) ? 4 : NMRFIT_GROUP;
 
-    unsigned pend_near = 0, pend_hits = 0;     // ... together with its near-peak and Gaussian-window masks
+    unsigned even_near = 0, even_hits = 0;     // FARFIELD, P <= 32: near-peak and Gaussian-window masks of the even ...
+    unsigned pend_near = 0, pend_hits = 0;     // ... and of the odd chunk of the current pair (expand_pair)
     double wnext[kPointsPerLane];
     if (kStage) {
 #pragma unroll
@@ -873,6 +895,71 @@ __device__ __forceinline__ void objective_body(
     // ... and the chunk body twice more, for full chunks and for the one ragged chunk at the end of
     // the grid: `full` is a compile-time constant inside, so the predicated and the unpredicated
     // loads never merge (each merge is eight register copies).
+    // FARFIELD, P <= 32: the far-field expansions of a PAIR of chunks -- lanes 0..31 those of chunk jbE, lanes 32..63
+    // those of the chunk after it -- summed over peaks into slots 0..15 / 16..31 of the wave's scratch, with the
+    // near-peak and Gaussian-window masks of the two chunks in scalar registers.  Either half runs the same
+    // operations in the same order, so a chunk's coefficients do not depend on which half made them, nor on when.
+    auto expand_pair = [&](const int64_t jbE) {
+        const double2 mm = chunk_minmax[jbE / kChunk];
+        const bool has_next = jbE + kChunk < j1;                  // wave-uniform
+        double2 mn = mm;
+        if (has_next) mn = chunk_minmax[jbE / kChunk + 1];
+        const bool upper = lane >= 32;
+        const int k = lane & 31;
+        const double lo_w = upper ? mn.x : mm.x, hi_w = upper ? mn.y : mm.y;
+        const bool act = (k < P) && (!upper || has_next);
+        bool far = false, ghit = false;
+        double a2 = 0.0, b2 = 0.0, y0 = 0.0, y1 = 0.0;
+        if (act) {
+            const PeakLor rec = lor[k];
+            const PeakWin wn = win[k];
+            ghit = (hi_w >= (double)wn.lo) && (lo_w <= (double)wn.hi);
+            const double tc = __builtin_fma(0.5 * (lo_w + hi_w), rec.ihw, rec.c);
+            const double hk = (0.5 * (hi_w - lo_w)) * rec.ihw;
+            const double den = __builtin_fma(tc, tc, 1.0);
+            far = den >= 100.0 * hk * hk;            // rho^2 <= 0.01 (false for NaN)
+            if (far) {
+                const double rq = rcp64(den);
+                const double qr = tc * rq;            // q = (tc + i)/(tc^2 + 1)
+                const double mr = -hk * qr, mi = -hk * rq;   // m = -hk q
+                a2 = mr + mr;
+                b2 = -__builtin_fma(mr, mr, mi * mi);
+                y0 = rec.al * rq;
+                y1 = rec.al * __builtin_fma(qr, mi, rq * mr);
+            }
+        }
+        const unsigned long long nearmask = __ballot(act && !far);
+        const unsigned long long hits = __ballot(ghit);
+        // order n carries al * Im(q m^n); both roots of the real recurrence y[n+1] = 2 Re(m) y[n] - |m|^2 y[n-1]
+        // have modulus |m| (stable), two operations a term; lanes without a far peak carry exact zeros (no branch
+        // on "any far peak at all": a pair of chunks without one is the rare case, and the branch would cut the
+        // straight-line code the scheduler interleaves with the chunk's other work)
+        double *dst = ffs + lane + (lane >> 4);
+#pragma unroll
+        for (int n = 0; n < kFarTerms; ++n) {
+            dst[n * kFarPad] = y0;
+            const double y2 = __builtin_fma(a2, y1, b2 * y0);
+            y0 = y1;
+            y1 = y2;
+        }
+        even_near = (unsigned)nearmask;
+        even_hits = (unsigned)hits;
+        pend_near = (unsigned)(nearmask >> 32);
+        pend_hits = (unsigned)(hits >> 32);
+        wave_lds_fence();   // same-wave LDS write -> read (expand_sums)
+    };
+    // ... second half: lane l sums order l>>2 over 16 peaks (quarter rows padded to 17 doubles), lanes l, l^1 hold
+    // the halves of one chunk; sums of the pair's first chunk -> slots 0..15, of its second -> slots 16..31
+    auto expand_sums = [&]() {
+        const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
+        double part = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) part += row[j];
+        part += __shfl_xor(part, 1, kWave);
+        wave_lds_fence();   // reads issued before the sums overwrite row 0
+        if ((lane & 1) == 0) ffs[((lane & 2) << 3) + (lane >> 2)] = part;
+        wave_lds_fence();
+    };
     auto chunk = [&](const int64_t jb, auto full_tag, auto odd_tag) {
         // FARFIELD, P <= 32: an odd chunk's expansion was made by the even chunk before it
         constexpr bool ff_odd = decltype(odd_tag)::value;
@@ -968,71 +1055,16 @@ __device__ __forceinline__ void objective_body(
                     unsigned near_c, hits_c;
                     if constexpr ((kAblate & 1) != 0) {
                         near_c = hits_c = 0u;
-                    } else
-                    if (!ff_odd) {
-                        const bool has_next = jb + kChunk < j1;                  // wave-uniform
-                        double2 mn = mm;
-                        if (has_next) mn = chunk_minmax[jb / kChunk + 1];
-                        const bool upper = lane >= 32;
-                        const int k = lane & 31;
-                        const double lo_w = upper ? mn.x : mm.x, hi_w = upper ? mn.y : mm.y;
-                        const bool act = (k < P) && (!upper || has_next);
-                        bool far = false, ghit = false;
-                        double a2 = 0.0, b2 = 0.0, y0 = 0.0, y1 = 0.0;
-                        if (act) {
-                            const PeakLor rec = lor[k];
-                            const PeakWin wn = win[k];
-                            ghit = (hi_w >= (double)wn.lo) && (lo_w <= (double)wn.hi);
-                            const double tc = __builtin_fma(0.5 * (lo_w + hi_w), rec.ihw, rec.c);
-                            const double hk = (0.5 * (hi_w - lo_w)) * rec.ihw;
-                            const double den = __builtin_fma(tc, tc, 1.0);
-                            far = den >= 100.0 * hk * hk;            // rho^2 <= 0.01 (false for NaN)
-                            if (far) {
-                                const double rq = rcp64(den);
-                                const double qr = tc * rq;            // q = (tc + i)/(tc^2 + 1)
-                                const double mr = -hk * qr, mi = -hk * rq;   // m = -hk q
-                                a2 = mr + mr;
-                                b2 = -__builtin_fma(mr, mr, mi * mi);
-                                y0 = rec.al * rq;
-                                y1 = rec.al * __builtin_fma(qr, mi, rq * mr);
-                            }
-                        }
-                        const unsigned long long farmask = __ballot(far);
-                        const unsigned long long nearmask = __ballot(act && !far);
-                        const unsigned long long hits = __ballot(ghit);
-                        double part = 0.0;
-                        if (farmask) {
-                            // order n carries al * Im(q m^n); both roots of the real recurrence
-                            // y[n+1] = 2 Re(m) y[n] - |m|^2 y[n-1] have modulus |m| (stable), two
-                            // operations a term; lanes without a far peak carry exact zeros
-                            double *dst = ffs + lane + (lane >> 4);
-#pragma unroll
-                            for (int n = 0; n < kFarTerms; ++n) {
-                                dst[n * kFarPad] = y0;
-                                const double y2 = __builtin_fma(a2, y1, b2 * y0);
-                                y0 = y1;
-                                y1 = y2;
-                            }
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
-                            // lane l sums order l>>2 over 16 peaks (quarters padded to 17:
-                            // conflict-free); lanes l, l^1 hold the halves of one chunk
-                            const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) part += row[j];
-                            part += __shfl_xor(part, 1, kWave);
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the sums overwrite row 0
-                        }
-                        // sums of this chunk -> slots 0..15, of the next -> slots 16..31
-                        if ((lane & 1) == 0) ffs[((lane & 2) << 3) + (lane >> 2)] = part;
-                        near_c = (unsigned)nearmask;
-                        hits_c = (unsigned)hits;
-                        pend_near = (unsigned)(nearmask >> 32);
-                        pend_hits = (unsigned)(hits >> 32);
                     } else {
-                        near_c = pend_near;
-                        hits_c = pend_hits;
+                        if constexpr (!kFarPipe)
+                            if (!ff_odd) {
+                                expand_pair(jb);
+                                expand_sums();
+                            }
+                        near_c = ff_odd ? pend_near : even_near;
+                        hits_c = ff_odd ? pend_hits : even_hits;
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wave_lds_fence();
                     const double *src = ffs + (ff_odd ? kFarTerms : 0);
                     if constexpr ((kAblate & 1) != 0) {
 #pragma unroll
@@ -1089,7 +1121,7 @@ __device__ __forceinline__ void objective_body(
                             y0 = y1;
                             y1 = y2;
                         }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
+                        wave_lds_fence();   // same-wave LDS write -> read
                         // lane l sums order l>>2 over 16 peaks of this pass (quarters padded to
                         // 17: conflict-free reads), then the quad combines
                         double part = 0.0;
@@ -1099,7 +1131,7 @@ __device__ __forceinline__ void objective_body(
                         part += __shfl_xor(part, 1, kWave);
                         part += __shfl_xor(part, 2, kWave);
                         csum += part;
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites
+                        wave_lds_fence();   // reads done before the next pass overwrites
                     }
                     for (unsigned long long m = nearmask; m; m &= m - 1)
                         lorentz_one(lor + kb + __builtin_ctzll(m), wv, acc);
@@ -1113,9 +1145,16 @@ __device__ __forceinline__ void objective_body(
                 }
                 // broadcast the kFarTerms sums through LDS and evaluate them at the lane's points
                 if ((lane & 3) == 0) ffs[lane >> 2] = csum;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wave_lds_fence();
 #pragma unroll
                 for (int n = 0; n < kFarTerms; ++n) cf[n] = ffs[n];
+                }
+                if constexpr (kFarPipe && ff_odd && full && FIT_IM != 2 && (kAblate & 1) == 0) {
+                    // Software pipeline (round 4): the expansions of the NEXT pair of chunks are started here, in the
+                    // odd chunk of the current pair -- whose own sums are in registers (cf) and whose masks are spent
+                    // -- so that their LDS writes complete under the Horner below instead of standing at the head of
+                    // the next even chunk with nothing else to issue; the sums over peaks follow in the epilogue.
+                    if (P <= 32 && jb + kChunk < j1) expand_pair(jb + kChunk);
                 }
                 const double ihwc = (hw > 0.0) ? rcp64(hw) : 0.0;
                 if constexpr ((kAblate & 4) != 0) {
@@ -1130,7 +1169,7 @@ __device__ __forceinline__ void objective_body(
                     for (int n = kFarTerms - 2; n >= 0; --n) pz = __builtin_fma(pz, uu, cf[n]);
                     acc[q] += pz;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wave_lds_fence();
             } else
             for (int kb = 0; kb < P; kb += kWave) {
                 const int kend = (P < kb + kWave) ? P : kb + kWave;
@@ -1238,7 +1277,7 @@ __device__ __forceinline__ void objective_body(
                         y0 = y1;
                         y1 = y2;
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS write -> read
+                    wave_lds_fence();   // same-wave LDS write -> read
                     double part = 0.0;
                     const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
 #pragma unroll
@@ -1246,7 +1285,7 @@ __device__ __forceinline__ void objective_body(
                     part += __shfl_xor(part, 1, kWave);
                     part += __shfl_xor(part, 2, kWave);
                     isum += part;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next pass overwrites
+                    wave_lds_fence();   // reads done before the next pass overwrites
                 }
                 for (unsigned long long m = nearmask; m; m &= m - 1) {
                     const PeakLor rec = lor[kb + __builtin_ctzll(m)];
@@ -1256,7 +1295,7 @@ __device__ __forceinline__ void objective_body(
             }
             if (anyfar) {   // wave-uniform
                 if ((lane & 3) == 0) ffs[lane >> 2] = isum;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wave_lds_fence();
                 double cfi[kFarTerms];
 #pragma unroll
                 for (int n = 0; n < kFarTerms; ++n) cfi[n] = ffs[n];
@@ -1270,7 +1309,7 @@ __device__ __forceinline__ void objective_body(
                     for (int n = kFarTerms - 2; n >= 0; --n) pz = __builtin_fma(pz, uu, cfi[n]);
                     iacc[q] += pz;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wave_lds_fence();
             }
         }
 
@@ -1336,6 +1375,11 @@ __device__ __forceinline__ void objective_body(
                 tq[q] = ok ? wt[js] : 0.0;   // weight 0: the point contributes nothing
             }
         }
+        if constexpr (kFar && kFarPipe && ff_odd && full && FIT_IM != 2 && (kAblate & 1) == 0) {
+            // ... and their sums over peaks here, while this chunk's u / v / weights are on their way: the LDS round
+            // trip (16 reads, the sums, one write) overlaps with a wait the wave has anyway.
+            if (P <= 32 && jb + kChunk < j1) expand_sums();
+        }
         if constexpr ((kAblate & 8) != 0) {
 #pragma unroll
             for (int q = 0; q < kPointsPerLane; ++q) bs = __builtin_fma(acc[q], tq[q] + uq[q] * vq[q], bs);
@@ -1391,6 +1435,11 @@ __device__ __forceinline__ void objective_body(
         }
     };
     int64_t jb = j0;
+    if constexpr (kFar && kFarPipe && FIT_IM != 2 && (kAblate & 1) == 0)
+        if (P <= 32 && j0 < j1) {   // the first pair's expansions; every later pair's: in the odd chunk before it
+            expand_pair(j0);
+            expand_sums();
+        }
     if constexpr (VARIANT == NMRFIT_VARIANT_FARFIELD) {   // chunks alternate even / odd from the segment start
         for (; jb + 2 * kChunk <= j1; jb += 2 * kChunk) {
             chunk(jb, std::true_type{}, std::false_type{});

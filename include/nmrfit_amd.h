@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NMRFIT_ABI_VERSION 3
+#define NMRFIT_ABI_VERSION 4
 
 enum {
     NMRFIT_OK = 0,
@@ -152,6 +152,9 @@ int nmrfit_timer_begin(nmrfit_ctx *ctx);
 int nmrfit_timer_end(nmrfit_ctx *ctx, double *elapsed_ms);
 /* launch geometry the last objective/residual launch used (for reports) */
 int nmrfit_last_launch(const nmrfit_ctx *ctx, int64_t *waves, int32_t *segments, int64_t *segment_len);
+/* ... and how many waves its workgroups had (ABI 4): 4, or 8 when a particle cut into eight segments was one
+ * eight-wave workgroup (small swarms on short grids -- the reference's default 204 particles, nmrfit/utils.py:177) */
+int nmrfit_last_launch_workgroup(const nmrfit_ctx *ctx, int32_t *waves_per_workgroup);
 
 /* ---- swarm loop ---------------------------------------------------------------------------
  * Replaces pyswarm.pso as FitUtility.fit calls it (nmrfit/utils.py:176-182): the swarm

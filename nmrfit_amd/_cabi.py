@@ -20,7 +20,7 @@ FIT_IM_OFF, FIT_IM_REFERENCE, FIT_IM_SUM = 0, 1, 2
 VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED, VARIANT_FARFIELD = 0, 1, 2, 3, 4, 5, 6
 VARIANT_NOREC = 7
 HANDOVER_FAST, HANDOVER_FENCED, HANDOVER_TWO_LAUNCH = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 _VARIANT_NAMES = {"default": 0, "baseline": 1, "noskip": 2, "single": 3, "quad": 4, "staged": 5, "farfield": 6,
                   "norec": 7}
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "nmrfit_timer_begin": [_VP],
     "nmrfit_timer_end": [_VP, _c_double_p],
     "nmrfit_last_launch": [_VP, ctypes.POINTER(_I64), ctypes.POINTER(_I32), ctypes.POINTER(_I64)],
+    "nmrfit_last_launch_workgroup": [_VP, ctypes.POINTER(_I32)],
     "nmrfit_pso_create": [_VP, _I64, _I64, _I64, _I32, _VP, _VP, ctypes.POINTER(PsoParams), _c_void_pp],
     "nmrfit_pso_destroy": [_VP],
     "nmrfit_pso_init": [_VP],

@@ -175,6 +175,7 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
     ctx->N = N;
     ctx->n_chunks = (N + kChunk - 1) / kChunk;
     if (const char *tw = getenv("NMRFIT_TARGET_WAVES")) ctx->target_waves = atoll(tw);   // tuning knob
+    if (getenv("NMRFIT_NO_WIDE_WORKGROUPS")) ctx->wide_workgroups = false;               // A/B knob
     // test knob: run a whole test suite with another kernel variant as every context's default
     if (const char *dv = getenv("NMRFIT_DEFAULT_VARIANT")) {
         const int vnum = atoi(dv);
@@ -611,6 +612,16 @@ int nmrfit_last_launch(const nmrfit_ctx *ctx, int64_t *waves, int32_t *segments,
     if (waves) *waves = ctx->last.waves;
     if (segments) *segments = ctx->last.nseg;
     if (segment_len) *segment_len = ctx->last.seg_len;
+    return NMRFIT_OK;
+}
+
+int nmrfit_last_launch_workgroup(const nmrfit_ctx *ctx, int32_t *waves_per_workgroup)
+{
+    if (!ctx) {
+        set_error("null context");
+        return NMRFIT_E_INVALID;
+    }
+    if (waves_per_workgroup) *waves_per_workgroup = ctx->last.waves_per_workgroup;
     return NMRFIT_OK;
 }
 

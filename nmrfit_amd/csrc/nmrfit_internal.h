@@ -70,6 +70,7 @@ struct LaunchGeom {
     int64_t waves = 0;
     int32_t nseg = 1;
     int64_t seg_len = 0;
+    int32_t waves_per_workgroup = 4;
 };
 
 }  // namespace nmrfit
@@ -85,6 +86,7 @@ struct nmrfit_ctx {
     double lane_step = 0.0;      // 64 * grid spacing when the grid is uniformly spaced, else 0 (Gaussian recurrence)
     double grid_dev = 0.0;       // bound on |(w[j+k] - w[j]) - k*spacing| over the grid (Gaussian recurrence)
     int64_t target_waves = 0;    // launch-geometry override (0 = heuristic)
+    bool wide_workgroups = true; // eight-wave workgroups for particles cut into eight segments (NMRFIT_NO_WIDE_WORKGROUPS: A/B knob)
     double *d_wc = nullptr;      // centred grid
     double *d_u = nullptr, *d_v = nullptr, *d_wt = nullptr;
     double2 *d_chunk = nullptr;  // per 512-point chunk: (min, max) of the centred grid

@@ -623,7 +623,7 @@ __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *r
                       (VARIANT) == NMRFIT_VARIANT_NOREC)                                                               \
                          ? NMRFIT_MIN_WAVES                                                                            \
                          : 4)
-template <int VARIANT, bool WRITE_R, int FIT_IM>
+template <int VARIANT, bool WRITE_R, int FIT_IM, int WPB>
 __device__ __forceinline__ void objective_body(
     unsigned char *lds_raw, const int64_t g,
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
@@ -637,7 +637,9 @@ __device__ __forceinline__ void objective_body(
     const unsigned aux_off,         // FIT_IM != 0: byte offset of the Dawson table in dynamic LDS
     double *wsums)                  // [2 * kMaxBlocks] in LDS: the particle's block sums when one workgroup owns it
 {
-    constexpr int WPB = kWavesPerBlock;   // waves per workgroup = LDS slices
+    // WPB: waves per workgroup = LDS slices.  Four (one per SIMD of a CU) everywhere except for particles cut into
+    // EIGHT segments (small swarms on short grids: the reference's default 204 particles x 4096 points), where an
+    // eight-wave workgroup holds the whole particle: one prologue, f and the personal best finished in this launch.
     const int lane = threadIdx.x & (kWave - 1);
     // (the wave index through v_readfirstlane: the compiler then KNOWS that everything derived from it -- particle,
     // segment, chunk bases, the chunk table's address -- is wave-uniform, keeps it in scalar registers and fetches the
@@ -1522,8 +1524,8 @@ __device__ __forceinline__ void objective_body(
     }
 }
 
-template <int VARIANT, bool WRITE_R, int FIT_IM>
-__global__ __launch_bounds__(kBlock, NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)) void objective_kernel(
+template <int VARIANT, bool WRITE_R, int FIT_IM, int WPB = kWavesPerBlock>
+__global__ __launch_bounds__(kWave *WPB, (WPB == kWavesPerBlock) ? NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM) : 2) void objective_kernel(
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax, const double *__restrict__ X, int64_t S,
     int P, int64_t N, double w0, double wspan, int nseg, int64_t seg_len, int blk_chunks, double lane_step,
@@ -1542,13 +1544,13 @@ __global__ __launch_bounds__(kBlock, NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)
     }
 #ifdef NMRFIT_DIAG_REMAP
     // block b, wave w -> particle 4*(b / nseg) + w, segment b % nseg (S a multiple of 4)
-    const int64_t g = ((int64_t)(blockIdx.x / nseg) * kWavesPerBlock + (threadIdx.x >> 6)) * nseg + (blockIdx.x % nseg);
+    const int64_t g = ((int64_t)(blockIdx.x / nseg) * WPB + (threadIdx.x >> 6)) * nseg + (blockIdx.x % nseg);
 #elif defined(NMRFIT_DIAG_VECTOR_G)   // A/B: the wave index as the compiler sees it without help (per-lane)
-    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t g = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
 #else
-    const int64_t g = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t g = (int64_t)blockIdx.x * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #endif
-    objective_body<VARIANT, WRITE_R, FIT_IM>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg, seg_len,
+    objective_body<VARIANT, WRITE_R, FIT_IM, WPB>(lds_raw, g, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg, seg_len,
                                              blk_chunks, lane_step, rec_devk, out, R_out, clk, upd, aux_off, wsums);
 }
 
@@ -1625,16 +1627,25 @@ __global__ void scatter_grid_kernel(const double *__restrict__ src, int64_t N, d
     if (j < N) dst[grid_slot(j)] = src[j];
 }
 
+// Which instantiations exist with eight-wave workgroups (one workgroup = one particle cut into eight segments):
+// the objective launches without the imaginary channel of the three kernels fit() can select.
+constexpr bool has_eight_wave_form(int variant)
+{
+    return variant == NMRFIT_VARIANT_DEFAULT || variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_NOREC;
+}
+constexpr int kWideWaves = 8;
+
 template <int VARIANT>
 int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *out, double *dR,
                    int nseg, int64_t seg_len, int blk_chunks, int64_t blocks, size_t lds, int fit_im,
-                   const PsoFused &upd, unsigned aux_off)
+                   const PsoFused &upd, unsigned aux_off, int wpb)
 {
-#define NMRFIT_LAUNCH(WR, FI)                                                                                   \
-    hipLaunchKernelGGL((objective_kernel<VARIANT, WR, FI>), dim3((unsigned)blocks), dim3(kBlock), lds,         \
+#define NMRFIT_LAUNCH_W(WR, FI, W)                                                                              \
+    hipLaunchKernelGGL((objective_kernel<VARIANT, WR, FI, W>), dim3((unsigned)blocks), dim3(kWave *(W)), lds,  \
                        ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,     \
                        ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, blk_chunks, ctx->lane_step,                 \
                        ctx->grid_dev * 11.0e10, out, dR, clk, upd, aux_off)
+#define NMRFIT_LAUNCH(WR, FI) NMRFIT_LAUNCH_W(WR, FI, kWavesPerBlock)
     // nmrfit_prof_enable: HIP events on the launch stream around this kernel alone
     const bool prof = ctx->prof_cap > 0 && ctx->prof_nk < ctx->prof_cap;
     unsigned long long *clk = prof ? ctx->d_clk : nullptr;
@@ -1642,7 +1653,14 @@ int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, doub
     if (dR) {
         NMRFIT_LAUNCH(true, 0);
     } else if (fit_im == 0) {
-        NMRFIT_LAUNCH(false, 0);
+        if constexpr (has_eight_wave_form(VARIANT)) {
+            if (wpb == kWideWaves)
+                NMRFIT_LAUNCH_W(false, 0, kWideWaves);
+            else
+                NMRFIT_LAUNCH(false, 0);
+        } else {
+            NMRFIT_LAUNCH(false, 0);
+        }
     } else if constexpr (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_FARFIELD || VARIANT == NMRFIT_VARIANT_NOREC) {
         if (fit_im == 1)
             NMRFIT_LAUNCH(false, 1);
@@ -1653,6 +1671,7 @@ int launch_variant(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, doub
         return NMRFIT_E_UNSUPPORTED;
     }
 #undef NMRFIT_LAUNCH
+#undef NMRFIT_LAUNCH_W
     NMRFIT_HIP(hipGetLastError());
     if (prof) {
         NMRFIT_HIP(hipEventRecord(ctx->prof_k1[(size_t)ctx->prof_nk], ctx->stream));
@@ -1688,9 +1707,8 @@ int scatter_grid(nmrfit_ctx *ctx, const double *d_src, double *d_dst)
 // The kernel variant a launch actually runs (the requested one may not fit in LDS, or may not
 // implement the imaginary part) and the dynamic LDS its per-wave records need.
 static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, int fit_im, int *variant_out,
-                              unsigned *aux_off)
+                              unsigned *aux_off, int wpb = kWavesPerBlock)
 {
-    constexpr int wpb = kWavesPerBlock;
     const size_t np = (size_t)std::max(P, 1);
     const size_t lds_recs = (((size_t)wpb * np * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
                             (size_t)wpb * kMaxBlocks * sizeof(double2) + kSharedPrologueBytes;
@@ -1763,14 +1781,29 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     int64_t seg_len = ((n_blocks + nseg - 1) / nseg) * blk_len;
     nseg = (N + seg_len - 1) / seg_len;
     const int64_t waves = S * nseg;
-    const int64_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    int variant = NMRFIT_VARIANT_DEFAULT;
+    unsigned aux_off = 0;
+    size_t lds = resolve_variant(ctx, P, dR != nullptr, fit_im, &variant, &aux_off);
+    // Eight segments per particle (small swarms on short grids -- the reference's default 204 x 4096): an EIGHT-wave
+    // workgroup is the particle, as the four-wave workgroup is for four segments: one prologue per particle, block
+    // sums through LDS, f (and, in a swarm generation, the personal best) finished in this launch.
+    int wpb = kWavesPerBlock;
+    const size_t xrow_bytes = (fused && fused->x_in) ? (size_t)(4 + 3 * (int64_t)P) * sizeof(double) : 0;
+    if (nseg == kWideWaves && !dR && fit_im == 0 && has_eight_wave_form(variant) && ctx->wide_workgroups) {
+        int v8 = variant;
+        unsigned aux8 = 0;
+        const size_t lds8 = resolve_variant(ctx, P, false, fit_im, &v8, &aux8, kWideWaves);
+        if (v8 == variant && lds8 + 64 + kWideWaves * xrow_bytes <= 160 * 1024) {
+            wpb = kWideWaves;
+            lds = lds8;
+            aux_off = aux8;
+        }
+    }
+    const int64_t blocks = (waves + wpb - 1) / wpb;
     if (blocks > 0x7fffffffLL) {
         set_error("swarm too large for one launch");
         return NMRFIT_E_INVALID;
     }
-    int variant = NMRFIT_VARIANT_DEFAULT;
-    unsigned aux_off = 0;
-    size_t lds = resolve_variant(ctx, P, dR != nullptr, fit_im, &variant, &aux_off);
     if (lds > 160 * 1024) {
         set_error("too many peaks for the imaginary model's LDS records");
         return NMRFIT_E_UNSUPPORTED;
@@ -1785,13 +1818,13 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         upd = *fused;
         lds = (lds + 15) & ~(size_t)15;
         upd.xrow_off = (unsigned)lds;
-        lds += (size_t)kWavesPerBlock * (size_t)(4 + 3 * (int64_t)P) * sizeof(double);
+        lds += (size_t)wpb * (size_t)(4 + 3 * (int64_t)P) * sizeof(double);
     }
     // nseg == 1: the wave writes f; nseg == 4: the four waves of a workgroup are the particle's four
     // segments and the workgroup writes f (block sums through LDS); otherwise per-block sums go to a
     // buffer and finalize_kernel (or the swarm's select kernel) adds them.  Same summation order in all.
-    const bool direct_f = (nseg == 1 || (kOneWorkgroupParticle && nseg == kWavesPerBlock));
-    if (!kOneWorkgroupParticle || nseg != kWavesPerBlock) upd.pbest = 0u;   // (only when ONE workgroup holds the whole particle; else the caller's kernel)
+    const bool direct_f = (nseg == 1 || (kOneWorkgroupParticle && nseg == wpb));
+    if (!kOneWorkgroupParticle || nseg != wpb) upd.pbest = 0u;   // (only when ONE workgroup holds the whole particle; else the caller's kernel)
     double *out = df;
     if (!direct_f) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));
@@ -1801,28 +1834,28 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     int rc;
     switch (variant) {
         case NMRFIT_VARIANT_BASELINE:
-            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
+            rc = launch_variant<NMRFIT_VARIANT_BASELINE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off, wpb);
             break;
         case NMRFIT_VARIANT_NOSKIP:
-            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
+            rc = launch_variant<NMRFIT_VARIANT_NOSKIP>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off, wpb);
             break;
         case NMRFIT_VARIANT_SINGLE:
-            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
+            rc = launch_variant<NMRFIT_VARIANT_SINGLE>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off, wpb);
             break;
         case NMRFIT_VARIANT_QUAD:
-            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
+            rc = launch_variant<NMRFIT_VARIANT_QUAD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off, wpb);
             break;
         case NMRFIT_VARIANT_FARFIELD:
-            rc = launch_variant<NMRFIT_VARIANT_FARFIELD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
+            rc = launch_variant<NMRFIT_VARIANT_FARFIELD>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off, wpb);
             break;
         case NMRFIT_VARIANT_NOREC:
-            rc = launch_variant<NMRFIT_VARIANT_NOREC>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
+            rc = launch_variant<NMRFIT_VARIANT_NOREC>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off, wpb);
             break;
         case NMRFIT_VARIANT_STAGED:
-            rc = launch_variant<NMRFIT_VARIANT_STAGED>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
+            rc = launch_variant<NMRFIT_VARIANT_STAGED>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off, wpb);
             break;
         default:
-            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off);
+            rc = launch_variant<NMRFIT_VARIANT_DEFAULT>(ctx, S, P, dX, out, dR, (int)nseg, seg_len, blk_chunks, blocks, lds, fit_im, upd, aux_off, wpb);
             break;
     }
     if (rc != NMRFIT_OK) return rc;
@@ -1838,6 +1871,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         NMRFIT_HIP(hipGetLastError());
     }
     ctx->last.waves = waves;
+    ctx->last.waves_per_workgroup = wpb;
     ctx->last.nseg = (int32_t)nseg;
     ctx->last.seg_len = seg_len;
     return NMRFIT_OK;

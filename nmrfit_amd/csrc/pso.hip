@@ -119,8 +119,8 @@ __device__ __forceinline__ void pbest_particle(int64_t i, int lane, int64_t D, c
 // Must be called by every thread of the block (contains a barrier).
 // While no particle has a finite objective yet (every fp still +inf: argmin 0) the record carries x[0] instead
 // of p[0] -- pyswarm seeds g with x[0, :] in that case (its `else` branch after the first evaluation), and the
-// fold's lowest-rank tie-break makes it GLOBAL particle 0's position; the restated loop (oracle.pso) and
-// tests/test_pso_cpu.py pin this.  Later folds ignore a record whose value is +inf.
+// fold's lowest-rank tie-break makes it GLOBAL particle 0's position; tests/test_pso_cpu.py pins this
+// against the restated pyswarm loop.  Later folds ignore a record whose value is +inf.
 __device__ __forceinline__ void argmin_block(int64_t S, int64_t D, const double *fp, const double *p, const double *x,
                                              double *cand, double *s_val, long long *s_idx)
 {

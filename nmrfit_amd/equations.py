@@ -205,7 +205,9 @@ class Evaluator:
         waves, nseg, seg_len = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int64(0)
         _cabi.check(self._lib.nmrfit_last_launch(self._ctx, ctypes.byref(waves), ctypes.byref(nseg),
                                                  ctypes.byref(seg_len)))
-        return dict(waves=waves.value, segments=nseg.value, segment_len=seg_len.value)
+        wpw = ctypes.c_int32(0)
+        _cabi.check(self._lib.nmrfit_last_launch_workgroup(self._ctx, ctypes.byref(wpw)))
+        return dict(waves=waves.value, segments=nseg.value, segment_len=seg_len.value, waves_per_workgroup=wpw.value)
 
 
 # ---- scalar shim with the reference signature ---------------------------------------------

@@ -226,6 +226,10 @@ def test_four_segment_workgroup_reduction_matches_the_other_geometries(eq, varia
             assert ev.last_launch()["segments"] == 4
             f_eight = ev.objective_batch(X[:60], fit_im=mode)
             assert ev.last_launch()["segments"] == 8
+            # eight segments: ONE eight-wave workgroup per particle (round 4; objective launches without the
+            # imaginary channel of the kernels fit() selects), block sums through LDS like the four-wave form
+            wide = mode is False and variant in ("default", "farfield", "norec")
+            assert ev.last_launch()["waves_per_workgroup"] == (8 if wide else 4)
             np.testing.assert_array_equal(f_four, f_one[:1200], err_msg=str(mode))
             np.testing.assert_array_equal(f_eight, f_one[:60], err_msg=str(mode))
         R = ev.residual_batch(X[:1200][:8])          # (residual rows are a small batch: eight segments)

@@ -358,6 +358,9 @@ def test_ticket_select_long_run(problem):
     (1000, 2048, 3, "default", False),     # ragged last workgroup
     (130, 700, 5, "default", False),       # ragged grid, just above the single-workgroup tail
     (204, 4096, 6, "farfield", False),
+    (50, 4096, 6, "default", False),       # eight segments per particle = ONE eight-wave workgroup (round 4): update,
+    (300, 4096, 6, "norec", False),        # evaluation, f and personal best in the objective launch ("fused_pbest")
+    (204, 16384, 12, "farfield", False),
     (120, 4096, 3, "default", True),       # the reference's fit_im=True
     (120, 4096, 3, "default", "sum"),
     (1024, 4096, 3, "default", True),      # four segments per particle: f written by the workgroup, with the
@@ -390,6 +393,8 @@ def test_handover_modes_match_numpy_mirror(S, N, P, variant, fit_im, mode):
                 dev.set_fused_pbest(False)
                 dev.set_handover(mode)
             dev.run(gens, check_every=ce)
+            if (S, N, P) in ((204, 4096, 6), (50, 4096, 6), (204, 16384, 12)) and fit_im is False:
+                assert ev.last_launch()["waves_per_workgroup"] == 8 and ev.last_launch()["segments"] == 8
             st = dev.state()
             for k in ("x", "v", "p", "fx", "fp"):
                 np.testing.assert_array_equal(st[k], getattr(host, k), err_msg="%s (check_every=%d)" % (k, ce))

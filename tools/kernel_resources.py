@@ -57,12 +57,13 @@ def main():
     print("%-58s %5s %5s %8s %6s %8s" % ("kernel", "VGPR", "AGPR", "scratch", "waves", "LDS"))
     for r in rows:
         name = r["pretty"]
-        m = re.match(r"objective_kernel<(\d+), (true|false), (\d+)>", name)
+        m = re.match(r"objective_kernel<(\d+), (true|false), (\d+), (\d+)>", name)
         label = name
         selectable = False
         if m:
             v, wr, fi = int(m.group(1)), m.group(2) == "true", int(m.group(3))
-            label = "objective_kernel<%s,%s,fit_im=%d>" % (VARIANTS.get(v, v), "residual" if wr else "objective", fi)
+            label = "objective_kernel<%s,%s,fit_im=%d%s>" % (VARIANTS.get(v, v), "residual" if wr else "objective", fi,
+                                                            ",8 waves" if m.group(4) == "8" else "")
             selectable = v in (0, 6, 7)
         scratch = int(r.get("ScratchSize [bytes/lane]", "0"))
         print("%-58s %5s %5s %8d %6s %8s" % (label[:58], r.get("VGPRs", "?"), r.get("AGPRs", "?"), scratch,

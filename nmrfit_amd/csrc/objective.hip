@@ -1706,10 +1706,15 @@ int scatter_grid(nmrfit_ctx *ctx, const double *d_src, double *d_dst)
 
 // The kernel variant a launch actually runs (the requested one may not fit in LDS, or may not
 // implement the imaginary part) and the dynamic LDS its per-wave records need.
+constexpr size_t kStaticLds = (2 * kMaxBlocks + 5) * sizeof(double) + 64;   // objective_kernel's own __shared__ (wsums) + alignment slack
 static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, int fit_im, int *variant_out,
-                              unsigned *aux_off, int wpb = kWavesPerBlock)
+                              unsigned *aux_off, int wpb = kWavesPerBlock, bool fused_rows = false)
 {
     const size_t np = (size_t)std::max(P, 1);
+    // what a workgroup may take of a CU's 160 KiB for the records sized here: everything but the kernel's static
+    // LDS and (swarm generations) the per-wave copies of the updated rows that launch_objective appends
+    const size_t room = 160 * 1024 - kStaticLds -
+                        (fused_rows ? (size_t)wpb * (size_t)(4 + 3 * (int64_t)P) * sizeof(double) + 16 : 0);
     const size_t lds_recs = (((size_t)wpb * np * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
                             (size_t)wpb * kMaxBlocks * sizeof(double2) + kSharedPrologueBytes;
     const size_t lds_stage = (size_t)wpb * 3 * kChunk * sizeof(double);
@@ -1727,10 +1732,10 @@ static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, i
     if (variant == NMRFIT_VARIANT_STAGED && fit_im != 0) variant = NMRFIT_VARIANT_DEFAULT;
     // STAGED needs three workgroups to still fit in a CU's 160 KiB (P <= 27); beyond that it
     // runs the unstaged kernel.
-    if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
-    if (variant == NMRFIT_VARIANT_FARFIELD && lds_recs + lds_far + lds_rec + lds_tab > 160 * 1024)
+    if (variant == NMRFIT_VARIANT_STAGED && 3 * (lds_recs + lds_stage + kStaticLds) > 160 * 1024) variant = NMRFIT_VARIANT_DEFAULT;
+    if (variant == NMRFIT_VARIANT_FARFIELD && lds_recs + lds_far + lds_rec + lds_tab + 16 > room)
         variant = NMRFIT_VARIANT_DEFAULT;   // P > ~600
-    if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_im + lds_rec + lds_fast + lds_tab > 160 * 1024)
+    if (variant == NMRFIT_VARIANT_DEFAULT && lds_recs + lds_im + lds_rec + lds_fast + lds_tab + 16 > room)
         variant = NMRFIT_VARIANT_NOREC;     // P > ~450: no room for the recurrence / scaled records
     size_t lds = lds_recs + (variant == NMRFIT_VARIANT_STAGED ? lds_stage : 0) +
                  (variant == NMRFIT_VARIANT_FARFIELD ? lds_far : lds_im) +
@@ -1783,7 +1788,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     const int64_t waves = S * nseg;
     int variant = NMRFIT_VARIANT_DEFAULT;
     unsigned aux_off = 0;
-    size_t lds = resolve_variant(ctx, P, dR != nullptr, fit_im, &variant, &aux_off);
+    const bool fused_rows = fused && fused->x_in;
+    size_t lds = resolve_variant(ctx, P, dR != nullptr, fit_im, &variant, &aux_off, kWavesPerBlock, fused_rows);
     // Eight segments per particle (small swarms on short grids -- the reference's default 204 x 4096): an EIGHT-wave
     // workgroup is the particle, as the four-wave workgroup is for four segments: one prologue per particle, block
     // sums through LDS, f (and, in a swarm generation, the personal best) finished in this launch.
@@ -1792,8 +1798,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     if (nseg == kWideWaves && !dR && fit_im == 0 && has_eight_wave_form(variant) && ctx->wide_workgroups) {
         int v8 = variant;
         unsigned aux8 = 0;
-        const size_t lds8 = resolve_variant(ctx, P, false, fit_im, &v8, &aux8, kWideWaves);
-        if (v8 == variant && lds8 + 64 + kWideWaves * xrow_bytes <= 160 * 1024) {
+        const size_t lds8 = resolve_variant(ctx, P, false, fit_im, &v8, &aux8, kWideWaves, fused_rows);
+        if (v8 == variant && lds8 + kStaticLds + 16 + kWideWaves * xrow_bytes <= 160 * 1024) {
             wpb = kWideWaves;
             lds = lds8;
             aux_off = aux8;
@@ -1804,8 +1810,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         set_error("swarm too large for one launch");
         return NMRFIT_E_INVALID;
     }
-    if (lds > 160 * 1024) {
-        set_error("too many peaks for the imaginary model's LDS records");
+    if (lds + kStaticLds + 16 + (size_t)wpb * xrow_bytes > 160 * 1024) {
+        set_error("too many peaks for the kernel's LDS records (with the imaginary model / the fused swarm update)");
         return NMRFIT_E_UNSUPPORTED;
     }
     // fused swarm update: one copy of the particle's updated row per wave, after everything else

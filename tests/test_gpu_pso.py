@@ -457,19 +457,24 @@ def test_handover_stress_short(S, N, P):
             a = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
             b = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
             c = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
-            a.set_fused_pbest(False)          # a, b: the select kernel runs at every shape (fence-free / two launches)
-            b.set_fused_pbest(False)
-            b.set_handover("two_launch")
-            for sw in (a, b, c):              # c: the defaults (personal bests inside the objective launch at 512, 1024)
+            d = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+            a.set_fused_pbest(False)          # a, b, d: the select kernel runs at every shape (fence-free / two launches /
+            b.set_fused_pbest(False)          # the textbook release-acquire form the fence-free one is an optimisation of:
+            b.set_handover("two_launch")      # ADVICE r3 -- a driver or toolchain change that broke FAST's ordering
+            d.set_fused_pbest(False)          # would show here as a difference between a and d)
+            d.set_handover("fenced")
+            for sw in (a, b, c, d):           # c: the defaults (personal bests inside the objective launch where a workgroup is a particle)
                 sw.run(gens, check_every=250)
-            sa, sb, sc = a.state(), b.state(), c.state()
+            sa, sb, sc, sd = a.state(), b.state(), c.state(), d.state()
             for k in ("x", "v", "p", "fx", "fp"):
                 np.testing.assert_array_equal(sa[k], sb[k], err_msg="%s (seed %d)" % (k, seed))
                 np.testing.assert_array_equal(sc[k], sb[k], err_msg="%s (seed %d, defaults)" % (k, seed))
-            assert a.status() == b.status() == c.status() and a.status()["iteration"] == gens
+                np.testing.assert_array_equal(sa[k], sd[k], err_msg="%s (seed %d, fast vs fenced)" % (k, seed))
+            assert a.status() == b.status() == c.status() == d.status() and a.status()["iteration"] == gens
             np.testing.assert_array_equal(a.best()[0], b.best()[0])
             np.testing.assert_array_equal(c.best()[0], b.best()[0])
-            for sw in (a, b, c):
+            np.testing.assert_array_equal(d.best()[0], b.best()[0])
+            for sw in (a, b, c, d):
                 sw.close()
 
 
@@ -673,3 +678,32 @@ def test_no_finite_objective_yet_seeds_g_with_particle_zero(S):
         assert np.isinf(fb) and dev.status()["iteration"] == 3
         np.testing.assert_array_equal(xb, x0)
         dev.close()
+
+
+@pytest.mark.parametrize("P", [130, 132, 133, 440, 452, 460, 598, 606, 700])
+@pytest.mark.parametrize("fit_im", [False, True, "sum"])
+def test_lds_budget_on_both_sides_of_every_threshold(P, fit_im):
+    """the LDS budget that picks the kernel variant (scaled records above ~450 peaks, far-field
+    scratch above ~600) counts the kernel's static LDS, the Dawson table of the imaginary channel and -- in a
+    swarm generation with D <= 400 (P <= 132) -- the per-wave copies of the updated rows.  On either side of each
+    threshold a swarm generation runs (no HIP launch error) and equals the numpy mirror, with and without the
+    imaginary channel, for the direct and the far-field kernel."""
+    from nmrfit_amd import equations
+    sp = synth.make_spectrum(1024, P, seed=9)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        for variant in ("default", "farfield"):
+            ev.set_variant(_cabi.variant_id(variant))
+            ev.set_fit_im(fit_im)
+            dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 6, seed=5, minfunc=-1.0, minstep=-1.0)
+            host = pso.HostSwarm(lambda X: ev.objective_batch(X, fit_im=fit_im), sp["lower"], sp["upper"], 6, seed=5,
+                                 minfunc=-1.0, minstep=-1.0)
+            dev.run(2, check_every=2)
+            host.init()
+            host.apply_global(host.candidate()[None, :])
+            for _ in range(2):
+                host.step_local()
+                host.apply_global(host.candidate()[None, :])
+            st = dev.state()
+            for k in ("x", "fx", "fp"):
+                np.testing.assert_array_equal(st[k], getattr(host, k), err_msg="%s %s" % (variant, k))
+            dev.close()

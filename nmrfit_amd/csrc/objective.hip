@@ -247,52 +247,12 @@ __device__ __forceinline__ double dispersion(double wcj, const PeakLor &r)
     return __builtin_fma(r.al * t, rcp64(s), (r.ag2 * kInvSqrtPi) * dawson(kSqrtLn2 * t));
 }
 
-// dawson() with every coefficient read from a table in LDS (layout: kNear[15], kFar[12], kMid[6][19]
-// = 141 doubles, staged once per workgroup) instead of sitting in registers: the objective kernel is
-// at the SGPR limit, and the three coefficient sets as loop-invariant register constants cost the
-// far-field instantiation 13 spilled VGPRs.  Same operations in the same order as dawson():
-// bit-identical values.
-constexpr int kDawLdsNear = 0, kDawLdsFar = 15, kDawLdsMid = 27, kDawLdsCount = 27 + 6 * 19;
-__device__ __forceinline__ double dawson_lds(double x, const double *tab)
-{
-    const double ax = fabs(x);
-    double r;
-    if (ax < 1.0) {
-        const double y = x * x;
-        double p = tab[kDawLdsNear + 14];
-#pragma unroll
-        for (int i = 13; i >= 0; --i) p = __builtin_fma(p, y, tab[kDawLdsNear + i]);
-        return x * p;
-    } else if (ax < 7.0) {
-        const int k = (int)ax;                 // 1..6
-        const double t = 2.0 * (ax - (double)k) - 1.0;
-        const double *q = tab + kDawLdsMid + (k - 1) * 19;
-        double p = q[18];
-#pragma unroll
-        for (int i = 17; i >= 0; --i) p = __builtin_fma(p, t, q[i]);
-        r = p;
-    } else {
-        const double inv = rcp64(ax);         // NaN/inf propagate: D(inf) = 0
-        const double s2 = 49.0 * inv * inv;
-        double p = tab[kDawLdsFar + 11];
-#pragma unroll
-        for (int i = 10; i >= 0; --i) p = __builtin_fma(p, s2, tab[kDawLdsFar + i]);
-        r = 0.5 * p * inv;
-    }
-    return copysign(r, x);
-}
-__device__ __forceinline__ double dispersion_lds(double wcj, const PeakLor &r, const double *tab)
-{
-    const double t = __builtin_fma(wcj, r.ihw, r.c);
-    const double s = __builtin_fma(t, t, 1.0);
-    return __builtin_fma(r.al * t, rcp64(s), (r.ag2 * kInvSqrtPi) * dawson_lds(kSqrtLn2 * t, tab));
-}
-
 // Dawson's integral for the objective's imaginary channel: the same piecewise fits, but one
 // degree-18 polynomial for EVERY unit interval [k, k+1), k = 0..15, gathered from a 2.4 KiB table
 // in LDS by a per-lane index -- no divergent branches (the lanes of a wave sit in two or three
 // different intervals), 19 FMAs + 19 broadcast-friendly LDS reads.  Beyond 16 the asymptotic form
 // (a branch almost no wave takes: such peaks are summed through the far-field expansion).
+constexpr int kDawTabFar = 16 * 19, kDawTabCount = 16 * 19 + 12;   // kTab[16][19], then kFar[12]
 __device__ __forceinline__ double dawson_tab(double x, const double *tab)
 {
     const double ax = fabs(x);
@@ -305,9 +265,9 @@ __device__ __forceinline__ double dawson_tab(double x, const double *tab)
     if (!(ax < 16.0)) {
         const double inv = rcp64(ax);                  // NaN/inf propagate: D(inf) = 0
         const double s2 = 49.0 * inv * inv;
-        double g = dawson::kFar[11];
+        double g = tab[kDawTabFar + 11];
 #pragma unroll
-        for (int i = 10; i >= 0; --i) g = __builtin_fma(g, s2, dawson::kFar[i]);
+        for (int i = 10; i >= 0; --i) g = __builtin_fma(g, s2, tab[kDawTabFar + i]);
         p = 0.5 * g * inv;
     }
     return copysign(p, x);
@@ -319,6 +279,46 @@ __device__ __forceinline__ double dispersion_tab(double wcj, const PeakLor &r, c
     const double t = __builtin_fma(wcj, r.ihw, r.c);
     const double s = __builtin_fma(t, t, 1.0);
     return __builtin_fma(r.al * t, rcp64(s), (r.ag2 * kInvSqrtPi) * dawson_tab(kSqrtLn2 * t, tab));
+}
+
+// The reference's fit_im=True compares the imaginary channel with the LAST peak's dispersion line only
+// (equations.py:199 assigns I_fit instead of accumulating): that one line at the lane's points of a chunk, all
+// points together.  In almost every chunk the peak is far away (|sqrt(ln2) t| >= 16 at every point of the wave: a
+// wave-uniform test), where Dawson's integral is its asymptotic series -- 12 coefficients read ONCE per chunk,
+// straight-line code over the eight points; otherwise the gathered table.  Round 3 evaluated point after point
+// with a three-way branch whose Horner steps each waited for their own LDS read (a chain of ~18 LDS round trips
+// per point at two or three waves per SIMD).
+__device__ __forceinline__ void dispersion_points(const double (&wv)[kPointsPerLane], const PeakLor &r, const double *tab,
+                                                  double (&out)[kPointsPerLane])
+{
+    double t[kPointsPerLane];
+    bool far = true;
+#pragma unroll
+    for (int q = 0; q < kPointsPerLane; ++q) {
+        t[q] = __builtin_fma(wv[q], r.ihw, r.c);
+        far = far && (fabs(kSqrtLn2 * t[q]) >= 16.0);   // false for NaN
+    }
+    const double agd = r.ag2 * kInvSqrtPi;
+    if (__ballot(!far) == 0ull) {
+        double cfar[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cfar[i] = tab[kDawTabFar + i];
+#pragma unroll
+        for (int q = 0; q < kPointsPerLane; ++q) {
+            const double x = kSqrtLn2 * t[q];
+            const double inv = rcp64(fabs(x));
+            const double s2 = 49.0 * inv * inv;
+            double g = cfar[11];
+#pragma unroll
+            for (int i = 10; i >= 0; --i) g = __builtin_fma(g, s2, cfar[i]);
+            const double d = copysign(0.5 * g * inv, x);
+            out[q] = __builtin_fma(r.al * t[q], rcp64(__builtin_fma(t[q], t[q], 1.0)), agd * d);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kPointsPerLane; ++q)
+            out[q] = __builtin_fma(r.al * t[q], rcp64(__builtin_fma(t[q], t[q], 1.0)), agd * dawson_tab(kSqrtLn2 * t[q], tab));
+    }
 }
 
 constexpr double binom_d(int n, int k)
@@ -612,12 +612,19 @@ __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *r
 // instead of accumulating; 2 the imaginary model is the sum over all peaks.
 // The 8-peak group keeps 24 per-peak constants live next to the 8-point register block:
 // ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
-// FIT_IM == 1 evaluates one dispersion line per point in the epilogue with the Dawson coefficients
-// read from LDS (dawson_lds): the direct kernels keep three waves per SIMD (168 / 156 VGPRs, no
-// scratch), the far-field one takes two (215 VGPRs) rather than spilling; FIT_IM == 2 holds eight
-// more accumulators and the far-field sums: two waves.
+// FIT_IM == 1 evaluates the last peak's dispersion line at the chunk's points in the epilogue
+// (dispersion_points, Dawson coefficients from LDS): the direct kernels keep three waves per SIMD, the
+// far-field one takes two rather than spilling; FIT_IM == 2 holds eight more accumulators and the
+// far-field sums: two waves.
+#ifndef NMRFIT_FARFIELD_IM_WAVES
+#define NMRFIT_FARFIELD_IM_WAVES 2
+#endif
+#ifndef NMRFIT_SUM_WAVES
+#define NMRFIT_SUM_WAVES 3     // (round 4: the direct kernels fit in 168 VGPRs with the imaginary sum; 3.5 -> 2.6 ms at C3)
+#endif
 #define NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)                                                                    \
-    (((FIT_IM) == 2 || ((FIT_IM) == 1 && (VARIANT) == NMRFIT_VARIANT_FARFIELD)) ? 2                                                                                                 \
+    (((FIT_IM) != 0 && (VARIANT) == NMRFIT_VARIANT_FARFIELD) ? NMRFIT_FARFIELD_IM_WAVES                               \
+     : ((FIT_IM) == 2) ? NMRFIT_SUM_WAVES                                                                             \
                    : ((VARIANT) == NMRFIT_VARIANT_DEFAULT || (VARIANT) == NMRFIT_VARIANT_NOSKIP ||                     \
                       (VARIANT) == NMRFIT_VARIANT_STAGED || (VARIANT) == NMRFIT_VARIANT_FARFIELD ||                    \
                       (VARIANT) == NMRFIT_VARIANT_NOREC)                                                               \
@@ -687,15 +694,12 @@ __device__ __forceinline__ void objective_body(
     PeakFast *lorf = reinterpret_cast<PeakFast *>(grec_base + (kRec ? (size_t)WPB * P * sizeof(double2) : 0)) +
                      (size_t)slice * P;
 
-    // FIT_IM == 2: Dawson table (16 intervals x 19 coefficients) for the gathered evaluation, one copy
-    // per workgroup; the barrier after the staging below makes it visible
+    // FIT_IM != 0: Dawson table (16 intervals x 19 coefficients for the gathered evaluation, then the 12 of the
+    // asymptotic series), one copy per workgroup; the barrier after the staging below makes it visible
     double *dtab = reinterpret_cast<double *>(lds_raw + aux_off);
-    if constexpr (FIT_IM == 2)
-        for (int i = threadIdx.x; i < 16 * 19; i += WPB * kWave) dtab[i] = (&dawson::kTab[0][0])[i];
-    if constexpr (FIT_IM == 1)   // the coefficient sets of dawson_lds
-        for (int i = threadIdx.x; i < kDawLdsCount; i += WPB * kWave)
-            dtab[i] = (i < kDawLdsFar) ? dawson::kNear[i]
-                                       : (i < kDawLdsMid) ? dawson::kFar[i - kDawLdsFar] : (&dawson::kMid[0][0])[i - kDawLdsMid];
+    if constexpr (FIT_IM != 0)   // kTab[16][19], then kFar[12]
+        for (int i = threadIdx.x; i < kDawTabCount; i += WPB * kWave)
+            dtab[i] = (i < kDawTabFar) ? (&dawson::kTab[0][0])[i] : dawson::kFar[i - kDawTabFar];
     if (clk && g == 0 && lane == 0) {   // nmrfit_prof_*: ticks of the core clock and of the 100 MHz reference
         clk[0] = __builtin_amdgcn_s_memtime();
         clk[1] = __builtin_amdgcn_s_memrealtime();
@@ -1315,6 +1319,11 @@ __device__ __forceinline__ void objective_body(
             }
         }
 
+        if constexpr (FIT_IM == 1) {   // equations.py:197-199: the last peak's line only (before the data loads: 48 VGPRs fewer are live)
+#pragma unroll
+            for (int q = 0; q < kPointsPerLane; ++q) iacc[q] = 0.0;
+            if (P > 0) dispersion_points(wv, lor[P - 1], dtab, iacc);
+        }
         // keep the u/v/weights loads below the peak loop: hoisted, they would hold 48 VGPRs
         // across it
         asm volatile("" ::: "memory");
@@ -1393,13 +1402,7 @@ __device__ __forceinline__ void objective_body(
             bs = __builtin_fma(e, e, bs);
             if (FIT_IM != 0) {                                            // equations.py:197-199,205-206
                 const double id = __builtin_fma(zr, vq[q], zi * uq[q]);  // Im((zr + i zi)(u + i v))
-                double ifit = 0.0;
-                if constexpr (FIT_IM == 1) {
-                    if (P > 0) ifit = dispersion_lds(wv[q], lor[P - 1], dtab);
-                } else {
-                    ifit = iacc[q];
-                }
-                const double ei = tq[q] * (id - ifit);
+                const double ei = tq[q] * (id - iacc[q]);
                 bs_im = __builtin_fma(ei, ei, bs_im);
             }
             if (WRITE_R && (full || jl + q * kWave < j1)) R_out[particle * N + jl + q * kWave] = e;
@@ -1725,8 +1728,8 @@ static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, i
     // the all-peak imaginary model sums far peaks through the far-field scratch and evaluates Dawson's
     // integral from a table in LDS
     const size_t lds_im = (fit_im == 2) ? lds_far : 0;
-    // (fit_im == 1: the 141 coefficients of dawson_lds in the same area)
-    const size_t lds_tab = (fit_im != 0) ? 16 * 19 * sizeof(double) + 16 : 0;
+    // (fit_im == 1 reads the same table: gathered intervals near the last peak, the asymptotic series elsewhere)
+    const size_t lds_tab = (fit_im != 0) ? (size_t)kDawTabCount * sizeof(double) + 16 : 0;
     int variant = ctx->variant;
     // the imaginary channel exists in DEFAULT, NOREC and FARFIELD; the A/B variants fail in launch_variant
     if (variant == NMRFIT_VARIANT_STAGED && fit_im != 0) variant = NMRFIT_VARIANT_DEFAULT;

@@ -52,7 +52,7 @@ def compute_weights(w, peaks, expon=0.5):
     return equations.laplace1d(weights)
 
 
-def default_variant(N, P):
+def default_variant(N, P, fit_im=False):
     """Kernel variant ``fit`` uses when options['variant'] is absent: the far-field form
     (distant peaks' Lorentzian tails through one shared expansion per 512-point chunk, values
     within 1e-14 of the direct kernel's) once there is enough grid x peaks for it to pay, the
@@ -73,7 +73,13 @@ def default_variant(N, P):
     between 1e5 and 2e5).  The whole GPU test suite passes with either as the default of every
     context (NMRFIT_DEFAULT_VARIANT), and tests/test_gpu_parity.py::test_farfield_adversarial_spectra
     covers the spectra where no peak is far.  bench.py's headline is always measured on the direct
-    kernel; its `fit_default` entry reports this one."""
+    kernel; its `fit_default` entry reports this one.
+
+    ``fit_im="sum"`` (every peak's imaginary line) always takes the direct kernel: with the imaginary
+    sums the far-field kernel needs more registers than three waves per SIMD leave (two waves: 3.18 ms
+    at 4096 x 65536 x 24 against the direct kernel's 2.57 ms at three; profiles/r04/fit_im_timing.txt)."""
+    if equations.fit_im_mode(fit_im) == _cabi.FIT_IM_SUM:
+        return "default"
     return "farfield" if int(N) * int(P) >= 100000 else "default"
 
 
@@ -186,7 +192,7 @@ class FitUtility:
             ev.set_fit_im(self.fit_im)     # True: the reference's imaginary term (equations.py:197-209)
             # kernel variant: by name or number, default by problem size (default_variant above)
             n_peaks = (len(self.lower) - 4) // 3
-            ev.set_variant(_cabi.variant_id(opt.get('variant', default_variant(len(self.data.w), n_peaks))))
+            ev.set_variant(_cabi.variant_id(opt.get('variant', default_variant(len(self.data.w), n_peaks, self.fit_im))))
             if exchange is None or (exchange.world == 1 and not isinstance(exchange, pso.RcclExchange)):
                 xopt, fopt = pso.pso(ev, self.lower, self.upper, swarmsize=swarmsize, maxiter=maxiter, seed=seed,
                                      check_every=opt.get('check_every', 64), verbose=True, **kw)

@@ -88,6 +88,8 @@ def test_default_variant_rule():
     assert utils.default_variant(4096, 6) == "default"           # the reference's default-size fits
     assert utils.default_variant(16384, 12) == "farfield"
     assert utils.default_variant(65536, 24) == "farfield"
+    assert utils.default_variant(65536, 24, fit_im=True) == "farfield"      # the reference's fit_im=True
+    assert utils.default_variant(65536, 24, fit_im="sum") == "default"      # every peak's imaginary line: the direct kernel
 
 
 def test_fit_device_follows_local_rank(monkeypatch):

@@ -12,6 +12,7 @@ if len(sys.argv) > 1:      # another build of the library (A/B): tools/fit_im_ti
     import ctypes
     L = ctypes.CDLL(os.path.abspath(sys.argv[1]))
     for name, argtypes in _cabi.SIGNATURES.items():
+        if not hasattr(L, name): continue      # (an older build of the library: entry points added since)
         fn = getattr(L, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
     L.nmrfit_last_error.argtypes = []; L.nmrfit_last_error.restype = ctypes.c_char_p
     _cabi._LIB = L

@@ -66,8 +66,8 @@ SIMDS = 1024                   # 256 CUs x 4 SIMDs
 PEAK_CLOCK_MHZ = 2400.0        # MI355X_MICROARCH.md
 LAUNCHER_GRACE_S = 15.0        # self-launcher: how much later than the ranks' own watchdogs its deadline falls
 FP64_ISSUE_CYCLES = 4.0        # one wave64 fp64 VALU instruction occupies a SIMD's issue port for 4 cycles
-PMC_SUMMARIES = [os.path.join("profiles", r, "bench_c3_pmc_summary.json") for r in ("r03", "r02", "r01")]
-FARFIELD_PMC_SUMMARIES = [os.path.join("profiles", "r03", "farfield_c3_pmc_summary.json")]
+PMC_SUMMARIES = [os.path.join("profiles", r, "bench_c3_pmc_summary.json") for r in ("r04", "r03", "r02", "r01")]
+FARFIELD_PMC_SUMMARIES = [os.path.join("profiles", r, "farfield_c3_pmc_summary.json") for r in ("r04", "r03")]
 
 
 def parse():
@@ -612,7 +612,9 @@ def main():
     # 8(d) prescribes as much as of the kernel, so the other end of the range is reported beside it -- never `value`
     dense = None
     try:
-        if rank == 0 and args.variant == 0 and not args.no_extras:
+        if rank == 0 and args.variant == 0 and not args.no_extras and args.other_configs:
+            # (--no-other-configs, i.e. profiled runs: every launch of the headline kernel then has the workload's
+            # own spectrum, and the profiler's average duration of that kernel is roofline.kernel_ms)
             Xd = synth.make_dense_swarm(S_local, P, seed=5, w_lo=float(spec["w"].min()), w_hi=float(spec["w"].max()))
             ev.upload(d_x, Xd)
             dense = {"spectrum": "broad overlapping lines (synth.make_dense_swarm: widths 0.3-0.8 of the span), same "

@@ -86,9 +86,13 @@ constexpr bool kOneWorkgroupParticle = false;
 constexpr bool kOneWorkgroupParticle = true;
 #endif
 constexpr int kFarTerms = 16;      // Taylor terms of the far-field expansion (rho <= 0.1 -> 1e-16)
-constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coefficient scratch in LDS:
-                                   // lane l sits at column l + l/16, which makes the transposed
-                                   // quarter-row reads below bank-conflict free
+constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coefficient scratch in LDS: lane l writes column
+                                   // l + l/16 of 16 rows, then reads 16 consecutive doubles of row l/4 from column 17*(l%4) --
+                                   // for ds_read_b64 / ds_read2_b64 (32- and 16-lane groups) every lane of a group then hits
+                                   // its own bank.  SQ_LDS_BANK_CONFLICT of the far-field kernel is 3.2e6 cycles per C3 launch
+                                   // (DEFAULT: 5e4) all the same: 12 cycles per chunk PAIR, from the per-lane reads of the
+                                   // 32-byte peak records (lanes i and i + 8 of a ds_read_b128 group share banks) -- 0.3 % of a
+                                   // pair's ~4500 cycles, not worth a padded record (profiles/r04/farfield_c3_pmc_summary.json)
 constexpr size_t kSharedPrologueBytes = ((2 + 2 * kWave) * sizeof(double) + 16 * sizeof(int) + 15) & ~(size_t)15;
 constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
 
@@ -1129,7 +1133,7 @@ __device__ __forceinline__ void objective_body(
                         }
                         wave_lds_fence();   // same-wave LDS write -> read
                         // lane l sums order l>>2 over 16 peaks of this pass (quarters padded to
-                        // 17: conflict-free reads), then the quad combines
+                        // 17: each lane of a read group its own bank), then the quad combines
                         double part = 0.0;
                         const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
 #pragma unroll
@@ -1783,7 +1787,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         while (nseg > 1 && n_chunks / nseg < 2 && S * ((nseg + 1) / 2) >= 2 * simds) nseg = (nseg + 1) / 2;
         // a small swarm whose waves just miss fitting on the chip at once (three per SIMD) while half
         // as many would leave it well filled: take the half (204 x 16384 x 12: 16 segments 30.4 us per
-        // generation, 8 segments 28.5; tools/nseg_generation_ab.py)
+        // generation, 8 segments 28.5; tools/archive/nseg_generation_ab.py)
         if (nseg > 1 && S * nseg > 3 * simds && S * (nseg / 2) < 2 * simds && n_chunks / nseg <= 2) nseg /= 2;
     }
     int64_t seg_len = ((n_blocks + nseg - 1) / nseg) * blk_len;

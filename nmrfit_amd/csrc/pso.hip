@@ -268,7 +268,7 @@ constexpr int kSelectMaxPosts = 65536;    // posts buffer; larger swarms: the wo
 //           themselves), each group of stores completed with s_waitcnt vmcnt(0) before the next is
 //           issued (value before tag/ticket); the reader uses agent-scope atomic loads.  No release
 //           fence -- on this part a fence is an L2 write-back, and the fences of one launch's
-//           workgroups serialise (tools/barrier_probe.hip: 8.0 us per exchange at 51 workgroups
+//           workgroups serialise (tools/archive/barrier_probe.hip: 8.0 us per exchange at 51 workgroups
 //           against 2.1).  Compiler ordering is pinned on both sides (the asm carries a memory
 //           clobber; __atomic_signal_fence around the ticket); the hardware ordering rests on
 //           measured gfx950 behaviour and is what tools/handover_stress.py is for.
@@ -285,7 +285,7 @@ constexpr int kSelectMaxPosts = 65536;    // posts buffer; larger swarms: the wo
 // they were stored with agent-scope atomic stores (write-through) and are read the same way, which
 // is coherent across the 8 XCDs without any fence.  A release fence per workgroup is an L2
 // write-back on this part: 8 us per 51-workgroup launch against 1.8 us this way
-// (tools/barrier_probe.hip).
+// (tools/archive/barrier_probe.hip).
 template <bool SHARED>
 __device__ __forceinline__ double load_f64(const double *p)
 {

@@ -57,7 +57,7 @@ def default_variant(N, P, fit_im=False):
     (distant peaks' Lorentzian tails through one shared expansion per 512-point chunk, values
     within 1e-14 of the direct kernel's) once there is enough grid x peaks for it to pay, the
     direct kernel below that.  The threshold was re-measured in round 3 at 204, 1024 and 4096
-    particles (tools/variant_threshold.py, per-generation time of the swarm loop, far-field /
+    particles (tools/archive/variant_threshold.py, per-generation time of the swarm loop, far-field /
     direct; profiles/r03/variant_threshold.txt):
 
         grid x peaks      204      1024     4096 particles

@@ -4,7 +4,7 @@ tests off), interleaved in ONE process on ONE device, several rounds, all values
     python tools/gen_ab.py nmrfit_amd/lib/libab_base.so nmrfit_amd/lib/libnmrfit_amd.so [--shapes "204,4096,6;1024,4096,6"]
 Also checks that the builds end on the same global best, bit for bit."""
 import argparse, ctypes, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nmrfit_amd import _cabi, synth, pso
 from nmrfit_amd.equations import Evaluator
 

@@ -10,7 +10,7 @@ P is an argument (default 8), so that python3 is the program directly after `--`
 never go through `env VAR=... python3` (the profiler's preload has initialised the GPU, and
 replacing such a process is refused on this pool)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from nmrfit_amd import synth
 from nmrfit_amd.equations import Evaluator

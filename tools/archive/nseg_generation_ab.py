@@ -2,7 +2,7 @@
 """Per-generation time of nmrfit_pso_run against the number of segments per particle (forced with
 NMRFIT_TARGET_WAVES, read at context creation), interleaved A/B/A/B in one process on one device."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nmrfit_amd import synth, pso
 from nmrfit_amd.equations import Evaluator
 

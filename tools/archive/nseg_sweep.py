@@ -3,7 +3,7 @@
 particle, forced through NMRFIT_TARGET_WAVES (read at context creation)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nmrfit_amd import synth
 from nmrfit_amd.equations import Evaluator
 

@@ -11,7 +11,7 @@ particle) pair of a shape interleaved in ONE process on ONE device, three rounds
 printed.  Segments are forced with NMRFIT_TARGET_WAVES (read at context creation); "auto" is the
 host heuristic of that build."""
 import ctypes, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nmrfit_amd import _cabi, synth, pso
 from nmrfit_amd.equations import Evaluator
 

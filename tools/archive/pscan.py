@@ -3,7 +3,7 @@
 (phase rotation, residual, loads) from the per-(point, peak) cost.  HIP-event timing of
 objective-only launches on resident inputs."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from nmrfit_amd import synth
 from nmrfit_amd.equations import Evaluator

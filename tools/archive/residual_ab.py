@@ -2,7 +2,7 @@
 """A/B of residual_batch_dev (rows written to HBM) between library builds, C3 size by default:
    python tools/residual_ab.py libA.so libB.so [S N P]"""
 import ctypes, os, statistics, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nmrfit_amd import _cabi, synth
 from nmrfit_amd.equations import Evaluator
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

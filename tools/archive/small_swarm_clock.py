@@ -4,7 +4,7 @@ clock probe (nmrfit_prof_*: s_memtime / s_memrealtime of workgroup 0) during lau
 generations of small swarms, against the C3 shape."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nmrfit_amd import synth, pso
 from nmrfit_amd.equations import Evaluator
 

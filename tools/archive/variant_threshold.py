@@ -6,7 +6,7 @@ Per-generation wall time of nmrfit_pso_run (what fit() runs; stopping tests off)
 the FARFIELD objective kernel, interleaved A/B/A/B in one process on one device, for swarms of 204,
 1024 and 4096 particles over a ladder of grid x peaks products either side of 1e5."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nmrfit_amd import _cabi, pso, synth
 from nmrfit_amd.equations import Evaluator
 from nmrfit_amd.utils import default_variant

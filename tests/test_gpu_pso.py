@@ -215,6 +215,19 @@ def test_native_rccl_single_rank(problem):
                         options={"swarmsize": 100, "maxiter": 40, "seed": 5})
     np.testing.assert_array_equal(r1.params, r2.params)
     assert r1.error == r2.error
+    # a READY RcclExchange as options['exchange'] (it used to fail in nmrfit_pso_set_comm, because fit()
+    # works on its own context and a communicator belongs to the context it was made on): fit() makes its own
+    # communicator over the exchange's channel, on the exchange's device; the caller's exchange stays usable
+    ex2 = pso.RcclExchange(ev)
+    r3 = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False,
+                        options={"swarmsize": 100, "maxiter": 40, "seed": 5, "exchange": ex2})
+    np.testing.assert_array_equal(r3.params, r2.params)
+    assert r3.error == r2.error and r3._device() == ev.device
+    ex2.barrier()
+    ex2.close()
+    with pytest.raises(ValueError, match="has been closed"):
+        nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False,
+                       options={"swarmsize": 100, "maxiter": 4, "seed": 5, "exchange": ex2})
 
 
 def test_no_torch_in_the_product_path():

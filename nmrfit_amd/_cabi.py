@@ -91,6 +91,8 @@ SIGNATURES = {
     "nmrfit_pso_run": [_VP, _I64, _I32],
     "nmrfit_pso_set_handover": [_VP, _INT],
     "nmrfit_pso_set_fused_pbest": [_VP, _INT],
+    "nmrfit_pso_set_fused_tail": [_VP, _INT],
+    "nmrfit_pso_last_launches": [_VP, ctypes.POINTER(_I32)],
     "nmrfit_pso_get_state": [_VP, _VP, _VP, _VP, _VP, _VP],
     "nmrfit_device_pci_bus_id": [_INT, ctypes.c_char_p, _INT],
     "nmrfit_comm_available": [],

@@ -120,7 +120,8 @@ struct ObjectiveDeferred {
     const double *partial = nullptr;   // [S * n_blocks] (x2 with fit_im)
     int64_t n_blocks = 0;
     int fit_im = 0;
-    bool pbest_done = false;           // the launch also updated the personal bests (PsoFused::pbest_*)
+    bool pbest_done = false;           // the launch also updated the personal bests (PsoFused::pbest)
+    bool tail_done = false;            // ... and finished the generation: candidate record and fold (PsoFused::tail)
 };
 // Enqueue the objective (R_out == nullptr) or residual launch on ctx->stream.
 // `fused` (swarm generations, pso.hip): advance every particle by the swarm's update rule in the

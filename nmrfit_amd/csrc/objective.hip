@@ -806,7 +806,12 @@ __device__ __forceinline__ void objective_body(
             }
             xrow[d] = xn;
             if (active && seg == 0) {
-                upd.x_out[idx] = xn;
+                if (upd.tail != 0u && particle == 0) {
+                    // one-launch generations: the finishing workgroup may hand out x[0] (no finite objective yet)
+                    __hip_atomic_store(upd.x_out + idx, xn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    upd.x_out[idx] = xn;
+                }
                 upd.v_out[idx] = vn;
             }
         }
@@ -1491,10 +1496,60 @@ __device__ __forceinline__ void objective_body(
                 double *pb = reinterpret_cast<double *>((uintptr_t)__double_as_longlong(wsums[2 * kMaxBlocks + 2]));
                 double *fpb = pb + __double_as_longlong(wsums[2 * kMaxBlocks + 3]) * D2;
                 const double *row = reinterpret_cast<const double *>(lds_raw + (unsigned)__double_as_longlong(wsums[2 * kMaxBlocks + 4]));
-                if (f < fpb[part]) {
-                    for (int64_t d = threadIdx.x & (kWave - 1); d < D2; d += kWave) pb[part * D2 + d] = row[d];
-                    if ((threadIdx.x & (kWave - 1)) == 0) fpb[part] = f;
+                const int ln = threadIdx.x & (kWave - 1);
+                if (upd.tail == 0u) {
+                    if (f < fpb[part]) {
+                        for (int64_t d = ln; d < D2; d += kWave) pb[part * D2 + d] = row[d];
+                        if (ln == 0) fpb[part] = f;
+                    }
+                    return;
                 }
+                // ---- one-launch generation (single rank, <= kFusedTailMaxS particles): hand-over to the workgroup that
+                // finishes.  Rows and values other workgroups may read go out as write-through agent-scope stores and
+                // are COMPLETE (s_waitcnt vmcnt(0)) before this wave draws its ticket: pso_select_kernel's protocol.
+                if (f < fpb[part]) {
+                    for (int64_t d = ln; d < D2; d += kWave)
+                        __hip_atomic_store(pb + part * D2 + d, row[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ln == 0) __hip_atomic_store(fpb + part, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                global_stores_done();
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                unsigned drawn = 0u;
+                if (ln == 0) drawn = __hip_atomic_fetch_add(upd.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                drawn = (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
+                if (drawn != gridDim.x - 1u) return;
+                // every other particle's stores had completed before its ticket was drawn
+                if (ln == 0) __hip_atomic_store(upd.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+                const int64_t Sn = __double_as_longlong(wsums[2 * kMaxBlocks + 3]);
+                double best = INFINITY;
+                long long bi = 0x7fffffffffffffffLL;
+                for (int64_t i = ln; i < Sn; i += kWave) {      // first index of the minimum, like np.argmin
+                    const double v = __hip_atomic_load(fpb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v < best) {
+                        best = v;
+                        bi = i;
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double ob = __shfl_down(best, off, kWave);
+                    const long long oi = __shfl_down(bi, off, kWave);
+                    if (lex_less(ob, oi, best, bi)) {
+                        best = ob;
+                        bi = oi;
+                    }
+                }
+                best = __shfl(best, 0, kWave);
+                bi = __shfl(bi, 0, kWave);
+                if (bi >= Sn) bi = 0;   // every fp is +inf: np.argmin -> 0, and the record carries x[0] (pso.hip, argmin_block)
+                const double *src = (best < INFINITY) ? pb + bi * D2 : upd.x_out;
+                if (ln == 0) upd.cand[0] = best;
+                for (int64_t d = ln; d < D2; d += kWave)
+                    upd.cand[1 + d] = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                global_stores_done();   // the record is this wave's own input below
+                apply_wave(ln, D2, 1, 0, upd.minstep, upd.minfunc, upd.cand, const_cast<long long *>(upd.flags),
+                           const_cast<double *>(upd.best));
             }
         }
     };
@@ -1837,7 +1892,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     // segments and the workgroup writes f (block sums through LDS); otherwise per-block sums go to a
     // buffer and finalize_kernel (or the swarm's select kernel) adds them.  Same summation order in all.
     const bool direct_f = (nseg == 1 || (kOneWorkgroupParticle && nseg == wpb));
-    if (!kOneWorkgroupParticle || nseg != wpb) upd.pbest = 0u;   // (only when ONE workgroup holds the whole particle; else the caller's kernel)
+    if (!kOneWorkgroupParticle || nseg != wpb) upd.pbest = 0u;
+    if (upd.pbest == 0u || S > kFusedTailMaxS) upd.tail = 0u;   // (the whole generation in this launch: only on top of the personal bests)   // (only when ONE workgroup holds the whole particle; else the caller's kernel)
     double *out = df;
     if (!direct_f) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));
@@ -1873,6 +1929,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     }
     if (rc != NMRFIT_OK) return rc;
     if (defer) defer->pbest_done = upd.x_in != nullptr && upd.pbest != 0u;
+    if (defer) defer->tail_done = defer->pbest_done && upd.tail != 0u;
     if (!direct_f && defer) {   // the caller's own kernel adds the per-block sums (pso_tail_kernel)
         defer->needed = true;
         defer->partial = ctx->d_partial;

@@ -58,6 +58,8 @@ struct nmrfit_pso {
     unsigned *d_ticket = nullptr;
     int handover = NMRFIT_HANDOVER_FAST;   // nmrfit_pso_set_handover: how the select kernel's workgroups hand over
     bool fused_pbest = true;               // nmrfit_pso_set_fused_pbest: personal bests inside the objective launch
+    bool fused_tail = true;                // ... and the rest of a single-rank generation (NMRFIT_NO_FUSED_TAIL: A/B knob)
+    int last_launches = 0;                 // kernel launches of the last generation's evaluate-and-select (diagnostics)
     nmrfit_comm *comm = nullptr;       // attached communicator (sharded swarm): the exchange runs inside nmrfit_pso_step
     bool initialized = false;    // nmrfit_pso_init has run
     bool seeded = false;         // the generation-0 candidates have been folded into (g, fg)
@@ -565,6 +567,16 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
         // personal bests in the same launch when one workgroup holds a whole particle (the launch decides from
         // its geometry and says so in def.pbest_done); d_fp == d_p + S*D, see nmrfit_pso_create
         if (pso->fused_pbest) f.pbest = 1u;
+        // ... and, single rank with the fence-free hand-over, the rest of the generation too (candidate record + fold
+        // by the workgroup that draws the last ticket): ONE launch per generation
+        if (pso->fused_pbest && pso->fused_tail && (more & kTailApply) && !is_init &&
+            pso->handover == NMRFIT_HANDOVER_FAST) {
+            f.tail = 1u;
+            f.cand = pso->d_cand;
+            f.ticket = pso->d_ticket;
+            f.minstep = pso->prm.minstep;
+            f.minfunc = pso->prm.minfunc;
+        }
         rc = launch_objective(ctx, S, pso->P, pso->d_x2, pso->d_fx, nullptr, &def, &f);
         if (rc != NMRFIT_OK) return rc;
         std::swap(pso->d_x, pso->d_x2);   // d_x / d_v: the state the kernel has just written
@@ -574,6 +586,8 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
         rc = launch_objective(ctx, S, pso->P, pso->d_x, pso->d_fx, nullptr, &def);
         if (rc != NMRFIT_OK) return rc;
     }
+    pso->last_launches = def.tail_done ? 1 : 2;
+    if (def.tail_done) return NMRFIT_OK;   // the objective launch was the whole generation
     if (def.pbest_done) {
         // The particle's whole step (update, evaluate, personal best) happened in the objective launch: what is
         // left is the argmin over fp, the candidate record and -- single rank -- the fold, none of which needs
@@ -598,6 +612,7 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
                        pso->d_part_idx, ticket ? pso->d_ticket : nullptr);
     NMRFIT_HIP(hipGetLastError());
     if (!ticket) {
+        pso->last_launches = 3;
         hipLaunchKernelGGL(pso_select_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, pso->d_part_val,
                            pso->d_part_idx, nb);
         NMRFIT_HIP(hipGetLastError());
@@ -648,6 +663,7 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
     if (const char *e = getenv("NMRFIT_SAFE_HANDOVER"))   // A/B knob: the fenced hand-over as every swarm's default
         if (atoi(e) != 0) pso->handover = NMRFIT_HANDOVER_FENCED;
     if (getenv("NMRFIT_NO_FUSED_PBEST")) pso->fused_pbest = false;   // A/B knob
+    if (getenv("NMRFIT_NO_FUSED_TAIL")) pso->fused_tail = false;     // A/B knob
     const size_t sd = (size_t)std::max<int64_t>(S_local * D, 1) * sizeof(double);
     const size_t s1 = (size_t)std::max<int64_t>(S_local, 1) * sizeof(double);
 #define PSO_HIP(call)                                                   \
@@ -806,6 +822,26 @@ int nmrfit_pso_set_fused_pbest(nmrfit_pso *pso, int enable)
         return NMRFIT_E_INVALID;
     }
     pso->fused_pbest = enable != 0;
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_set_fused_tail(nmrfit_pso *pso, int enable)
+{
+    if (!pso) {
+        set_error("null swarm handle");
+        return NMRFIT_E_INVALID;
+    }
+    pso->fused_tail = enable != 0;
+    return NMRFIT_OK;
+}
+
+int nmrfit_pso_last_launches(const nmrfit_pso *pso, int32_t *launches)
+{
+    if (!pso || !launches) {
+        set_error("null argument");
+        return NMRFIT_E_INVALID;
+    }
+    *launches = pso->last_launches;
     return NMRFIT_OK;
 }
 

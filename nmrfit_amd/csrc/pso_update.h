@@ -85,7 +85,20 @@ struct PsoFused {
     // pointers (the headline kernel has no scalar register to spare): the swarm keeps fp[S] right behind
     // p[S x D] in one allocation, so fp = p + S*D.
     unsigned pbest = 0;                               // 1: do it (sits in the padding after xrow_off)
+    // ... and, single rank, the REST of the generation too (round 4): every workgroup (= particle) draws a ticket
+    // once its personal best is complete in memory; the one that draws the last reads all of fp, writes the
+    // candidate record and folds it with pyswarm's acceptance / stopping rule -- the generation is ONE launch.
+    // Same hand-over as pso_select_kernel's fence-free form (write-through agent-scope stores completed with
+    // s_waitcnt vmcnt(0) before the ticket, agent-scope loads on the reading side).
+    unsigned tail = 0;                                // 1: do it (swarms of up to kFusedTailMaxS particles)
+    double *cand = nullptr;                           // (D+1): candidate record
+    unsigned *ticket = nullptr;
+    double minstep = 0.0, minfunc = 0.0;
 };
+// Up to 256 particles: every workgroup's ticket is one returning atomic on ONE address, and they serialise at a
+// few nanoseconds each (measured per generation, one launch against two: 50 particles 11.7 / 14.7 us, 204: 13.9 /
+// 14.9, 512: 19.0 / 17.2, 1024: 30.2 / 25.5) -- the same limit as pso_select_kernel's last-ticket form.
+constexpr int64_t kFusedTailMaxS = 256;
 
 // Wait until every global store this wave has issued has completed.  For the agent-scope (sc1,
 // write-through) atomic stores used to hand data to other workgroups of a running launch that means:

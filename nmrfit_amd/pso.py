@@ -459,6 +459,18 @@ class DeviceSwarm:
         A/B knob: off restores the separate personal-best / argmin kernel; bit-identical results)."""
         _cabi.check(self._lib.nmrfit_pso_set_fused_pbest(self._h, 1 if enable else 0))
 
+    def set_fused_tail(self, enable=True):
+        """The whole generation in the objective launch (single rank, up to 256 particles, one workgroup per
+        particle, fence-free hand-over): default on; off restores the separate one-workgroup launch for the
+        candidate record and the fold (A/B knob, bit-identical results)."""
+        _cabi.check(self._lib.nmrfit_pso_set_fused_tail(self._h, 1 if enable else 0))
+
+    def last_launches(self):
+        """Kernel launches of the last generation's evaluate-and-select part (1, 2 or 3)."""
+        n = ctypes.c_int32(0)
+        _cabi.check(self._lib.nmrfit_pso_last_launches(self._h, ctypes.byref(n)))
+        return n.value
+
     def candidate_dev(self):
         p = ctypes.c_void_p()
         _cabi.check(self._lib.nmrfit_pso_candidate_dev(self._h, ctypes.byref(p)))

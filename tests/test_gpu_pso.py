@@ -476,8 +476,9 @@ def test_handover_stress_short(S, N, P):
             b.set_handover("two_launch")      # ADVICE r3 -- a driver or toolchain change that broke FAST's ordering
             d.set_fused_pbest(False)          # would show here as a difference between a and d)
             d.set_handover("fenced")
-            for sw in (a, b, c, d):           # c: the defaults (personal bests inside the objective launch where a workgroup is a particle)
+            for sw in (a, b, c, d):           # c: the defaults (where a workgroup is a particle: the whole generation in the objective launch)
                 sw.run(gens, check_every=250)
+            assert c.last_launches() == (1 if S <= 256 else 2) and a.last_launches() == 2
             sa, sb, sc, sd = a.state(), b.state(), c.state(), d.state()
             for k in ("x", "v", "p", "fx", "fp"):
                 np.testing.assert_array_equal(sa[k], sb[k], err_msg="%s (seed %d)" % (k, seed))
@@ -720,3 +721,39 @@ def test_lds_budget_on_both_sides_of_every_threshold(P, fit_im):
             for k in ("x", "fx", "fp"):
                 np.testing.assert_array_equal(st[k], getattr(host, k), err_msg="%s %s" % (variant, k))
             dev.close()
+
+
+@pytest.mark.parametrize("S,N,P,variant", [(50, 4096, 6, "default"), (204, 4096, 6, "default"), (204, 16384, 12, "farfield"),
+                                           (256, 2048, 3, "norec"), (257, 4096, 6, "default"), (1024, 4096, 6, "default")])
+def test_one_launch_generation(S, N, P, variant):
+    """Round 4: a single-rank generation of up to 256 particles is ONE launch where a workgroup is a particle -- the
+    objective kernel updates the position, evaluates, updates the personal best, and the workgroup that draws the
+    last ticket makes the candidate record and folds it with pyswarm's rule (the body of pyswarm.pso's loop,
+    nmrfit/utils.py:176-182).  Bit-identical to the two-launch form and to the numpy mirror, with the stopping rule
+    armed (same stop generation, same returned best) and disarmed; larger swarms keep the separate launch (every
+    workgroup's ticket is a returning atomic on one address: beyond ~256 they cost more than the launch saved)."""
+    from nmrfit_amd import equations
+    sp = synth.make_spectrum(N, P, seed=11)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        ev.set_variant(_cabi.variant_id(variant))
+        for kw, gens in ((dict(minfunc=-1.0, minstep=-1.0), 60), ({}, 400)):
+            host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=41, **kw)
+            xh, fh = pso.run_sharded(host, pso.LocalExchange(), gens)
+            res = {}
+            for fused in (True, False):
+                dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=41, **kw)
+                dev.set_fused_tail(fused)
+                dev.run(gens, check_every=9)
+                assert dev.last_launches() == (1 if (fused and S <= 256) else 2), (S, fused, dev.last_launches())
+                st = dev.state()
+                for k in ("x", "v", "p", "fx", "fp"):
+                    np.testing.assert_array_equal(st[k], getattr(host, k), err_msg="%s fused=%s" % (k, fused))
+                xb, fb = dev.best()
+                np.testing.assert_array_equal(xb, xh)
+                assert fb == fh
+                assert dev.status() == dict(iteration=host.iteration, stop=host.stop, fg=host.fg)
+                np.testing.assert_array_equal(dev.candidate(), host.candidate())
+                res[fused] = dev.status()
+                dev.close()
+            if not kw:
+                assert res[True]["stop"] in (1, 2)          # pyswarm's defaults do stop these searches

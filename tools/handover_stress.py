@@ -34,15 +34,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nmrfit_amd import pso, synth                      # noqa: E402
 from nmrfit_amd.equations import Evaluator             # noqa: E402
 
-SHAPES = {"204": (204, 4096, 6), "256": (256, 4096, 6), "512": (512, 4096, 6), "1024": (1024, 4096, 6)}
+SHAPES = {"204": (204, 4096, 6), "256": (256, 4096, 6), "512": (512, 4096, 6), "1024": (1024, 4096, 6),
+          "50": (50, 4096, 6), "256x2048": (256, 2048, 3), "204x16384": (204, 16384, 12)}
 
 
 def run(ev, sp, S, seed, gens, mode):
     sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
-    # the select kernel must run at every shape here: at four grid segments per particle (512 / 1024 x 4096) the
-    # product default does the personal bests inside the objective launch and hands nothing over at all
-    sw.set_fused_pbest(False)
-    sw.set_handover(mode)
+    if mode == "one_launch":
+        # round 4: the product default for single-rank swarms of up to 256 particles where a workgroup is a particle --
+        # personal best, ticket, candidate record and fold inside the objective launch (--one-launch: this against
+        # TWO_LAUNCH with everything after the objective in kernels of its own)
+        pass
+    else:
+        # the select kernel must run at every shape here: where a workgroup is a particle the product default does the
+        # personal bests (and, small swarms, the whole generation) inside the objective launch
+        sw.set_fused_pbest(False)
+        sw.set_handover(mode)
     sw.init()
     ev.synchronize()
     t0 = time.perf_counter()
@@ -51,6 +58,7 @@ def run(ev, sp, S, seed, gens, mode):
     st = sw.state()
     st["best_x"], st["best_f"] = sw.best()
     st["status"] = sw.status()
+    st["launches"] = sw.last_launches()
     sw.close()
     return st, dt
 
@@ -71,7 +79,10 @@ def main():
     ap.add_argument("--shapes", default="204,256,512,1024")
     ap.add_argument("--fenced-every", type=int, default=25)
     ap.add_argument("--seed0", type=int, default=1000)
+    ap.add_argument("--one-launch", action="store_true", help="mode A = the one-launch generation (product default, "
+                    "<= 256 particles) instead of the select kernel's fence-free hand-over")
     a = ap.parse_args()
+    mode_a = "one_launch" if a.one_launch else "fast"
     total_ex = total_posts = total_bad = 0
     t_start = time.perf_counter()
     for name in a.shapes.split(","):
@@ -85,7 +96,9 @@ def main():
         with Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
             seed = a.seed0
             while ex < a.exchanges:
-                A, ta = run(ev, sp, S, seed, a.gens, "fast")
+                A, ta = run(ev, sp, S, seed, a.gens, mode_a)
+                if a.one_launch:
+                    assert A["launches"] == 1, A["launches"]
                 B, tb = run(ev, sp, S, seed, a.gens, "two_launch")
                 assert A["status"]["iteration"] == a.gens
                 bad = same(A, B)
@@ -108,8 +121,8 @@ def main():
                     print("  ... shape %s: %d exchanges, %d mismatching seeds, %.0f s" % (
                         name, ex, bad_seeds, time.perf_counter() - t_start), flush=True)
         print("shape S=%d N=%d P=%d (%d workgroups): %d exchanges (%d posts) over %d seeds x %d generations, "
-              "FAST vs TWO_LAUNCH mismatching seeds: %d; per generation FAST %.2f us, TWO_LAUNCH %.2f us, "
-              "FENCED %.2f us (%d seeds)" % (S, N, P, wgs, ex, ex * wgs, n_seeds, a.gens, bad_seeds,
+              "A (%s) vs TWO_LAUNCH mismatching seeds: %d; per generation A %.2f us, TWO_LAUNCH %.2f us, "
+              "FENCED %.2f us (%d seeds)" % (S, N, P, wgs, ex, ex * wgs, n_seeds, a.gens, mode_a, bad_seeds,
                                             t_fast / ex * 1e6, t_two / ex * 1e6,
                                             (t_fenced / g_fenced * 1e6) if g_fenced else float("nan"), n_fenced),
               flush=True)

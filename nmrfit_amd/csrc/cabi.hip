@@ -159,10 +159,24 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
         return NMRFIT_E_NO_DEVICE;
     }
     NMRFIT_HIP(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    NMRFIT_HIP(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        set_error(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    // (hipGetDeviceProperties costs about a millisecond: once per device and process -- a default fit is 30 ms)
+    struct DevInfo {
+        bool known = false;
+        int cus = 0;
+        char arch[64] = {0};
+    };
+    static thread_local std::vector<DevInfo> dev_cache;
+    if ((int)dev_cache.size() <= device) dev_cache.resize((size_t)device + 1);
+    if (!dev_cache[(size_t)device].known) {
+        hipDeviceProp_t prop;
+        NMRFIT_HIP(hipGetDeviceProperties(&prop, device));
+        dev_cache[(size_t)device].cus = prop.multiProcessorCount;
+        strncpy(dev_cache[(size_t)device].arch, prop.gcnArchName, sizeof(dev_cache[0].arch) - 1);
+        dev_cache[(size_t)device].known = true;
+    }
+    const DevInfo &prop = dev_cache[(size_t)device];
+    if (strncmp(prop.arch, "gfx950", 6) != 0) {
+        set_error(std::string("device is ") + prop.arch + ", this library is built for gfx950 only");
         return NMRFIT_E_NO_DEVICE;
     }
     nmrfit_ctx *ctx = new (std::nothrow) nmrfit_ctx();
@@ -171,7 +185,7 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
         return NMRFIT_E_INVALID;
     }
     ctx->device = device;
-    ctx->compute_units = prop.multiProcessorCount;
+    ctx->compute_units = prop.cus;
     ctx->N = N;
     ctx->n_chunks = (N + kChunk - 1) / kChunk;
     if (const char *tw = getenv("NMRFIT_TARGET_WAVES")) ctx->target_waves = atoll(tw);   // tuning knob
@@ -202,7 +216,6 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
         hipError_t _e = (call);                                                    \
         if (_e != hipSuccess) {                                                    \
             int _rc = hip_fail(_e, #call, __FILE__, __LINE__);                     \
-            if (d_w_raw) (void)hipFree(d_w_raw);                                   \
             nmrfit_ctx_destroy(ctx);                                               \
             return _rc;                                                            \
         }                                                                          \
@@ -211,14 +224,21 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
     ctx->stream = ctx->own_stream;
     CTX_HIP(hipEventCreate(&ctx->ev0));
     CTX_HIP(hipEventCreate(&ctx->ev1));
-    double **grid_arrays[] = {&ctx->d_wc, &ctx->d_u, &ctx->d_v, &ctx->d_wt};
-    for (double **a : grid_arrays) {
-        CTX_HIP(hipMalloc((void **)a, padded));
-        CTX_HIP(hipMemsetAsync(*a, 0, padded, ctx->stream));
+    // ONE allocation for the four padded grid arrays, the chunk table and the landing buffer (which first holds the raw w)
+    const size_t chunk_bytes = ((size_t)ctx->n_chunks * sizeof(double2) + 255) & ~(size_t)255;
+    const size_t padded_al = (padded + 255) & ~(size_t)255;
+    CTX_HIP(hipMalloc((void **)&ctx->d_block, 4 * padded_al + chunk_bytes + bytes));
+    CTX_HIP(hipMemsetAsync(ctx->d_block, 0, 4 * padded_al, ctx->stream));
+    {
+        unsigned char *base = reinterpret_cast<unsigned char *>(ctx->d_block);
+        ctx->d_wc = reinterpret_cast<double *>(base);
+        ctx->d_u = reinterpret_cast<double *>(base + padded_al);
+        ctx->d_v = reinterpret_cast<double *>(base + 2 * padded_al);
+        ctx->d_wt = reinterpret_cast<double *>(base + 3 * padded_al);
+        ctx->d_chunk = reinterpret_cast<double2 *>(base + 4 * padded_al);
+        ctx->d_stage = reinterpret_cast<double *>(base + 4 * padded_al + chunk_bytes);
     }
-    CTX_HIP(hipMalloc((void **)&ctx->d_chunk, (size_t)ctx->n_chunks * sizeof(double2)));
-    CTX_HIP(hipMalloc((void **)&ctx->d_stage, bytes));
-    CTX_HIP(hipMalloc((void **)&d_w_raw, bytes));
+    d_w_raw = ctx->d_stage;
     CTX_HIP(hipMemcpyAsync(d_w_raw, w, bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = prepare_grid(ctx, d_w_raw);
     // u, v, weights: land in plain order, then into the pair-interleaved order the kernels read (nmrfit_internal.h,
@@ -230,13 +250,10 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
         rc = scatter_grid(ctx, ctx->d_stage, dev_arrays[a]);
     }
     if (rc != NMRFIT_OK) {
-        (void)hipFree(d_w_raw);
         nmrfit_ctx_destroy(ctx);
         return rc;
     }
     CTX_HIP(hipStreamSynchronize(ctx->stream));
-    CTX_HIP(hipFree(d_w_raw));
-    d_w_raw = nullptr;
 #undef CTX_HIP
     *out = ctx;
     return NMRFIT_OK;
@@ -247,7 +264,7 @@ int nmrfit_ctx_destroy(nmrfit_ctx *ctx)
     if (!ctx) return NMRFIT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
-    void *bufs[] = {ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, ctx->d_stage, ctx->d_X, ctx->d_f, ctx->d_partial, ctx->d_R};
+    void *bufs[] = {ctx->d_block /* wc, u, v, weights, chunk table, landing buffer */, ctx->d_X, ctx->d_f, ctx->d_partial, ctx->d_R};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -87,6 +87,7 @@ struct nmrfit_ctx {
     double grid_dev = 0.0;       // bound on |(w[j+k] - w[j]) - k*spacing| over the grid (Gaussian recurrence)
     int64_t target_waves = 0;    // launch-geometry override (0 = heuristic)
     bool wide_workgroups = true; // eight-wave workgroups for particles cut into eight segments (NMRFIT_NO_WIDE_WORKGROUPS: A/B knob)
+    void *d_block = nullptr;     // the one allocation behind d_wc, d_u, d_v, d_wt, d_chunk, d_stage
     double *d_wc = nullptr;      // centred grid
     double *d_u = nullptr, *d_v = nullptr, *d_wt = nullptr;
     double2 *d_chunk = nullptr;  // per 512-point chunk: (min, max) of the centred grid

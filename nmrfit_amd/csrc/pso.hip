@@ -44,6 +44,7 @@ struct nmrfit_pso {
     int32_t P = 0;
     int64_t D = 0;
     nmrfit_pso_params prm{};
+    void *d_block = nullptr;           // the one allocation behind every pointer below
     double *d_lb = nullptr, *d_ub = nullptr;
     double *d_x = nullptr, *d_v = nullptr, *d_p = nullptr;
     double *d_x2 = nullptr, *d_v2 = nullptr;   // the other half of the x / v ping-pong (fused update: the objective
@@ -675,27 +676,41 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
             return _rc;                                                 \
         }                                                               \
     } while (0)
-    PSO_HIP(hipMalloc((void **)&pso->d_lb, (size_t)D * sizeof(double)));
-    PSO_HIP(hipMalloc((void **)&pso->d_ub, (size_t)D * sizeof(double)));
-    PSO_HIP(hipMalloc((void **)&pso->d_x, sd));
-    PSO_HIP(hipMalloc((void **)&pso->d_v, sd));
-    PSO_HIP(hipMalloc((void **)&pso->d_x2, sd));
-    PSO_HIP(hipMalloc((void **)&pso->d_v2, sd));
-    // personal bests and their values in ONE allocation, fp[S] right behind p[S x D]: the objective kernel's
-    // fused personal-best step finds fp from p without another pointer argument (objective.hip)
-    PSO_HIP(hipMalloc((void **)&pso->d_p, (size_t)std::max<int64_t>(S_local * D, 0) * sizeof(double) + s1));
-    pso->d_fp = pso->d_p + S_local * D;
-    PSO_HIP(hipMalloc((void **)&pso->d_fx, s1));
-    PSO_HIP(hipMalloc((void **)&pso->d_cand_own, (size_t)(D + 1) * sizeof(double)));
-    pso->d_cand = pso->d_cand_own;
-    PSO_HIP(hipMalloc((void **)&pso->d_flags, 2 * sizeof(long long)));
-    PSO_HIP(hipMalloc((void **)&pso->d_best, (size_t)(2 + 2 * D) * sizeof(double)));
+    // ONE allocation for the whole swarm state (every hipMalloc / hipFree is a synchronising call; a default fit
+    // is 30 ms).  Layout: 256-byte aligned pieces; fp[S] right behind p[S x D] (the objective kernel's fused
+    // personal-best step finds fp from p without another pointer argument, objective.hip).
     {
-        const size_t nb = (size_t)kSelectMaxPosts;
-        PSO_HIP(hipMalloc((void **)&pso->d_part_val, nb * sizeof(double)));
-        PSO_HIP(hipMalloc((void **)&pso->d_part_idx, nb * sizeof(long long)));
-        PSO_HIP(hipMalloc((void **)&pso->d_ticket, sizeof(unsigned)));
-        PSO_HIP(hipMemsetAsync(pso->d_part_idx, 0, nb * sizeof(long long), ctx->stream));
+        const size_t nposts = (size_t)kSelectMaxPosts;
+        const size_t sizes[] = {(size_t)D * sizeof(double), (size_t)D * sizeof(double), sd, sd, sd, sd,
+                                (size_t)std::max<int64_t>(S_local * D, 0) * sizeof(double) + s1, s1,
+                                (size_t)(D + 1) * sizeof(double), 2 * sizeof(long long), (size_t)(2 + 2 * D) * sizeof(double),
+                                nposts * sizeof(double), nposts * sizeof(long long), 256};
+        size_t off[sizeof(sizes) / sizeof(sizes[0])], total = 0;
+        for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
+            off[i] = total;
+            total += (sizes[i] + 255) & ~(size_t)255;
+        }
+        PSO_HIP(hipMalloc(&pso->d_block, total));
+        unsigned char *base = reinterpret_cast<unsigned char *>(pso->d_block);
+        pso->d_lb = reinterpret_cast<double *>(base + off[0]);
+        pso->d_ub = reinterpret_cast<double *>(base + off[1]);
+        pso->d_x = reinterpret_cast<double *>(base + off[2]);
+        pso->d_v = reinterpret_cast<double *>(base + off[3]);
+        pso->d_x2 = reinterpret_cast<double *>(base + off[4]);
+        pso->d_v2 = reinterpret_cast<double *>(base + off[5]);
+        pso->d_p = reinterpret_cast<double *>(base + off[6]);
+        pso->d_fp = pso->d_p + S_local * D;
+        pso->d_fx = reinterpret_cast<double *>(base + off[7]);
+        pso->d_cand_own = reinterpret_cast<double *>(base + off[8]);
+        pso->d_cand = pso->d_cand_own;
+        pso->d_flags = reinterpret_cast<long long *>(base + off[9]);
+        pso->d_best = reinterpret_cast<double *>(base + off[10]);
+        pso->d_part_val = reinterpret_cast<double *>(base + off[11]);
+        pso->d_part_idx = reinterpret_cast<long long *>(base + off[12]);
+        pso->d_ticket = reinterpret_cast<unsigned *>(base + off[13]);
+        // (posts beyond the workgroups a swarm of this size launches are never read)
+        const size_t used_posts = (size_t)std::min<int64_t>((S_local + kSelectWaves - 1) / kSelectWaves + 1, kSelectMaxPosts);
+        PSO_HIP(hipMemsetAsync(pso->d_part_idx, 0, used_posts * sizeof(long long), ctx->stream));
         PSO_HIP(hipMemsetAsync(pso->d_ticket, 0, sizeof(unsigned), ctx->stream));
     }
     PSO_HIP(hipMemcpyAsync(pso->d_lb, lower, (size_t)D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -717,10 +732,7 @@ int nmrfit_pso_destroy(nmrfit_pso *pso)
         (void)hipSetDevice(pso->ctx->device);
         (void)hipStreamSynchronize(pso->ctx->stream);
     }
-    void *bufs[] = {pso->d_lb, pso->d_ub, pso->d_x, pso->d_v, pso->d_x2, pso->d_v2, pso->d_p /* + d_fp */, pso->d_fx, pso->d_cand_own, pso->d_flags, pso->d_best,
-                    pso->d_part_val, pso->d_part_idx, pso->d_ticket};
-    for (void *b : bufs)
-        if (b) (void)hipFree(b);
+    if (pso->d_block) (void)hipFree(pso->d_block);
     delete pso;
     return NMRFIT_OK;
 }

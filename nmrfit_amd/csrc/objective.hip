@@ -624,7 +624,9 @@ __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *r
 #define NMRFIT_FARFIELD_IM_WAVES 2
 #endif
 #ifndef NMRFIT_SUM_WAVES
-#define NMRFIT_SUM_WAVES 3     // (round 4: the direct kernels fit in 168 VGPRs with the imaginary sum; 3.5 -> 2.6 ms at C3)
+#define NMRFIT_SUM_WAVES 2     // launch bound of the direct kernels with the imaginary sum.  Round 4: they fit in 168 VGPRs,
+                               // i.e. run at THREE waves per SIMD (3.5 -> 2.57 ms at C3) -- with the bound left at two: asked
+                               // for three the compiler stops at 160 registers and schedules worse (2.86 ms, measured)
 #endif
 #define NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)                                                                    \
     (((FIT_IM) != 0 && (VARIANT) == NMRFIT_VARIANT_FARFIELD) ? NMRFIT_FARFIELD_IM_WAVES                               \

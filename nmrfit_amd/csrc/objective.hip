@@ -71,6 +71,9 @@ constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 #ifndef NMRFIT_MIN_WAVES
 #define NMRFIT_MIN_WAVES 3
 #endif
+#ifndef NMRFIT_DISP_INTERLEAVE
+#define NMRFIT_DISP_INTERLEAVE 4   // fit_im=True: points of the last peak's dispersion line in flight together
+#endif
 constexpr int kBatchInv = NMRFIT_BATCHINV;
 #ifndef NMRFIT_DIAG_ABLATE
 #define NMRFIT_DIAG_ABLATE 0   // diagnostic builds (wrong values on purpose): 1 no expansions, 2 no near peaks / Gaussians,
@@ -317,6 +320,9 @@ __device__ __forceinline__ void dispersion_points(const double (&wv)[kPointsPerL
             for (int i = 10; i >= 0; --i) g = __builtin_fma(g, s2, cfar[i]);
             const double d = copysign(0.5 * g * inv, x);
             out[q] = __builtin_fma(r.al * t[q], rcp64(__builtin_fma(t[q], t[q], 1.0)), agd * d);
+            // (scheduling fence: 2, 4 or 8 points in flight together time within 0.5 % of each other, and none brings the
+            // far-field kernel under 168 VGPRs -- it is its scalar registers that run out)
+            if ((q + 1) % NMRFIT_DISP_INTERLEAVE == 0) __builtin_amdgcn_sched_barrier(0);
         }
     } else {
 #pragma unroll
@@ -620,6 +626,9 @@ __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *r
 // (dispersion_points, Dawson coefficients from LDS): the direct kernels keep three waves per SIMD, the
 // far-field one takes two rather than spilling; FIT_IM == 2 holds eight more accumulators and the
 // far-field sums: two waves.
+#ifndef NMRFIT_FARFIELD_TRUE_WAVES
+#define NMRFIT_FARFIELD_TRUE_WAVES 2
+#endif
 #ifndef NMRFIT_FARFIELD_IM_WAVES
 #define NMRFIT_FARFIELD_IM_WAVES 2
 #endif
@@ -629,7 +638,8 @@ __device__ __forceinline__ void gauss_add_rec(const PeakLor *r, const double2 *r
                                // for three the compiler stops at 160 registers and schedules worse (2.86 ms, measured)
 #endif
 #define NMRFIT_OBJECTIVE_MIN_WAVES(VARIANT, FIT_IM)                                                                    \
-    (((FIT_IM) != 0 && (VARIANT) == NMRFIT_VARIANT_FARFIELD) ? NMRFIT_FARFIELD_IM_WAVES                               \
+    (((FIT_IM) == 1 && (VARIANT) == NMRFIT_VARIANT_FARFIELD) ? NMRFIT_FARFIELD_TRUE_WAVES                             \
+     : ((FIT_IM) == 2 && (VARIANT) == NMRFIT_VARIANT_FARFIELD) ? NMRFIT_FARFIELD_IM_WAVES                             \
      : ((FIT_IM) == 2) ? NMRFIT_SUM_WAVES                                                                             \
                    : ((VARIANT) == NMRFIT_VARIANT_DEFAULT || (VARIANT) == NMRFIT_VARIANT_NOSKIP ||                     \
                       (VARIANT) == NMRFIT_VARIANT_STAGED || (VARIANT) == NMRFIT_VARIANT_FARFIELD ||                    \
@@ -1331,6 +1341,7 @@ __device__ __forceinline__ void objective_body(
         }
 
         if constexpr (FIT_IM == 1) {   // equations.py:197-199: the last peak's line only (before the data loads: 48 VGPRs fewer are live)
+            __builtin_amdgcn_sched_barrier(0);   // (not interleaved with the far-field Horner above: its coefficients are dead first)
 #pragma unroll
             for (int q = 0; q < kPointsPerLane; ++q) iacc[q] = 0.0;
             if (P > 0) dispersion_points(wv, lor[P - 1], dtab, iacc);

@@ -550,8 +550,13 @@ int nmrfit_prof_enable(nmrfit_ctx *ctx, int64_t capacity)
         return NMRFIT_OK;
     }
     if (!ctx->d_clk) {
-        NMRFIT_HIP(hipMalloc((void **)&ctx->d_clk, 4 * sizeof(unsigned long long)));
-        NMRFIT_HIP(hipMemsetAsync(ctx->d_clk, 0, 4 * sizeof(unsigned long long), ctx->stream));
+#ifdef NMRFIT_DIAG_STAMPS   // diagnostic builds: room for 16 phase stamps of up to 1024 workgroups behind the clock ticks
+        constexpr size_t kClkWords = 4 + 16 * 1024;
+#else
+        constexpr size_t kClkWords = 4;
+#endif
+        NMRFIT_HIP(hipMalloc((void **)&ctx->d_clk, kClkWords * sizeof(unsigned long long)));
+        NMRFIT_HIP(hipMemsetAsync(ctx->d_clk, 0, kClkWords * sizeof(unsigned long long), ctx->stream));
     }
     for (int64_t i = 0; i < capacity; ++i) {
         hipEvent_t a = nullptr, b = nullptr, c = nullptr;
@@ -641,5 +646,16 @@ int nmrfit_last_launch_workgroup(const nmrfit_ctx *ctx, int32_t *waves_per_workg
     if (waves_per_workgroup) *waves_per_workgroup = ctx->last.waves_per_workgroup;
     return NMRFIT_OK;
 }
+
+#ifdef NMRFIT_DIAG_STAMPS
+// diagnostic builds only (not in the header): the phase stamps of the last profiled launch, [workgroup][16]
+int nmrfit_diag_read_stamps(nmrfit_ctx *ctx, unsigned long long *out, int64_t workgroups)
+{
+    if (!ctx || !ctx->d_clk || workgroups > 1024) return NMRFIT_E_INVALID;
+    NMRFIT_HIP(hipStreamSynchronize(ctx->stream));
+    NMRFIT_HIP(hipMemcpy(out, ctx->d_clk + 4, (size_t)workgroups * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return NMRFIT_OK;
+}
+#endif
 
 }  // extern "C"

@@ -75,6 +75,10 @@ constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 #define NMRFIT_DISP_INTERLEAVE 4   // fit_im=True: points of the last peak's dispersion line in flight together
 #endif
 constexpr int kBatchInv = NMRFIT_BATCHINV;
+// objective_kernel's static LDS: block sums (x2 with the imaginary channel); f; then what the end of a fused swarm
+// generation needs, parked by the first instructions of the kernel and by its prologue: [+1] personal bests on,
+// [+2] p, [+3] S, [+4] the row's LDS offset, [+5] this particle's fp, [+6] fg, [+7] completed generations
+constexpr int kWsumsCount = 2 * kMaxBlocks + 8;
 #ifndef NMRFIT_DIAG_ABLATE
 #define NMRFIT_DIAG_ABLATE 0   // diagnostic builds (wrong values on purpose): 1 no expansions, 2 no near peaks / Gaussians,
 #endif                         // 4 no Horner, 8 no epilogue arithmetic -- what each phase of the far-field chunk costs
@@ -198,6 +202,18 @@ __device__ __forceinline__ void wave_lds_fence()
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
+#endif
+}
+
+// Diagnostic builds (-DNMRFIT_DIAG_STAMPS): shader-clock stamps of wave 0 of every workgroup at the phases of a
+// one-launch swarm generation, read back with nmrfit_diag_read_stamps (tools/generation_phases.py).
+__device__ __forceinline__ void phase_stamp(unsigned long long *clk, int i)
+{
+#ifdef NMRFIT_DIAG_STAMPS
+    if (clk && threadIdx.x == 0 && blockIdx.x < 1024) clk[4 + 16 * blockIdx.x + i] = __builtin_amdgcn_s_memtime();
+#else
+    (void)clk;
+    (void)i;
 #endif
 }
 
@@ -716,6 +732,7 @@ __device__ __forceinline__ void objective_body(
     if constexpr (FIT_IM != 0)   // kTab[16][19], then kFar[12]
         for (int i = threadIdx.x; i < kDawTabCount; i += WPB * kWave)
             dtab[i] = (i < kDawTabFar) ? (&dawson::kTab[0][0])[i] : dawson::kFar[i - kDawTabFar];
+    phase_stamp(clk, 0);
     if (clk && g == 0 && lane == 0) {   // nmrfit_prof_*: ticks of the core clock and of the 100 MHz reference
         clk[0] = __builtin_amdgcn_s_memtime();
         clk[1] = __builtin_amdgcn_s_memrealtime();
@@ -810,10 +827,14 @@ __device__ __forceinline__ void objective_body(
         for (int64_t d = lane; d < D; d += kWave) {
             const int64_t idx = particle * D + d;
             double xn = upd.x_in[idx], vn = upd.v_in[idx];
+            const double gd = upd.best[2 + d];
+            // one-launch generations: g (and fg, the generation count) stay in LDS for the fold at the kernel's end --
+            // slice 1 of the row area, free when the workgroup is one particle
+            if (upd.tail != 0u) xrow[D + d] = gd;
             if (!stopped) {
                 double rp, rg;
                 uniform2(upd.seed, gen, (uint32_t)d, (uint64_t)(upd.offset + particle), &rp, &rg);
-                xn = update_value(xn, vn, upd.p[idx], upd.best[2 + d], upd.lb[d], upd.ub[d], rp, rg, upd.omega,
+                xn = update_value(xn, vn, upd.p[idx], gd, upd.lb[d], upd.ub[d], rp, rg, upd.omega,
                                   upd.phip, upd.phig, &vn);
             }
             xrow[d] = xn;
@@ -827,7 +848,12 @@ __device__ __forceinline__ void objective_body(
                 upd.v_out[idx] = vn;
             }
         }
+        if (upd.tail != 0u && wave == 0 && lane == 0) {
+            wsums[2 * kMaxBlocks + 6] = upd.best[0];
+            wsums[2 * kMaxBlocks + 7] = __longlong_as_double(upd.flags[0]);
+        }
         if (stopped) return;   // the same for every wave of the grid
+        phase_stamp(clk, 1);   // position update done
         if (shared) __syncthreads();   // wave 0's row is every wave's input
         wave_lds_fence();   // same-wave LDS write -> read
     }
@@ -867,6 +893,7 @@ __device__ __forceinline__ void objective_body(
         __syncthreads();
     }
     if (!active) return;
+    phase_stamp(clk, 2);   // per-peak constants and phase seeds staged
 
     const int64_t j0 = (int64_t)seg * seg_len;
     const int64_t j1 = (j0 + seg_len < N) ? j0 + seg_len : N;
@@ -1489,6 +1516,7 @@ __device__ __forceinline__ void objective_body(
     else
         chunk_loop(std::false_type{});
 
+    phase_stamp(clk, 3);   // chunk loop done
     if (clk && g == 0 && lane == 0) {
         clk[2] = __builtin_amdgcn_s_memtime();
         clk[3] = __builtin_amdgcn_s_memrealtime();
@@ -1510,8 +1538,9 @@ __device__ __forceinline__ void objective_body(
                 double *fpb = pb + __double_as_longlong(wsums[2 * kMaxBlocks + 3]) * D2;
                 const double *row = reinterpret_cast<const double *>(lds_raw + (unsigned)__double_as_longlong(wsums[2 * kMaxBlocks + 4]));
                 const int ln = threadIdx.x & (kWave - 1);
+                const double fp_old = wsums[2 * kMaxBlocks + 5];   // (requested by the kernel's first instructions)
                 if (upd.tail == 0u) {
-                    if (f < fpb[part]) {
+                    if (f < fp_old) {
                         for (int64_t d = ln; d < D2; d += kWave) pb[part * D2 + d] = row[d];
                         if (ln == 0) fpb[part] = f;
                     }
@@ -1520,29 +1549,39 @@ __device__ __forceinline__ void objective_body(
                 // ---- one-launch generation (single rank, <= kFusedTailMaxS particles): hand-over to the workgroup that
                 // finishes.  Rows and values other workgroups may read go out as write-through agent-scope stores and
                 // are COMPLETE (s_waitcnt vmcnt(0)) before this wave draws its ticket: pso_select_kernel's protocol.
-                if (f < fpb[part]) {
+                if (f < fp_old) {
                     for (int64_t d = ln; d < D2; d += kWave)
                         __hip_atomic_store(pb + part * D2 + d, row[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (ln == 0) __hip_atomic_store(fpb + part, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 global_stores_done();
+                phase_stamp(clk, 5);   // personal best complete in memory
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
                 unsigned drawn = 0u;
                 if (ln == 0) drawn = __hip_atomic_fetch_add(upd.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
                 drawn = (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
+                phase_stamp(clk, 6);   // ticket drawn
                 if (drawn != gridDim.x - 1u) return;
                 // every other particle's stores had completed before its ticket was drawn
                 if (ln == 0) __hip_atomic_store(upd.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
                 const int64_t Sn = __double_as_longlong(wsums[2 * kMaxBlocks + 3]);
                 double best = INFINITY;
                 long long bi = 0x7fffffffffffffffLL;
-                for (int64_t i = ln; i < Sn; i += kWave) {      // first index of the minimum, like np.argmin
-                    const double v = __hip_atomic_load(fpb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v < best) {
-                        best = v;
-                        bi = i;
+                {   // first index of the minimum, like np.argmin; all (<= kFusedTailMaxS / 64) loads of a lane in flight together
+                    constexpr int kPer = (int)(kFusedTailMaxS / kWave);
+                    double v[kPer];
+#pragma unroll
+                    for (int k = 0; k < kPer; ++k) {
+                        const int64_t i = ln + (int64_t)k * kWave;
+                        v[k] = (i < Sn) ? __hip_atomic_load(fpb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFINITY;
                     }
+#pragma unroll
+                    for (int k = 0; k < kPer; ++k)
+                        if (v[k] < best) {
+                            best = v[k];
+                            bi = ln + (long long)k * kWave;
+                        }
                 }
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
@@ -1555,14 +1594,63 @@ __device__ __forceinline__ void objective_body(
                 }
                 best = __shfl(best, 0, kWave);
                 bi = __shfl(bi, 0, kWave);
+                phase_stamp(clk, 7);   // argmin over fp
                 if (bi >= Sn) bi = 0;   // every fp is +inf: np.argmin -> 0, and the record carries x[0] (pso.hip, argmin_block)
                 const double *src = (best < INFINITY) ? pb + bi * D2 : upd.x_out;
+                // The winner's row: to the candidate record (what nmrfit_pso_candidate_dev hands out) and to LDS, next to g
+                // (slice 1 of the row area, parked by the prologue) -- the fold below then needs no further round trip
+                // to memory: same operations in the same order as apply_wave (pso_update.h), same values.
+                double *grow = const_cast<double *>(row) + D2, *crow = const_cast<double *>(row) + 2 * D2;
                 if (ln == 0) upd.cand[0] = best;
-                for (int64_t d = ln; d < D2; d += kWave)
-                    upd.cand[1 + d] = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                global_stores_done();   // the record is this wave's own input below
-                apply_wave(ln, D2, 1, 0, upd.minstep, upd.minfunc, upd.cand, const_cast<long long *>(upd.flags),
-                           const_cast<double *>(upd.best));
+                for (int64_t d = ln; d < D2; d += kWave) {
+                    const double c = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    upd.cand[1 + d] = c;
+                    crow[d] = c;
+                }
+                wave_lds_fence();
+                phase_stamp(clk, 8);   // winner's row loaded
+                {
+#pragma clang fp contract(off)
+                    const double fc = best, fg = wsums[2 * kMaxBlocks + 6];
+                    double *bestw = const_cast<double *>(upd.best);
+                    long long *flagsw = const_cast<long long *>(upd.flags);
+                    double *gout = bestw + 2, *bx = bestw + 2 + D2;
+                    int code = 0;   // 0: not better, 1: stop minfunc, 2: stop minstep, 3: accept
+                    if (fc < fg) {
+                        double acc = 0.0;
+                        for (int64_t d = ln; d < D2; d += kWave) {
+                            const double df = grow[d] - crow[d];
+                            acc += df * df;
+                        }
+                        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+                        acc = __shfl(acc, 0, 64);
+                        const double stepsize = sqrt(acc);
+                        if (fabs(fg - fc) <= upd.minfunc)
+                            code = 1;
+                        else if (stepsize <= upd.minstep)
+                            code = 2;
+                        else
+                            code = 3;
+                    }
+                    if (code == 1 || code == 2) {
+                        for (int64_t d = ln; d < D2; d += kWave) bx[d] = crow[d];
+                        if (ln == 0) {
+                            bestw[1] = fc;
+                            flagsw[1] = code;
+                        }
+                    } else if (code == 3) {
+                        for (int64_t d = ln; d < D2; d += kWave) {
+                            gout[d] = crow[d];
+                            bx[d] = crow[d];
+                        }
+                        if (ln == 0) {
+                            bestw[0] = fc;
+                            bestw[1] = fc;
+                        }
+                    }
+                    if (ln == 0) flagsw[0] = __double_as_longlong(wsums[2 * kMaxBlocks + 7]) + 1;
+                }
+                phase_stamp(clk, 9);   // fold written
             }
         }
     };
@@ -1593,8 +1681,12 @@ __device__ __forceinline__ void objective_body(
             wsums[2 * kMaxBlocks] = f;
         }
         if constexpr (!WRITE_R) {
-            __syncthreads();
-            if ((threadIdx.x >> 6) == 0) personal_best(wsums[2 * kMaxBlocks]);
+            // (wave 0 alone goes on: f travels from its lane 0 through the same LDS word, no second workgroup barrier)
+            if ((threadIdx.x >> 6) == 0) {
+                wave_lds_fence();
+                phase_stamp(clk, 4);   // f known
+                personal_best(wsums[2 * kMaxBlocks]);
+            }
         }
     }
 }
@@ -1610,12 +1702,16 @@ __global__ __launch_bounds__(kWave *WPB, (WPB == kWavesPerBlock) ? NMRFIT_OBJECT
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // block sums (x2 with the imaginary channel); then f; then what the fused personal-best step needs at the very
     // end of the kernel (flag, p, S, the row's LDS offset), parked here by the prologue
-    __shared__ double wsums[2 * kMaxBlocks + 5];
+    __shared__ double wsums[kWsumsCount];
     if (threadIdx.x == 0) {   // first thing in the kernel, while nothing else is live (a barrier follows the staging)
-        wsums[2 * kMaxBlocks + 1] = (!WRITE_R && upd.x_in != nullptr && upd.pbest != 0u) ? 1.0 : 0.0;
+        const bool pbest = !WRITE_R && upd.x_in != nullptr && upd.pbest != 0u;
+        wsums[2 * kMaxBlocks + 1] = pbest ? 1.0 : 0.0;
         wsums[2 * kMaxBlocks + 2] = __longlong_as_double((long long)(uintptr_t)upd.p);
         wsums[2 * kMaxBlocks + 3] = __longlong_as_double((long long)S);
         wsums[2 * kMaxBlocks + 4] = __longlong_as_double((long long)upd.xrow_off);
+        // this particle's personal-best value, requested NOW: a memory round trip off the end of the kernel's
+        // critical path (nobody else writes it in this launch)
+        if (pbest && nseg == WPB) wsums[2 * kMaxBlocks + 5] = upd.p[S * (4 + 3 * (int64_t)P) + blockIdx.x];
     }
 #ifdef NMRFIT_DIAG_REMAP
     // block b, wave w -> particle 4*(b / nseg) + w, segment b % nseg (S a multiple of 4)
@@ -1781,7 +1877,7 @@ int scatter_grid(nmrfit_ctx *ctx, const double *d_src, double *d_dst)
 
 // The kernel variant a launch actually runs (the requested one may not fit in LDS, or may not
 // implement the imaginary part) and the dynamic LDS its per-wave records need.
-constexpr size_t kStaticLds = (2 * kMaxBlocks + 5) * sizeof(double) + 64;   // objective_kernel's own __shared__ (wsums) + alignment slack
+constexpr size_t kStaticLds = (size_t)kWsumsCount * sizeof(double) + 64;   // objective_kernel's own __shared__ (wsums) + alignment slack
 static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, int fit_im, int *variant_out,
                               unsigned *aux_off, int wpb = kWavesPerBlock, bool fused_rows = false)
 {

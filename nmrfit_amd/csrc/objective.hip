@@ -71,6 +71,9 @@ constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 #ifndef NMRFIT_MIN_WAVES
 #define NMRFIT_MIN_WAVES 3
 #endif
+#ifndef NMRFIT_PREFETCH_W
+#define NMRFIT_PREFETCH_W 0   // w of the next chunk requested in the epilogue of the current one: measured +1 % (C3) ... +5 %
+#endif                        // (204 x 4096 x 6) -- 16 register copies per chunk and a fuller epilogue; A/B knob
 #ifndef NMRFIT_DISP_INTERLEAVE
 #define NMRFIT_DISP_INTERLEAVE 4   // fit_im=True: points of the last peak's dispersion line in flight together
 #endif
@@ -700,6 +703,13 @@ __device__ __forceinline__ void objective_body(
     PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)WPB * P * sizeof(PeakLor)) +
                    (size_t)slice * P;
     constexpr bool kStage = (VARIANT == NMRFIT_VARIANT_STAGED);
+    // STAGED (and, as an A/B knob, -DNMRFIT_PREFETCH_W=1 for the selectable kernels): w of the NEXT chunk is requested
+    // in the epilogue of the current one, the first chunk's before the prologue's barrier.  Round 4 measured it on
+    // its own: slower everywhere (+1 % at C3, +5 % on the reference's default swarm)
+    // (not with the imaginary sum: its 16 registers are what keeps that kernel at three waves per SIMD)
+    constexpr bool kPrefW = kStage || (NMRFIT_PREFETCH_W != 0 && FIT_IM != 2 &&
+                                       (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_FARFIELD ||
+                                        VARIANT == NMRFIT_VARIANT_NOREC));
     // per-wave table of block seeds (<= 16 blocks per grid); the shared-prologue area (rotation step,
     // per-lane phase seeds, flags); then (kStage) the per-wave staging area for one chunk of u, v,
     // weights (3 x 512 doubles = 12 KiB)
@@ -741,6 +751,24 @@ __device__ __forceinline__ void objective_body(
     const int64_t particle = active ? g / nseg : 0;
     const int seg = active ? (int)(g % nseg) : 0;
     const int64_t D = 4 + 3 * (int64_t)P;
+    double wnext[kPointsPerLane];
+    if (kPrefW && active) {   // the first chunk's w: on its way while the prologue runs
+        const int64_t ja = (int64_t)seg * seg_len;
+        const int64_t je = (ja + seg_len < N) ? ja + seg_len : N;
+        if (ja + kChunk <= je) {
+            const double2 *wp = reinterpret_cast<const double2 *>(wc + ja) + lane;
+#pragma unroll
+            for (int m = 0; m < kPointsPerLane / 2; ++m) {
+                const double2 d = wp[m * kWave];
+                wnext[2 * m] = d.x;
+                wnext[2 * m + 1] = d.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < kPointsPerLane; ++q)
+                wnext[q] = (ja + lane + q * kWave < je) ? wc[ja + (q >> 1) * (2 * kWave) + 2 * lane + (q & 1)] : 0.0;
+        }
+    }
     double p0, p1, r, yoff;
     // stage this particle's per-peak constants in the wave's LDS slices (x: the particle's row,
     // in global memory or -- fused swarm update -- in this wave's LDS copy)
@@ -934,12 +962,6 @@ __device__ __forceinline__ void objective_body(
 
     unsigned even_near = 0, even_hits = 0;     // FARFIELD, P <= 32: near-peak and Gaussian-window masks of the even ...
     unsigned pend_near = 0, pend_hits = 0;     // ... and of the odd chunk of the current pair (expand_pair)
-    double wnext[kPointsPerLane];
-    if (kStage) {
-#pragma unroll
-        for (int q = 0; q < kPointsPerLane; ++q)
-            wnext[q] = (j0 + lane + q * kWave < j1) ? wc[j0 + (q >> 1) * (2 * kWave) + 2 * lane + (q & 1)] : 0.0;
-    }
 
     // The chunk loop exists twice, once per Lorentzian group form, chosen ONCE per wave: inside one
     // copy the accumulators never meet the other form's registers (a merge of the two forms per
@@ -1033,14 +1055,14 @@ __device__ __forceinline__ void objective_body(
         }
         double wv[kPointsPerLane], acc[kPointsPerLane];
         double uq[kPointsPerLane], vq[kPointsPerLane], tq[kPointsPerLane];
-        if (kStage) {
+        if (kPrefW) {
             // w of this chunk was prefetched into registers during the previous epilogue
 #pragma unroll
             for (int q = 0; q < kPointsPerLane; ++q) {
                 wv[q] = wnext[q];
-                asm volatile("" : "+v"(wv[q]));   // consume the load before any LDS-DMA is in flight
+                if (kStage) asm volatile("" : "+v"(wv[q]));   // consume the load before any LDS-DMA is in flight
             }
-            if (full) {
+            if (kStage && full) {
                 // LDS-DMA: u, v, weights of this chunk -> the wave's staging area, 16 B per lane
                 // per instruction, no VGPRs held; they land while the peak loop runs
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier reads of the area are done
@@ -1376,8 +1398,8 @@ __device__ __forceinline__ void objective_body(
         // keep the u/v/weights loads below the peak loop: hoisted, they would hold 48 VGPRs
         // across it
         asm volatile("" ::: "memory");
-        if (kStage) {
-            if (full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk has landed
+        if (kPrefW) {
+            if (kStage && full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of this chunk has landed
             // prefetch w of the next chunk into registers (the per-peak constants are dead here)
             const int64_t jn = jl + kChunk, jnb = jb + kChunk;
             if (jb + 2 * kChunk <= j1) {

@@ -1493,7 +1493,7 @@ __device__ __forceinline__ void objective_body(
             if (nseg == 1) {
                 ss += cs;
                 ss_im += cs_im;
-            } else if (kOneWorkgroupParticle && nseg == WPB) {   // the four waves of THIS workgroup hold the whole particle: sums meet in LDS
+            } else if (kOneWorkgroupParticle && nseg == WPB) {   // the waves of THIS workgroup (four, or eight) hold the whole particle: sums meet in LDS
                 if (lane == 0) {
                     wsums[blk0 + bidx] = cs;
                     if (FIT_IM != 0) wsums[kMaxBlocks + blk0 + bidx] = cs_im;
@@ -1554,7 +1554,7 @@ __device__ __forceinline__ void objective_body(
                 // headline kernel, which has neither a scalar nor a vector register to spare, into scratch memory.
                 // fp[S] sits right behind p[S x D] (PsoFused).
                 const int64_t D2 = 4 + 3 * (int64_t)P;
-                // (four segments per particle: workgroup = particle -- no need for the prologue's 64-bit division result)
+                // (as many segments as waves per workgroup: workgroup = particle -- no need for the prologue's 64-bit division result)
                 const int64_t part = (int64_t)blockIdx.x;
                 double *pb = reinterpret_cast<double *>((uintptr_t)__double_as_longlong(wsums[2 * kMaxBlocks + 2]));
                 double *fpb = pb + __double_as_longlong(wsums[2 * kMaxBlocks + 3]) * D2;
@@ -1689,7 +1689,7 @@ __device__ __forceinline__ void objective_body(
     if (kOneWorkgroupParticle && nseg == WPB && nseg > 1) {
         // One workgroup = one particle (segment = wave): the block sums are added here, in grid order
         // like finalize_value does -- the same canonical order, bit-identical f -- and the launch needs
-        // neither the partial-sum buffer nor a finalize pass after it.  (All four waves get here: a
+        // neither the partial-sum buffer nor a finalize pass after it.  (All its waves get here: a
         // workgroup is active or inactive as a whole, and a stopped swarm returned before the loop.)
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -2019,12 +2019,12 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         upd.xrow_off = (unsigned)lds;
         lds += (size_t)wpb * (size_t)(4 + 3 * (int64_t)P) * sizeof(double);
     }
-    // nseg == 1: the wave writes f; nseg == 4: the four waves of a workgroup are the particle's four
+    // nseg == 1: the wave writes f; nseg == 4 (or 8, wide form): the waves of a workgroup are the particle's
     // segments and the workgroup writes f (block sums through LDS); otherwise per-block sums go to a
     // buffer and finalize_kernel (or the swarm's select kernel) adds them.  Same summation order in all.
     const bool direct_f = (nseg == 1 || (kOneWorkgroupParticle && nseg == wpb));
-    if (!kOneWorkgroupParticle || nseg != wpb) upd.pbest = 0u;
-    if (upd.pbest == 0u || S > kFusedTailMaxS) upd.tail = 0u;   // (the whole generation in this launch: only on top of the personal bests)   // (only when ONE workgroup holds the whole particle; else the caller's kernel)
+    if (!kOneWorkgroupParticle || nseg != wpb) upd.pbest = 0u;   // (only when ONE workgroup holds the whole particle; else the caller's kernel)
+    if (upd.pbest == 0u || S > kFusedTailMaxS) upd.tail = 0u;    // (the whole generation in this launch: only on top of the personal bests)
     double *out = df;
     if (!direct_f) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));

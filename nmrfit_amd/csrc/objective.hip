@@ -90,6 +90,10 @@ constexpr int kAblate = NMRFIT_DIAG_ABLATE;
 #define NMRFIT_FF_PIPE 0   // FARFIELD, P <= 32: the NEXT pair's expansions started in the odd chunk before it (measured: +2 %; A/B knob)
 #endif
 constexpr bool kFarPipe = NMRFIT_FF_PIPE != 0;
+#ifndef NMRFIT_FF_HORNER_FIRST
+#define NMRFIT_FF_HORNER_FIRST 1   // FARFIELD, P <= 32: the shared polynomial before the near peaks and Gaussians (A/B knob)
+#endif
+constexpr bool kHornerFirst = NMRFIT_FF_HORNER_FIRST != 0;
 #ifdef NMRFIT_DIAG_REMAP
 constexpr bool kOneWorkgroupParticle = false;
 #else
@@ -1122,6 +1126,7 @@ __device__ __forceinline__ void objective_body(
                 const double wcen = wave_uniform(0.5 * (mm.x + mm.y));
                 const double hw = wave_uniform(0.5 * (mm.y - mm.x));
                 double cf[kFarTerms];
+                bool horner_done = false;
                 if (P <= 32 && FIT_IM != 2) {   // (the all-peak imaginary pass below reuses the scratch that parks the odd chunk's sums)
                     // Half a wave of peaks: the even chunks of a segment work out the expansions
                     // of TWO chunks at once -- lanes 0..31 for this chunk, lanes 32..63 for the
@@ -1150,6 +1155,22 @@ __device__ __forceinline__ void objective_body(
                     for (int n = 0; n < kFarTerms; ++n) cf[n] = src[n];
                     }
                     if constexpr ((kAblate & 2) != 0) near_c = hits_c = 0u;
+                    if constexpr (kHornerFirst && (kAblate & 4) == 0) {
+                        // The shared polynomial FIRST, straight into the accumulators (the offset P*yoff rides in its constant
+                        // term): its 16 coefficients are dead before the near peaks and Gaussians need their registers,
+                        // and the accumulators need neither initialising nor a separate add per point.
+                        const double ihw1 = (hw > 0.0) ? rcp64(hw) : 0.0;
+                        const double c0 = cf[0] + base;
+#pragma unroll
+                        for (int q = 0; q < kPointsPerLane; ++q) {
+                            const double uu = (wv[q] - wcen) * ihw1;
+                            double pz = cf[kFarTerms - 1];
+#pragma unroll
+                            for (int n = kFarTerms - 2; n >= 1; --n) pz = __builtin_fma(pz, uu, cf[n]);
+                            acc[q] = __builtin_fma(pz, uu, c0);
+                        }
+                        horner_done = true;
+                    }
                     for (unsigned m = near_c; m; m &= m - 1) lorentz_one(lor + __builtin_ctz(m), wv, acc);
                     if (kRec && full && rec_all) {
                         for (unsigned m = hits_c; m; m &= m - 1) gauss_add_rec(lor + __builtin_ctz(m), grec + __builtin_ctz(m), wv, acc);
@@ -1232,6 +1253,7 @@ __device__ __forceinline__ void objective_body(
                     // the next even chunk with nothing else to issue; the sums over peaks follow in the epilogue.
                     if (P <= 32 && jb + kChunk < j1) expand_pair(jb + kChunk);
                 }
+                if (!horner_done) {
                 const double ihwc = (hw > 0.0) ? rcp64(hw) : 0.0;
                 if constexpr ((kAblate & 4) != 0) {
 #pragma unroll
@@ -1244,6 +1266,7 @@ __device__ __forceinline__ void objective_body(
 #pragma unroll
                     for (int n = kFarTerms - 2; n >= 0; --n) pz = __builtin_fma(pz, uu, cf[n]);
                     acc[q] += pz;
+                }
                 }
                 wave_lds_fence();
             } else

@@ -703,8 +703,11 @@ __device__ __forceinline__ void objective_body(
     const bool shared = (nseg % WPB == 0);
 #endif
     const int slice = shared ? 0 : wave;
+    // (one copy of every per-peak record per workgroup when its waves share a particle, else one per wave: the
+    // dynamic LDS is sized accordingly by resolve_variant -- at C3 that is what lets a fourth workgroup onto a CU)
+    const int nslices = shared ? 1 : WPB;
     PeakLor *lor = reinterpret_cast<PeakLor *>(lds_raw) + (size_t)slice * P;
-    PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)WPB * P * sizeof(PeakLor)) +
+    PeakWin *win = reinterpret_cast<PeakWin *>(lds_raw + (size_t)nslices * P * sizeof(PeakLor)) +
                    (size_t)slice * P;
     constexpr bool kStage = (VARIANT == NMRFIT_VARIANT_STAGED);
     // STAGED (and, as an A/B knob, -DNMRFIT_PREFETCH_W=1 for the selectable kernels): w of the NEXT chunk is requested
@@ -717,7 +720,7 @@ __device__ __forceinline__ void objective_body(
     // per-wave table of block seeds (<= 16 blocks per grid); the shared-prologue area (rotation step,
     // per-lane phase seeds, flags); then (kStage) the per-wave staging area for one chunk of u, v,
     // weights (3 x 512 doubles = 12 KiB)
-    unsigned char *lds_tail = lds_raw + (((size_t)WPB * P * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15);
+    unsigned char *lds_tail = lds_raw + (((size_t)nslices * P * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15);
     double2 *seeds = reinterpret_cast<double2 *>(lds_tail) + (size_t)wave * kMaxBlocks;
     double *shr = reinterpret_cast<double *>(lds_tail + (size_t)WPB * kMaxBlocks * sizeof(double2));   // rho, L_lane[64] re / im
     int *sflag = reinterpret_cast<int *>(shr + 2 + 2 * kWave);                                          // one per wave
@@ -737,7 +740,7 @@ __device__ __forceinline__ void objective_body(
 
     // DEFAULT: scaled Lorentzian constants for the two-operation pair form, after grec
     constexpr bool kFast = (NMRFIT_FASTPAIR != 0) && (VARIANT == NMRFIT_VARIANT_DEFAULT) && (NMRFIT_GROUP == 8);
-    PeakFast *lorf = reinterpret_cast<PeakFast *>(grec_base + (kRec ? (size_t)WPB * P * sizeof(double2) : 0)) +
+    PeakFast *lorf = reinterpret_cast<PeakFast *>(grec_base + (kRec ? (size_t)nslices * P * sizeof(double2) : 0)) +
                      (size_t)slice * P;
 
     // FIT_IM != 0: Dawson table (16 intervals x 19 coefficients for the gathered evaluation, then the 12 of the
@@ -1923,21 +1926,23 @@ int scatter_grid(nmrfit_ctx *ctx, const double *d_src, double *d_dst)
 // The kernel variant a launch actually runs (the requested one may not fit in LDS, or may not
 // implement the imaginary part) and the dynamic LDS its per-wave records need.
 constexpr size_t kStaticLds = (size_t)kWsumsCount * sizeof(double) + 64;   // objective_kernel's own __shared__ (wsums) + alignment slack
+// `slices`: copies of the per-peak records in a workgroup (1 when its waves are segments of one particle, else wpb);
+// `rows`: copies of the updated row kept for a fused swarm generation (0: none)
 static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, int fit_im, int *variant_out,
-                              unsigned *aux_off, int wpb = kWavesPerBlock, bool fused_rows = false)
+                              unsigned *aux_off, int wpb, int slices, int rows)
 {
     const size_t np = (size_t)std::max(P, 1);
     // what a workgroup may take of a CU's 160 KiB for the records sized here: everything but the kernel's static
     // LDS and (swarm generations) the per-wave copies of the updated rows that launch_objective appends
     const size_t room = 160 * 1024 - kStaticLds -
-                        (fused_rows ? (size_t)wpb * (size_t)(4 + 3 * (int64_t)P) * sizeof(double) + 16 : 0);
-    const size_t lds_recs = (((size_t)wpb * np * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
+                        (rows ? (size_t)rows * (size_t)(4 + 3 * (int64_t)P) * sizeof(double) + 16 : 0);
+    const size_t lds_recs = (((size_t)slices * np * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
                             (size_t)wpb * kMaxBlocks * sizeof(double2) + kSharedPrologueBytes;
     const size_t lds_stage = (size_t)wpb * 3 * kChunk * sizeof(double);
     const size_t lds_far = (size_t)wpb * kFarTerms * kFarPad * sizeof(double);
     // Gaussian recurrence constants (d, C) per peak: objective launches of DEFAULT / FARFIELD
-    const size_t lds_rec = residual ? 0 : (size_t)wpb * np * sizeof(double2);
-    const size_t lds_fast = (NMRFIT_FASTPAIR != 0 && NMRFIT_GROUP == 8) ? (size_t)wpb * np * sizeof(PeakFast) : 0;
+    const size_t lds_rec = residual ? 0 : (size_t)slices * np * sizeof(double2);
+    const size_t lds_fast = (NMRFIT_FASTPAIR != 0 && NMRFIT_GROUP == 8) ? (size_t)slices * np * sizeof(PeakFast) : 0;
     // the all-peak imaginary model sums far peaks through the far-field scratch and evaluates Dawson's
     // integral from a table in LDS
     const size_t lds_im = (fit_im == 2) ? lds_far : 0;
@@ -2005,18 +2010,30 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     int variant = NMRFIT_VARIANT_DEFAULT;
     unsigned aux_off = 0;
     const bool fused_rows = fused && fused->x_in;
-    size_t lds = resolve_variant(ctx, P, dR != nullptr, fit_im, &variant, &aux_off, kWavesPerBlock, fused_rows);
+    // LDS copies: per-peak records once per workgroup when its waves are segments of ONE particle (nseg a multiple of
+    // the waves per workgroup), else once per wave; the updated row of a fused swarm generation likewise, plus two
+    // more rows (g, the winner's row) when the workgroup may finish the generation (objective.hip, personal_best)
+    auto copies = [&](int w, int *slices, int *rows) {
+        const bool one_particle = kOneWorkgroupParticle && (nseg % w == 0);   // (objective_body: `shared`)
+        *slices = one_particle ? 1 : w;
+        *rows = !fused_rows ? 0 : !one_particle ? w : (fused->tail != 0u && nseg == w && S <= kFusedTailMaxS) ? 3 : 1;
+    };
+    int wpb = kWavesPerBlock, slices = 0, rows = 0;
+    copies(wpb, &slices, &rows);
+    size_t lds = resolve_variant(ctx, P, dR != nullptr, fit_im, &variant, &aux_off, wpb, slices, rows);
     // Eight segments per particle (small swarms on short grids -- the reference's default 204 x 4096): an EIGHT-wave
     // workgroup is the particle, as the four-wave workgroup is for four segments: one prologue per particle, block
     // sums through LDS, f (and, in a swarm generation, the personal best) finished in this launch.
-    int wpb = kWavesPerBlock;
-    const size_t xrow_bytes = (fused && fused->x_in) ? (size_t)(4 + 3 * (int64_t)P) * sizeof(double) : 0;
+    const size_t xrow_bytes = fused_rows ? (size_t)(4 + 3 * (int64_t)P) * sizeof(double) : 0;
     if (nseg == kWideWaves && !dR && fit_im == 0 && has_eight_wave_form(variant) && ctx->wide_workgroups) {
-        int v8 = variant;
+        int v8 = variant, s8 = 0, r8 = 0;
         unsigned aux8 = 0;
-        const size_t lds8 = resolve_variant(ctx, P, false, fit_im, &v8, &aux8, kWideWaves, fused_rows);
-        if (v8 == variant && lds8 + kStaticLds + 16 + kWideWaves * xrow_bytes <= 160 * 1024) {
+        copies(kWideWaves, &s8, &r8);
+        const size_t lds8 = resolve_variant(ctx, P, false, fit_im, &v8, &aux8, kWideWaves, s8, r8);
+        if (v8 == variant && lds8 + kStaticLds + 16 + (size_t)r8 * xrow_bytes <= 160 * 1024) {
             wpb = kWideWaves;
+            slices = s8;
+            rows = r8;
             lds = lds8;
             aux_off = aux8;
         }
@@ -2026,7 +2043,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         set_error("swarm too large for one launch");
         return NMRFIT_E_INVALID;
     }
-    if (lds + kStaticLds + 16 + (size_t)wpb * xrow_bytes > 160 * 1024) {
+    if (lds + kStaticLds + 16 + (size_t)rows * xrow_bytes > 160 * 1024) {
         set_error("too many peaks for the kernel's LDS records (with the imaginary model / the fused swarm update)");
         return NMRFIT_E_UNSUPPORTED;
     }
@@ -2040,7 +2057,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
         upd = *fused;
         lds = (lds + 15) & ~(size_t)15;
         upd.xrow_off = (unsigned)lds;
-        lds += (size_t)wpb * (size_t)(4 + 3 * (int64_t)P) * sizeof(double);
+        lds += (size_t)rows * (size_t)(4 + 3 * (int64_t)P) * sizeof(double);
     }
     // nseg == 1: the wave writes f; nseg == 4 (or 8, wide form): the waves of a workgroup are the particle's
     // segments and the workgroup writes f (block sums through LDS); otherwise per-block sums go to a

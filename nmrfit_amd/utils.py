@@ -56,21 +56,22 @@ def default_variant(N, P, fit_im=False):
     """Kernel variant ``fit`` uses when options['variant'] is absent: the far-field form
     (distant peaks' Lorentzian tails through one shared expansion per 512-point chunk, values
     within 1e-14 of the direct kernel's) once there is enough grid x peaks for it to pay, the
-    direct kernel below that.  The threshold was re-measured in round 3 at 204, 1024 and 4096
-    particles (tools/archive/variant_threshold.py, per-generation time of the swarm loop, far-field /
-    direct; profiles/r03/variant_threshold.txt):
+    direct kernel below that.  The threshold was re-measured in round 4 with the final kernels at 204, 1024
+    and 4096 particles (tools/archive/variant_threshold.py, per-generation time of the swarm loop, far-field /
+    direct; profiles/r04/variant_threshold.txt):
 
         grid x peaks      204      1024     4096 particles
-        4096 x 6          1.03     1.02     1.06
-        4096 x 24         1.08     1.10     1.12      (short grid: few chunks, every peak near)
-        16384 x 6         0.98     0.94     1.02
-        16384 x 12        0.94     0.91     0.88
-        8192 x 24         1.04     0.98     0.97
-        32768 x 12        0.85     0.81     0.78
-        65536 x 24        0.62     0.56     0.52
+        4096 x 6          1.06     0.99     1.03
+        4096 x 24         1.09     1.06     1.06      (short grid: few chunks, every peak near)
+        8192 x 12         1.02     0.81     0.97
+        16384 x 6         1.02     0.90     0.98
+        16384 x 12        0.95     0.84     0.84
+        8192 x 24         0.99     0.77     0.91
+        32768 x 12        0.78     0.75     0.73
+        65536 x 24        0.55     0.52     0.47
 
-    i.e. the crossover sits at grid x peaks ~ 1e5 for every swarm size (within +-4 % either way
-    between 1e5 and 2e5).  The whole GPU test suite passes with either as the default of every
+    i.e. on grids of 8192 points and more the crossover sits at or just below grid x peaks ~ 1e5 for every
+    swarm size (a 4096-point grid has too few chunks for any peak to be far), so the rule stands.  The whole GPU test suite passes with either as the default of every
     context (NMRFIT_DEFAULT_VARIANT), and tests/test_gpu_parity.py::test_farfield_adversarial_spectra
     covers the spectra where no peak is far.  bench.py's headline is always measured on the direct
     kernel; its `fit_default` entry reports this one.

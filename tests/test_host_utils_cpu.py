@@ -117,3 +117,17 @@ def test_fit_device_follows_local_rank(monkeypatch):
     monkeypatch.setattr(_cabi, "device_count", lambda: 4)
     with pytest.raises(RuntimeError, match="HIP_VISIBLE_DEVICES"):
         FitUtility(None, [], [], options={"exchange": "rccl"})._device()
+
+
+def test_dense_swarm_generator_is_the_opposite_of_the_sparse_workload():
+    """synth.make_dense_swarm (bench.py's `dense_spectrum`): broad overlapping lines -- every
+    width at least 0.3 of the span, every centre inside it -- where make_spectrum's lines are ~0.5 % of the span."""
+    from nmrfit_amd import synth
+    X = synth.make_dense_swarm(64, 24, seed=5, w_lo=3.0, w_hi=4.0)
+    assert X.shape == (64, 4 + 3 * 24) and X.flags["C_CONTIGUOUS"]
+    assert (X[:, 4::3] >= 0.3).all() and (X[:, 4::3] <= 0.8).all()
+    assert (X[:, 5::3] >= 3.2).all() and (X[:, 5::3] <= 3.8).all()
+    assert (np.abs(X[:, :2]) <= np.pi).all() and (X[:, 2] >= 0).all() and (X[:, 2] <= 1).all()
+    sp = synth.make_spectrum(4096, 24, seed=1)
+    assert sp["x_true"][4::3].max() < 0.01          # the headline workload's lines: 0.4-0.6 % of the span
+    np.testing.assert_array_equal(X, synth.make_dense_swarm(64, 24, seed=5))      # seeded

@@ -71,6 +71,9 @@ constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 #ifndef NMRFIT_MIN_WAVES
 #define NMRFIT_MIN_WAVES 3
 #endif
+#ifndef NMRFIT_SADDR
+#define NMRFIT_SADDR 1
+#endif
 #ifndef NMRFIT_PREFETCH_W
 #define NMRFIT_PREFETCH_W 0   // w of the next chunk requested in the epilogue of the current one: measured +1 % (C3) ... +5 %
 #endif                        // (204 x 4096 x 6) -- 16 register copies per chunk and a fuller epilogue; A/B knob
@@ -221,6 +224,21 @@ __device__ __forceinline__ void phase_stamp(unsigned long long *clk, int i)
 #else
     (void)clk;
     (void)i;
+#endif
+}
+
+// Address of a lane's 16-byte pair in a chunk: wave-uniform base + 16 * lane, with the lane part made opaque at the
+// point of use -- otherwise the compiler hoists `array + lane` out of the chunk loop as a 64-bit per-lane pointer for
+// each of the four arrays (8 VGPRs held across the loop, a v_lshl_add_u64 per array per chunk) instead of using the
+// scalar-base + 32-bit-offset form of global_load.
+__device__ __forceinline__ const double2 *lane_ptr(const double *uniform_base, int lane)
+{
+#if NMRFIT_SADDR
+    unsigned off = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(off));
+    return reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(uniform_base) + (size_t)off);
+#else
+    return reinterpret_cast<const double2 *>(uniform_base) + lane;
 #endif
 }
 
@@ -1087,7 +1105,7 @@ __device__ __forceinline__ void objective_body(
             for (int q = 0; q < kPointsPerLane; ++q) wv[q] = (double)(jl + q * kWave) * (lane_step * (1.0 / 64.0)) - wspan;
 #else
             // (grid_slot order: the lane's points 2m, 2m+1 are one 16-byte pair -> global_load_dwordx4)
-            const double2 *wp = reinterpret_cast<const double2 *>(wc + jb) + lane;
+            const double2 *wp = lane_ptr(wc + jb, lane);
 #pragma unroll
             for (int m = 0; m < kPointsPerLane / 2; ++m) {
                 const double2 d = wp[m * kWave];
@@ -1459,9 +1477,7 @@ __device__ __forceinline__ void objective_body(
                 tq[q] = 1.0 + (double)q * 0.125;
             }
 #else
-            const double2 *up = reinterpret_cast<const double2 *>(u + jb) + lane;
-            const double2 *vp = reinterpret_cast<const double2 *>(v + jb) + lane;
-            const double2 *tp = reinterpret_cast<const double2 *>(wt + jb) + lane;
+            const double2 *up = lane_ptr(u + jb, lane), *vp = lane_ptr(v + jb, lane), *tp = lane_ptr(wt + jb, lane);
 #pragma unroll
             for (int m = 0; m < kPointsPerLane / 2; ++m) {
                 const double2 du = up[m * kWave], dv = vp[m * kWave], dt = tp[m * kWave];

@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from nmrfit_amd import synth, pso, utils, equations, _cabi
 sp = synth.make_spectrum(4096, 6, seed=1)

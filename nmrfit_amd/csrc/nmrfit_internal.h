@@ -20,8 +20,9 @@ constexpr int kPointsPerLane = NMRFIT_POINTS;    // grid points register-blocked
 constexpr int kChunk = kWave * kPointsPerLane;   // 512 grid points per wave per chunk
 constexpr int kMaxBlocks = 16;       // blocks per grid: the unit of the canonical summation order and of the phase
                                      // re-seeding (blk_chunks = ceil(n_chunks / 16)); objective.hip, pso_update.h
-constexpr int kMaxPeaks = 1000;      // LDS: 4 waves x P x (32 B PeakLor + 8 B PeakWin [+ 16 B recurrence + 32 B PeakFast,
-                                     // dropped above P ~ 450]) + 1 KiB of block seeds <= 160 KiB
+constexpr int kMaxPeaks = 960;       // LDS: one copy of the per-peak records per wave when the waves of a workgroup hold different
+                                     // particles -- 4 x P x (32 B PeakLor + 8 B PeakWin [+ 16 B recurrence + 32 B PeakFast, dropped
+                                     // above P ~ 450]) -- + block seeds, per-wave lane phase seeds, the Dawson table <= 160 KiB
 
 // Physical order of the four grid arrays (centred w, u, v, weights) in device memory.  A lane's q-th point of a
 // chunk is the grid point at offset lane + 64*q (lanes stride the grid); in memory each chunk is stored

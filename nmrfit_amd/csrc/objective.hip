@@ -71,6 +71,9 @@ constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
 #ifndef NMRFIT_MIN_WAVES
 #define NMRFIT_MIN_WAVES 3
 #endif
+#ifndef NMRFIT_PAIRFOLD
+#define NMRFIT_PAIRFOLD 1
+#endif
 #ifndef NMRFIT_SADDR
 #define NMRFIT_SADDR 1
 #endif
@@ -468,23 +471,51 @@ __device__ __forceinline__ void lorentz_group_fast(const PeakFast *r, const doub
     constexpr int kInterleave = NMRFIT_INTERLEAVE;
     constexpr int B = kBatchInv;
     static_assert(kPointsPerLane % B == 0, "batch");
+    auto point = [&](const double w, double &num, double &den) {
+        double pn[G / 2], pd[G / 2];
+#pragma unroll
+        for (int g = 0; g < G; g += 2) {
+            const double t0 = __builtin_fma(w, ih[g], c[g]);
+            const double t1 = __builtin_fma(w, ih[g + 1], c[g + 1]);
+            const double s0 = __builtin_fma(t0, t0, ia[g]);
+            const double s1 = __builtin_fma(t1, t1, ia[g + 1]);
+            pn[g / 2] = s0 + s1;
+            pd[g / 2] = s0 * s1;
+        }
+        lorentz_tree<G / 2, 0, G / 2>(pn, pd, num, den);
+    };
+#if NMRFIT_PAIRFOLD
+    if constexpr (B == 4) {
+        // Four points per reciprocal, folded pair by pair: once two points' (numerator, denominator) are known they
+        // become (n0 d1, n1 d0, d0 d1) -- three values instead of four held while the other pair is worked out (the
+        // same 13 operations + one reciprocal per batch as the unfolded form below; values move by one rounding)
+#pragma unroll
+        for (int q0 = 0; q0 < kPointsPerLane; q0 += 4) {
+            double n0, d0, n1, d1;
+            point(wv[q0], n0, d0);
+            point(wv[q0 + 1], n1, d1);
+            const double p01 = d0 * d1, a0 = n0 * d1, a1 = n1 * d0;
+            __builtin_amdgcn_sched_barrier(0);
+            double n2, d2, n3, d3;
+            point(wv[q0 + 2], n2, d2);
+            point(wv[q0 + 3], n3, d3);
+            const double p23 = d2 * d3, a2 = n2 * d3, a3 = n3 * d2;
+            const double r = rcp64(p01 * p23);
+            const double r01 = r * p23, r23 = r * p01;
+            acc[q0] = __builtin_fma(a0, r01, acc[q0]);
+            acc[q0 + 1] = __builtin_fma(a1, r01, acc[q0 + 1]);
+            acc[q0 + 2] = __builtin_fma(a2, r23, acc[q0 + 2]);
+            acc[q0 + 3] = __builtin_fma(a3, r23, acc[q0 + 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int q0 = 0; q0 < kPointsPerLane; q0 += B) {
         double num[B], den[B];
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
-            double pn[G / 2], pd[G / 2];
-#pragma unroll
-            for (int g = 0; g < G; g += 2) {
-                const double t0 = __builtin_fma(wv[q0 + b], ih[g], c[g]);
-                const double t1 = __builtin_fma(wv[q0 + b], ih[g + 1], c[g + 1]);
-                const double s0 = __builtin_fma(t0, t0, ia[g]);
-                const double s1 = __builtin_fma(t1, t1, ia[g + 1]);
-                pn[g / 2] = s0 + s1;
-                pd[g / 2] = s0 * s1;
-            }
-            lorentz_tree<G / 2, 0, G / 2>(pn, pd, num[b], den[b]);
-        }
+        for (int b = 0; b < B; ++b) point(wv[q0 + b], num[b], den[b]);
         if constexpr (B == 1) {
             acc[q0] = __builtin_fma(num[0], rcp64(den[0]), acc[q0]);
         } else if constexpr (B == 2) {
@@ -742,7 +773,12 @@ __device__ __forceinline__ void objective_body(
     double2 *seeds = reinterpret_cast<double2 *>(lds_tail) + (size_t)wave * kMaxBlocks;
     double *shr = reinterpret_cast<double *>(lds_tail + (size_t)WPB * kMaxBlocks * sizeof(double2));   // rho, L_lane[64] re / im
     int *sflag = reinterpret_cast<int *>(shr + 2 + 2 * kWave);                                          // one per wave
-    unsigned char *lds_tail2 = reinterpret_cast<unsigned char *>(shr) + kSharedPrologueBytes;
+    // per-lane phase seeds L_lane: in `shr` when the workgroup is one particle, else one copy per wave right behind
+    // it; read back at the start of every block instead of living in four VGPRs across the chunk loop
+    double *lseed = shared ? shr + 2
+                           : reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(shr) + kSharedPrologueBytes) + (size_t)wave * (2 * kWave);
+    unsigned char *lds_tail2 = reinterpret_cast<unsigned char *>(shr) + kSharedPrologueBytes +
+                               (shared ? 0 : (size_t)WPB * 2 * kWave * sizeof(double));
     double *stage = reinterpret_cast<double *>(lds_tail2) + (size_t)wave * (3 * kChunk);
     // FARFIELD: per-wave scratch [kFarTerms][kFarPad] for the cross-peak coefficient sums
     // (shares the offset of `stage`; the two variants are exclusive)
@@ -910,7 +946,7 @@ __device__ __forceinline__ void objective_body(
         if (shared) __syncthreads();   // wave 0's row is every wave's input
         wave_lds_fence();   // same-wave LDS write -> read
     }
-    double rr = 1.0, ri = 0.0, lr = 1.0, li = 0.0;   // rotation step exp(i p1 64/N), lane seed exp(i (p0 + p1 lane/N))
+    double rr = 1.0, ri = 0.0;   // rotation step exp(i p1 64/N) (the lane seeds exp(i (p0 + p1 lane/N)): lseed, in LDS)
     const double invN = 1.0 / (double)N;
     bool fast_all, rec_all;
     if (shared) {
@@ -936,8 +972,6 @@ __device__ __forceinline__ void objective_body(
         rec_all = kRec && !(all & 2);
         rr = wave_uniform(shr[0]);
         ri = wave_uniform(shr[1]);
-        lr = shr[2 + lane];
-        li = shr[2 + kWave + lane];
     } else {
         stage_row(0, 1);
         // wave-uniform: every group of this particle may take the two-operation pair form
@@ -963,7 +997,10 @@ __device__ __forceinline__ void objective_body(
         sincos_fast((p1 * 64.0) * invN, &ri, &rr);
         rr = wave_uniform(rr);
         ri = wave_uniform(ri);
+        double lr, li;
         sincos_fast(p0 + (p1 * (double)lane) * invN, &li, &lr);
+        lseed[lane] = lr;
+        lseed[kWave + lane] = li;
     }
     {
         const int64_t b0 = j0 / blk_len;
@@ -1075,6 +1112,7 @@ __device__ __forceinline__ void objective_body(
         // segmentation of the grid and any sharding of the swarm.
         if (cib == 0) {   // first chunk of a block (segments start on block boundaries)
             const double2 e = seeds[bidx];
+            const double lr = lseed[lane], li = lseed[kWave + lane];
             zr = __builtin_fma(e.x, lr, -(e.y * li));
             zi = __builtin_fma(e.x, li, e.y * lr);
         }
@@ -1953,7 +1991,8 @@ static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, i
     const size_t room = 160 * 1024 - kStaticLds -
                         (rows ? (size_t)rows * (size_t)(4 + 3 * (int64_t)P) * sizeof(double) + 16 : 0);
     const size_t lds_recs = (((size_t)slices * np * (sizeof(PeakLor) + sizeof(PeakWin)) + 15) & ~(size_t)15) +
-                            (size_t)wpb * kMaxBlocks * sizeof(double2) + kSharedPrologueBytes;
+                            (size_t)wpb * kMaxBlocks * sizeof(double2) + kSharedPrologueBytes +
+                            (slices == 1 ? 0 : (size_t)wpb * 2 * kWave * sizeof(double));   // per-wave lane phase seeds
     const size_t lds_stage = (size_t)wpb * 3 * kChunk * sizeof(double);
     const size_t lds_far = (size_t)wpb * kFarTerms * kFarPad * sizeof(double);
     // Gaussian recurrence constants (d, C) per peak: objective launches of DEFAULT / FARFIELD

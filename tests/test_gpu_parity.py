@@ -237,12 +237,12 @@ def test_four_segment_workgroup_reduction_matches_the_other_geometries(eq, varia
         np.testing.assert_array_equal(Rb, R[:3])
 
 
-@pytest.mark.parametrize("P", [9, 64, 65, 130, 1000])
+@pytest.mark.parametrize("P", [9, 64, 65, 130, 960])
 def test_many_peaks(eq, P):
     """More peaks than a 64-peak window-mask block (P = 65, 130), group tails of every size and
-    the LDS limit (P = 1000 -> one workgroup per CU)."""
+    the LDS limit (P = 960 -> one workgroup per CU)."""
     from oracle import c_oracle
-    N = 1500 if P < 1000 else 600
+    N = 1500 if P < 960 else 600
     sp = synth.make_spectrum(N, P, seed=61)
     X = synth.make_swarm(sp["lower"], sp["upper"], 9, seed=62, x_true=sp["x_true"])
     ref_R, ref_f = c_oracle.residual_batch(X, sp["w"], sp["u"], sp["v"], sp["weights"], threads=8)
@@ -253,10 +253,10 @@ def test_many_peaks(eq, P):
         ev.set_variant(_cabi.VARIANT_DEFAULT)
         R = ev.residual_batch(X[:2])
     np.testing.assert_allclose(R, ref_R[:2], rtol=0, atol=1e-11 * np.abs(ref_R).max())
-    if P == 1000:
+    if P == 960:
         with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
             with pytest.raises(eq.NmrfitError) as ei:
-                ev.objective_batch(np.zeros((1, 4 + 3 * 1001)))
+                ev.objective_batch(np.zeros((1, 4 + 3 * 961)))
             assert ei.value.code == _cabi.E_INVALID
 
 

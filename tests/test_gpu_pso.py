@@ -315,9 +315,9 @@ def test_closing_the_evaluator_closes_its_swarms():
     del sw, ev
 
 
-@pytest.mark.parametrize("S,P", [(12, 100), (12, 300), (300, 120), (3, 1000), (1, 2), (2, 0)])
+@pytest.mark.parametrize("S,P", [(12, 100), (12, 300), (300, 120), (3, 960), (1, 2), (2, 0)])
 def test_device_swarm_wide_parameter_vectors(S, P):
-    """Many-peak models (D = 4 + 3P up to 3004) and degenerate swarms, on both sides of the
+    """Many-peak models (D = 4 + 3P up to 2884) and degenerate swarms, on both sides of the
     fused-tail threshold: still bit-identical to the numpy mirror."""
     from nmrfit_amd import equations
     sp = synth.make_spectrum(1024, P, seed=9)

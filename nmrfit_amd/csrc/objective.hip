@@ -2034,10 +2034,10 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     const int fit_im = dR ? 0 : ctx->fit_im;
     if (S == 0) return NMRFIT_OK;
     const int64_t N = ctx->N;
-    // Segmenting: a wave is one (particle, segment) task.  Aim for ~16 tasks per SIMD so the
-    // hardware dispatcher load-balances (measured on C3: 4096 one-per-particle waves 1.81 ms,
-    // 16384 waves 1.74 ms); a segment is a whole number of blocks.  Swarms that
-    // already supply enough waves get nseg = 1 and the wave writes f directly.
+    // Segmenting: a wave is one (particle, segment) task; a segment is a whole number of blocks.  Swarms that already
+    // supply enough waves get nseg = 1 and the wave writes f directly.  (Rounds 1-3 aimed at ~16 tasks per SIMD so that
+    // the hardware dispatcher load-balances -- C3: 4096 one-per-particle waves 1.81 ms, 16384 waves 1.74 ms; the
+    // round-4 rule below replaces it unless NMRFIT_SEG_RULE=3 or an explicit target is set.)
     int64_t target_waves = (int64_t)ctx->compute_units * 4 * 16;
     if (ctx->target_waves > 0) target_waves = ctx->target_waves;
     // Blocks: the unit of the canonical summation / phase re-seeding, a function of N only
@@ -2047,6 +2047,20 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
     const int64_t blk_len = (int64_t)blk_chunks * kChunk;
     int64_t nseg = std::max<int64_t>(1, std::min<int64_t>(n_blocks, (target_waves + S - 1) / S));
+    static const bool seg_rule_r4 = [] {
+        const char *e = getenv("NMRFIT_SEG_RULE");   // A/B knob: 3 = the round-3 rule (~16 tasks per SIMD)
+        return !(e && atoi(e) == 3);
+    }();
+    if (ctx->target_waves == 0 && seg_rule_r4) {
+        // Round 4 (the selectable kernels now run four waves per SIMD): as few segments as fill the chip ONCE -- every
+        // further segment repeats a wave's prologue and cuts its chunk loop shorter (1024 x 16384 x 12: 16 segments
+        // 69 us, 4 segments 60 us; 4096 x 4096 x 6: 4 segments 56 us, 1 segment 49 us) -- but four where a wave then
+        // still has 16 chunks or more: the prologue no longer counts there, and four segments make the workgroup
+        // the particle (f and the personal best finished in the launch)
+        const int64_t slots = (int64_t)ctx->compute_units * 4 * 4;
+        nseg = std::max<int64_t>(1, std::min<int64_t>(n_blocks, (slots + S - 1) / S));
+        if (n_chunks / 4 >= 16) nseg = std::max<int64_t>(nseg, std::min<int64_t>(4, n_blocks));
+    }
     // Short grids: a wave's own prologue (block seeds, pointers, the barrier of the shared part) still
     // costs a good fraction of a chunk, so prefer >= 2 chunks per wave as long as two waves per SIMD
     // remain (measured on C2, S=1024 N=4096, with the per-workgroup prologue: 8 segments 25.0 us,

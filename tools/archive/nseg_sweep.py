@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from nmrfit_amd import synth
 from nmrfit_amd.equations import Evaluator
 
-shapes = [(204, 4096, 6), (1024, 4096, 6), (204, 16384, 12), (4096, 65536, 24)]
+shapes = [(204, 4096, 6), (512, 4096, 6), (1024, 4096, 6), (2048, 4096, 6), (4096, 4096, 6), (204, 16384, 12), (1024, 16384, 12), (2048, 16384, 12),
+          (512, 65536, 24), (1024, 65536, 24), (2048, 65536, 24), (4096, 65536, 24)]
 for (S, N, P) in shapes:
     sp = synth.make_spectrum(N, P, seed=1)
     X = synth.make_swarm(sp["lower"], sp["upper"], S, seed=2, x_true=sp["x_true"])

@@ -61,17 +61,17 @@ def default_variant(N, P, fit_im=False):
     direct; profiles/r04/variant_threshold.txt):
 
         grid x peaks      204      1024     4096 particles
-        4096 x 6          1.06     0.99     1.03
-        4096 x 24         1.09     1.06     1.06      (short grid: few chunks, every peak near)
-        8192 x 12         1.02     0.81     0.97
-        16384 x 6         1.02     0.90     0.98
-        16384 x 12        0.95     0.84     0.84
-        8192 x 24         0.99     0.77     0.91
-        32768 x 12        0.78     0.75     0.73
-        65536 x 24        0.55     0.52     0.47
+        4096 x 6          1.06     1.11     1.25
+        4096 x 24         1.09     1.11     1.14      (short grid: few chunks, every peak near)
+        8192 x 12         1.02     1.01     1.05
+        16384 x 6         1.01     1.05     1.08
+        16384 x 12        0.93     0.89     0.88
+        8192 x 24         0.99     0.96     0.96
+        32768 x 12        0.84     0.77     0.74
+        65536 x 24        0.57     0.50     0.47
 
-    i.e. on grids of 8192 points and more the crossover sits at or just below grid x peaks ~ 1e5 for every
-    swarm size (a 4096-point grid has too few chunks for any peak to be far), so the rule stands.  The whole GPU test suite passes with either as the default of every
+    i.e. the direct kernel wins everywhere below grid x peaks = 1e5 and the far-field kernel everywhere from 2e5
+    on, for every swarm size: the rule stands.  The whole GPU test suite passes with either as the default of every
     context (NMRFIT_DEFAULT_VARIANT), and tests/test_gpu_parity.py::test_farfield_adversarial_spectra
     covers the spectra where no peak is far.  bench.py's headline is always measured on the direct
     kernel; its `fit_default` entry reports this one.

@@ -1,0 +1,36 @@
+"""
+CPU tier: what the compiler made of the kernels (its own resource remarks; hipcc cross-compiles without a GPU).
+No kernel nmrfit_amd.fit() can select may use scratch memory, and the two kernels a fit spends its time in --
+the direct and the far-field objective kernel without the imaginary channel -- must fit FOUR waves per SIMD
+(<= 128 VGPRs): round 4 got them there (values that die early, lane seeds in LDS, scalar-base addressing), and a
+change that quietly costs a wave per SIMD costs C2 10 % and the far-field kernel 7 %.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_selectable_kernels_use_no_scratch_and_the_hot_two_fit_four_waves():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--check"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    rows = {}
+    for line in out.stdout.splitlines():
+        m = re.match(r"(objective_kernel<[^>]+>)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)", line)
+        if m:
+            rows[m.group(1)] = dict(vgpr=int(m.group(2)), scratch=int(m.group(4)), waves=int(m.group(5)))
+    assert len(rows) >= 20, out.stdout[-2000:]
+    for name in ("objective_kernel<DEFAULT,objective,fit_im=0>", "objective_kernel<FARFIELD,objective,fit_im=0>",
+                 "objective_kernel<DEFAULT,objective,fit_im=0,8 waves>", "objective_kernel<FARFIELD,objective,fit_im=0,8 waves>"):
+        assert rows[name]["scratch"] == 0 and rows[name]["vgpr"] <= 128 and rows[name]["waves"] >= 4, (name, rows[name])
+    # the imaginary channel: the reference's fit_im=True on the far-field kernel and the all-peak sum on the direct one
+    # (what fit() selects) run three waves per SIMD
+    for name in ("objective_kernel<FARFIELD,objective,fit_im=1>", "objective_kernel<DEFAULT,objective,fit_im=2>",
+                 "objective_kernel<DEFAULT,objective,fit_im=1>"):
+        assert rows[name]["scratch"] == 0 and rows[name]["vgpr"] <= 168, (name, rows[name])

@@ -120,7 +120,8 @@ int nmrfit_ctx_n(const nmrfit_ctx *ctx, int64_t *N);
  * (nmrfit/equations.py:152-212, called by pyswarm from nmrfit/utils.py:176-182) by one
  * batched launch: f_out[i] = sqrt(mean_j (weights_j * (V_data_ij - V_fit_ij))^2).
  * fit_im is one of NMRFIT_FIT_IM_*; with it the value is (rmse_real + rmse_imag)/2
- * (equations.py:205-209).  S == 0 is a no-op.                                        */
+ * (equations.py:205-209).  S == 0 is a no-op.  P is limited to 960 peaks (a workgroup keeps its
+ * particle's per-peak records in the CU's 160 KiB of LDS); more is NMRFIT_E_INVALID.     */
 int nmrfit_objective_batch(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *X, int fit_im,
                            double *f_out);
 /* R_out[b*N + j] = weights_j * (V_data_bj - V_fit_bj): the vector inside the mean of

@@ -56,7 +56,7 @@ static int check_batch(const nmrfit_ctx *ctx, int64_t S, int32_t P, const void *
         return NMRFIT_E_INVALID;
     }
     if (P > kMaxPeaks) {
-        set_error("P exceeds the supported maximum of 1000 peaks");
+        set_error("P exceeds the supported maximum of " + std::to_string(kMaxPeaks) + " peaks (per-peak records of a workgroup live in a CU's 160 KiB of LDS)");
         return NMRFIT_E_INVALID;
     }
     if (S > 0 && (!X || !out)) {

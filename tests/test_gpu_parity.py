@@ -257,7 +257,7 @@ def test_many_peaks(eq, P):
         with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
             with pytest.raises(eq.NmrfitError) as ei:
                 ev.objective_batch(np.zeros((1, 4 + 3 * 961)))
-            assert ei.value.code == _cabi.E_INVALID
+            assert ei.value.code == _cabi.E_INVALID and "960 peaks" in str(ei.value)
 
 
 def test_non_finite_parameters_do_not_crash(eq):

@@ -217,13 +217,16 @@ int nmrfit_pso_set_handover(nmrfit_pso *pso, int mode);
  * inside a launch: 512 x 4096 x 6: 19.5 -> 17.0 us per generation, 1024 x 4096 x 6: 30.2 -> 26.8 us.  On by
  * default; enable = 0 restores the separate kernel (an A/B knob: results are bit-identical either way). */
 int nmrfit_pso_set_fused_pbest(nmrfit_pso *pso, int enable);
-/* ABI 4.  On top of that, a single-rank swarm of up to 256 particles with the fence-free hand-over finishes the
- * whole generation in the objective launch: every workgroup (= particle) draws a ticket once its personal best is
- * complete in memory, and the one that draws the last makes the candidate record and folds it with pyswarm's
- * acceptance / stopping rule -- ONE launch per generation (what pyswarm.pso's loop body, nmrfit/utils.py:176-182,
- * becomes; 204 x 4096 x 6: see DESIGN.md 4.2).  On by default; enable = 0 restores the separate one-workgroup
- * launch (an A/B knob: results are bit-identical either way).  nmrfit_pso_last_launches: how many kernel
- * launches the evaluate-and-select part of the last generation took (1, 2 or 3). */
+/* ABI 4.  On top of that, a single-rank swarm of up to 1024 particles (2048 where the workgroup has eight waves) runs a
+ * whole generation as ONE launch (what pyswarm.pso's loop body, nmrfit/utils.py:176-182, becomes): the objective launch
+ * ends with the personal bests, and the rest -- argmin over fp, candidate record, pyswarm's acceptance / stopping rule --
+ * is deferred into the NEXT launch's prologue, where every workgroup works it out for itself before it moves its
+ * particle (nothing is handed over inside a launch; the state blocks are double-buffered).  Every entry point that
+ * shows or continues the swarm's state first folds the waiting generation in a launch of its own, so the deferral is
+ * not observable through this interface (204 x 4096 x 6: 13.4 -> 11.7 us per generation).  On by
+ * default; enable = 0 restores the separate one-workgroup launch (an A/B knob: results are bit-identical either
+ * way).  nmrfit_pso_last_launches: how many kernel launches the evaluate-and-select part of the last generation
+ * took (1, 2 or 3). */
 int nmrfit_pso_set_fused_tail(nmrfit_pso *pso, int enable);
 int nmrfit_pso_last_launches(const nmrfit_pso *pso, int32_t *launches);
 /* copy swarm state to host for inspection/tests (any pointer may be NULL):

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 struct nmrfit_comm {
@@ -52,6 +53,9 @@ Rccl g_rccl;
 
 int load_rccl()
 {
+    // (contexts may be driven from different host threads: the first communicators of two of them may race here)
+    static std::mutex load_lock;
+    std::lock_guard<std::mutex> guard(load_lock);
     if (g_rccl.handle) return NMRFIT_OK;
     // NMRFIT_RCCL_LIB: a specific RCCL build (or, in tests, a missing one) instead of the usual names
     const char *forced = getenv("NMRFIT_RCCL_LIB");

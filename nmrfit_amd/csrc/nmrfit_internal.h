@@ -124,6 +124,8 @@ struct ObjectiveDeferred {
     int fit_im = 0;
     bool pbest_done = false;           // the launch also updated the personal bests (PsoFused::pbest)
     bool tail_done = false;            // ... and finished the generation: candidate record and fold (PsoFused::tail)
+    bool need_flush = false;           // NOTHING was launched: a pending fold (PsoFused::pending) cannot ride in this launch's geometry;
+                                       // the caller folds in its own launch and calls again without it
 };
 // Enqueue the objective (R_out == nullptr) or residual launch on ctx->stream.
 // `fused` (swarm generations, pso.hip): advance every particle by the swarm's update rule in the

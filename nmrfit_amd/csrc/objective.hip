@@ -909,41 +909,192 @@ __device__ __forceinline__ void objective_body(
         // writes it (and the velocity) to the swarm's other state buffer -- never the one being
         // read, so the segments of a particle cannot race.  After a stop every launch is a no-op:
         // the row is carried over unchanged and the kernel returns.
-        const bool stopped = upd.flags[1] != 0;
-        const uint32_t gen = (uint32_t)(upd.flags[0] + 1);
+        const bool deferred = upd.tail != 0u;   // (the host asks for it only when the workgroup is the particle: `shared`)
+        const bool updater = !shared || wave == 0;   // the wave that moves the particle
+        bool stopped = false;
+        long long gen_done = 0, stop_code = 0;
+        double *const grow = xrow + D, *const crow = xrow + 2 * D;   // (tail != 0: rows 1 and 2 of the row area)
+        // Everything whose address is known goes out NOW, in one round trip: the flags and, into registers, the first 64
+        // entries (all of them up to 20 peaks) of the particle's state, of the bounds and of g.
+        const bool have0 = updater && lane < D;
+        const int64_t idx0 = particle * D + lane;
+        double x0 = 0.0, v0 = 0.0, pold0 = 0.0, lo0 = 0.0, hi0 = 0.0, g0 = 0.0, fg = 0.0;
+        if (updater || !deferred) {   // (deferred form: wave 0 tells the workgroup what the fold said, through LDS)
+            gen_done = upd.flags[0];
+            stop_code = upd.flags[1];
+        }
+        if (updater) {
+            if (deferred) fg = upd.best[0];
+            if (have0) {
+                x0 = upd.x_in[idx0];
+                v0 = upd.v_in[idx0];
+                pold0 = upd.p[idx0];
+                lo0 = upd.lb[lane];
+                hi0 = upd.ub[lane];
+                g0 = upd.best[2 + lane];
+            }
+        }
+        double rp0 = 0.0, rg0 = 0.0;   // the first entry's uniforms (deferred form: drawn while the winner's row is on its way)
+        bool drawn0 = false;
+        if (deferred) {
+            // ---- deferred fold (PsoFused): the previous launch left the personal bests of its generation; before this
+            // particle moves, its workgroup works out what the swarm's best is NOW -- as every other workgroup does,
+            // from the same memory with the same operations (pso_update.h apply_wave, pso.hip argmin_block).
+            if (upd.pending != 0u) {   // every wave: first index of the minimum over its share of fp
+                const double *fpb = upd.p + S * D;
+                const int kper = (int)((S + WPB * kWave - 1) / (WPB * kWave));   // <= kDeferredPerLane (launch_objective)
+                const int64_t base = (int64_t)wave * kper * kWave + lane;
+                double vv[kDeferredPerLane];
+#pragma unroll
+                for (int k = 0; k < kDeferredPerLane; ++k) {   // all loads of a lane in flight together
+                    const int64_t i = base + (int64_t)k * kWave;
+                    vv[k] = (k < kper && i < S) ? fpb[i] : INFINITY;
+                }
+                double best = INFINITY;
+                long long bi = 0x7fffffffffffffffLL;
+#pragma unroll
+                for (int k = 0; k < kDeferredPerLane; ++k)
+                    if (vv[k] < best) {
+                        best = vv[k];
+                        bi = base + (long long)k * kWave;
+                    }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double ob = __shfl_down(best, off, kWave);
+                    const long long oi = __shfl_down(bi, off, kWave);
+                    if (lex_less(ob, oi, best, bi)) {
+                        best = ob;
+                        bi = oi;
+                    }
+                }
+                if (lane == 0) {   // (the block-sum slots are free until the chunk loop ends)
+                    wsums[wave] = best;
+                    wsums[kMaxBlocks + wave] = __longlong_as_double(bi);
+                }
+            }
+            __syncthreads();
+            phase_stamp(clk, 10);   // every wave's share of the argmin over fp is in LDS
+            if (wave == 0) {
+                if (upd.pending != 0u) {
+                    double fc = wsums[0];
+                    long long bi = __double_as_longlong(wsums[kMaxBlocks]);
+#pragma unroll
+                    for (int w2 = 1; w2 < WPB; ++w2) {
+                        const double ob = wsums[w2];
+                        const long long oi = __double_as_longlong(wsums[kMaxBlocks + w2]);
+                        if (lex_less(ob, oi, fc, bi)) {
+                            fc = ob;
+                            bi = oi;
+                        }
+                    }
+                    if (bi >= S) bi = 0;   // every fp is +inf: np.argmin -> 0, and the row is x[0] (pso.hip, argmin_block)
+                    const double *src = (fc < INFINITY) ? upd.p + bi * D : upd.x_in;
+                    const double c0 = have0 ? src[lane] : 0.0;   // the second (and last) round trip of the prologue
+                    if (stop_code == 0) gen_done += 1;   // (after a stop nothing folds and nothing counts: pso_apply_kernel)
+                    if (have0 && stop_code == 0) {       // meanwhile: this generation's uniforms of entry `lane`
+                        uniform2(upd.seed, (uint32_t)(gen_done + 1), (uint32_t)lane, (uint64_t)(upd.offset + particle), &rp0, &rg0);
+                        drawn0 = true;
+                    }
+                    int code = 0;   // 0: not better, 1: stop minfunc, 2: stop minstep, 3: accept
+                    {
+#pragma clang fp contract(off)
+                        double acc = 0.0;
+                        if (have0) {
+                            crow[lane] = c0;
+                            grow[lane] = g0;
+                            const double df = g0 - c0;
+                            acc += df * df;
+                        }
+                        for (int64_t d = lane + kWave; d < D; d += kWave) {
+                            const double c = src[d], gd = upd.best[2 + d];
+                            crow[d] = c;
+                            grow[d] = gd;
+                            const double df = gd - c;
+                            acc += df * df;
+                        }
+                        if (stop_code == 0 && fc < fg) {
+                            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+                            acc = __shfl(acc, 0, 64);
+                            const double stepsize = sqrt(acc);
+                            if (fabs(fg - fc) <= upd.minfunc)
+                                code = 1;
+                            else if (stepsize <= upd.minstep)
+                                code = 2;
+                            else
+                                code = 3;
+                        }
+                        if (code == 1 || code == 2) stop_code = code;
+                    }
+                    wave_lds_fence();
+                    if (particle == 0) {   // ONE writer of the other state block (nobody reads it in this launch)
+                        double *bo = const_cast<double *>(upd.best) + upd.flip;
+                        long long *fo = const_cast<long long *>(upd.flags) + upd.flip;
+                        for (int64_t d = lane; d < D; d += kWave) {
+                            const double c = crow[d];
+                            bo[2 + d] = (code == 3) ? c : grow[d];
+                            bo[2 + D + d] = (code != 0) ? c : upd.best[2 + D + d];
+                            upd.cand[1 + d] = c;
+                        }
+                        if (lane == 0) {
+                            bo[0] = (code == 3) ? fc : fg;
+                            bo[1] = (code != 0) ? fc : upd.best[1];
+                            fo[0] = gen_done;
+                            fo[1] = stop_code;
+                            upd.cand[0] = fc;
+                        }
+                    }
+                    if (code == 3) {
+                        g0 = c0;
+                        for (int64_t d = lane + kWave; d < D; d += kWave) grow[d] = crow[d];
+                    }
+                    wave_lds_fence();
+                } else {
+                    for (int64_t d = lane + kWave; d < D; d += kWave) grow[d] = upd.best[2 + d];
+                    wave_lds_fence();
+                }
+                if (lane == 0) wsums[2 * kMaxBlocks + 6] = (stop_code != 0) ? 1.0 : 0.0;
+                phase_stamp(clk, 11);   // folded
+            }
+        }
+        stopped = stop_code != 0;
+        const uint32_t gen = (uint32_t)(gen_done + 1);
 
-        if (!shared || wave == 0)
+        // every entry of the row: draw, move, clip (pso_update.h); the new row goes to LDS (what this launch evaluates)
+        // and, by the wave of segment 0, with the velocity to the swarm's other state buffer.  The first entry of a
+        // lane comes from the registers loaded above.
+        if (updater)
         for (int64_t d = lane; d < D; d += kWave) {
             const int64_t idx = particle * D + d;
-            double xn = upd.x_in[idx], vn = upd.v_in[idx];
-            const double gd = upd.best[2 + d];
-            // one-launch generations: g (and fg, the generation count) stay in LDS for the fold at the kernel's end --
-            // slice 1 of the row area, free when the workgroup is one particle
-            if (upd.tail != 0u) xrow[D + d] = gd;
+            const bool first = d < kWave;
+            double xn = first ? x0 : upd.x_in[idx], vn = first ? v0 : upd.v_in[idx];
+            const double pold = first ? pold0 : upd.p[idx];
+            // (two loads and a select of VALUES: a select between an LDS and a global address crashes this compiler)
+            double g_lds = 0.0, g_mem = 0.0;
+            if (!first && deferred) g_lds = grow[d];
+            if (!first && !deferred) g_mem = upd.best[2 + d];
+            const double gd = first ? g0 : deferred ? g_lds : g_mem;
+            const double lo = first ? lo0 : upd.lb[d], hi = first ? hi0 : upd.ub[d];
+            if (deferred) {   // the personal best as it stands: for the kernel's end (row 2 is free again), or carried over now
+                crow[d] = pold;
+                if (stopped) const_cast<double *>(upd.p)[upd.pflip + idx] = pold;
+            }
             if (!stopped) {
-                double rp, rg;
-                uniform2(upd.seed, gen, (uint32_t)d, (uint64_t)(upd.offset + particle), &rp, &rg);
-                xn = update_value(xn, vn, upd.p[idx], gd, upd.lb[d], upd.ub[d], rp, rg, upd.omega,
-                                  upd.phip, upd.phig, &vn);
+                double rp = rp0, rg = rg0;
+                if (!(first && drawn0)) uniform2(upd.seed, gen, (uint32_t)d, (uint64_t)(upd.offset + particle), &rp, &rg);
+                xn = update_value(xn, vn, pold, gd, lo, hi, rp, rg, upd.omega, upd.phip, upd.phig, &vn);
             }
             xrow[d] = xn;
             if (active && seg == 0) {
-                if (upd.tail != 0u && particle == 0) {
-                    // one-launch generations: the finishing workgroup may hand out x[0] (no finite objective yet)
-                    __hip_atomic_store(upd.x_out + idx, xn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    upd.x_out[idx] = xn;
-                }
+                upd.x_out[idx] = xn;
                 upd.v_out[idx] = vn;
             }
         }
-        if (upd.tail != 0u && wave == 0 && lane == 0) {
-            wsums[2 * kMaxBlocks + 6] = upd.best[0];
-            wsums[2 * kMaxBlocks + 7] = __longlong_as_double(upd.flags[0]);
-        }
-        if (stopped) return;   // the same for every wave of the grid
+        if (deferred && stopped && wave == 0 && lane == 0)   // (after a stop: the value is carried over like the rows)
+            const_cast<double *>(upd.p)[upd.pflip + S * D + particle] = upd.p[S * D + particle];
+        if (!deferred && stopped) return;   // the same for every wave of the grid
         phase_stamp(clk, 1);   // position update done
         if (shared) __syncthreads();   // wave 0's row is every wave's input
+        if (deferred && wsums[2 * kMaxBlocks + 6] != 0.0) return;   // (wave 0 told the workgroup: the same in every workgroup of the grid)
         wave_lds_fence();   // same-wave LDS write -> read
     }
     double rr = 1.0, ri = 0.0;   // rotation step exp(i p1 64/N) (the lane seeds exp(i (p0 + p1 lane/N)): lseed, in LDS)
@@ -1641,118 +1792,18 @@ __device__ __forceinline__ void objective_body(
                 const double *row = reinterpret_cast<const double *>(lds_raw + (unsigned)__double_as_longlong(wsums[2 * kMaxBlocks + 4]));
                 const int ln = threadIdx.x & (kWave - 1);
                 const double fp_old = wsums[2 * kMaxBlocks + 5];   // (requested by the kernel's first instructions)
-                if (upd.tail == 0u) {
-                    if (f < fp_old) {
-                        for (int64_t d = ln; d < D2; d += kWave) pb[part * D2 + d] = row[d];
-                        if (ln == 0) fpb[part] = f;
-                    }
-                    return;
+                if (upd.tail != 0u) {
+                    // deferred form: the other (p, fp) buffer gets this particle's row and value whether it improved
+                    // or not (PsoFused::pflip; the old row was parked in row 2 of the LDS area by the prologue)
+                    const bool better = f < fp_old;
+                    const double *keep = row + 2 * D2;
+                    for (int64_t d = ln; d < D2; d += kWave) pb[upd.pflip + part * D2 + d] = better ? row[d] : keep[d];
+                    if (ln == 0) fpb[upd.pflip + part] = better ? f : fp_old;
+                    phase_stamp(clk, 5);   // personal best on its way to memory
+                } else if (f < fp_old) {
+                    for (int64_t d = ln; d < D2; d += kWave) pb[part * D2 + d] = row[d];
+                    if (ln == 0) fpb[part] = f;
                 }
-                // ---- one-launch generation (single rank, <= kFusedTailMaxS particles): hand-over to the workgroup that
-                // finishes.  Rows and values other workgroups may read go out as write-through agent-scope stores and
-                // are COMPLETE (s_waitcnt vmcnt(0)) before this wave draws its ticket: pso_select_kernel's protocol.
-                if (f < fp_old) {
-                    for (int64_t d = ln; d < D2; d += kWave)
-                        __hip_atomic_store(pb + part * D2 + d, row[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (ln == 0) __hip_atomic_store(fpb + part, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                global_stores_done();
-                phase_stamp(clk, 5);   // personal best complete in memory
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                unsigned drawn = 0u;
-                if (ln == 0) drawn = __hip_atomic_fetch_add(upd.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                drawn = (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
-                phase_stamp(clk, 6);   // ticket drawn
-                if (drawn != gridDim.x - 1u) return;
-                // every other particle's stores had completed before its ticket was drawn
-                if (ln == 0) __hip_atomic_store(upd.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
-                const int64_t Sn = __double_as_longlong(wsums[2 * kMaxBlocks + 3]);
-                double best = INFINITY;
-                long long bi = 0x7fffffffffffffffLL;
-                {   // first index of the minimum, like np.argmin; all (<= kFusedTailMaxS / 64) loads of a lane in flight together
-                    constexpr int kPer = (int)(kFusedTailMaxS / kWave);
-                    double v[kPer];
-#pragma unroll
-                    for (int k = 0; k < kPer; ++k) {
-                        const int64_t i = ln + (int64_t)k * kWave;
-                        v[k] = (i < Sn) ? __hip_atomic_load(fpb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFINITY;
-                    }
-#pragma unroll
-                    for (int k = 0; k < kPer; ++k)
-                        if (v[k] < best) {
-                            best = v[k];
-                            bi = ln + (long long)k * kWave;
-                        }
-                }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const double ob = __shfl_down(best, off, kWave);
-                    const long long oi = __shfl_down(bi, off, kWave);
-                    if (lex_less(ob, oi, best, bi)) {
-                        best = ob;
-                        bi = oi;
-                    }
-                }
-                best = __shfl(best, 0, kWave);
-                bi = __shfl(bi, 0, kWave);
-                phase_stamp(clk, 7);   // argmin over fp
-                if (bi >= Sn) bi = 0;   // every fp is +inf: np.argmin -> 0, and the record carries x[0] (pso.hip, argmin_block)
-                const double *src = (best < INFINITY) ? pb + bi * D2 : upd.x_out;
-                // The winner's row: to the candidate record (what nmrfit_pso_candidate_dev hands out) and to LDS, next to g
-                // (slice 1 of the row area, parked by the prologue) -- the fold below then needs no further round trip
-                // to memory: same operations in the same order as apply_wave (pso_update.h), same values.
-                double *grow = const_cast<double *>(row) + D2, *crow = const_cast<double *>(row) + 2 * D2;
-                if (ln == 0) upd.cand[0] = best;
-                for (int64_t d = ln; d < D2; d += kWave) {
-                    const double c = __hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    upd.cand[1 + d] = c;
-                    crow[d] = c;
-                }
-                wave_lds_fence();
-                phase_stamp(clk, 8);   // winner's row loaded
-                {
-#pragma clang fp contract(off)
-                    const double fc = best, fg = wsums[2 * kMaxBlocks + 6];
-                    double *bestw = const_cast<double *>(upd.best);
-                    long long *flagsw = const_cast<long long *>(upd.flags);
-                    double *gout = bestw + 2, *bx = bestw + 2 + D2;
-                    int code = 0;   // 0: not better, 1: stop minfunc, 2: stop minstep, 3: accept
-                    if (fc < fg) {
-                        double acc = 0.0;
-                        for (int64_t d = ln; d < D2; d += kWave) {
-                            const double df = grow[d] - crow[d];
-                            acc += df * df;
-                        }
-                        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-                        acc = __shfl(acc, 0, 64);
-                        const double stepsize = sqrt(acc);
-                        if (fabs(fg - fc) <= upd.minfunc)
-                            code = 1;
-                        else if (stepsize <= upd.minstep)
-                            code = 2;
-                        else
-                            code = 3;
-                    }
-                    if (code == 1 || code == 2) {
-                        for (int64_t d = ln; d < D2; d += kWave) bx[d] = crow[d];
-                        if (ln == 0) {
-                            bestw[1] = fc;
-                            flagsw[1] = code;
-                        }
-                    } else if (code == 3) {
-                        for (int64_t d = ln; d < D2; d += kWave) {
-                            gout[d] = crow[d];
-                            bx[d] = crow[d];
-                        }
-                        if (ln == 0) {
-                            bestw[0] = fc;
-                            bestw[1] = fc;
-                        }
-                    }
-                    if (ln == 0) flagsw[0] = __double_as_longlong(wsums[2 * kMaxBlocks + 7]) + 1;
-                }
-                phase_stamp(clk, 9);   // fold written
             }
         }
     };
@@ -2082,10 +2133,14 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     // LDS copies: per-peak records once per workgroup when its waves are segments of ONE particle (nseg a multiple of
     // the waves per workgroup), else once per wave; the updated row of a fused swarm generation likewise, plus two
     // more rows (g, the winner's row) when the workgroup may finish the generation (objective.hip, personal_best)
+    // swarms the two whole-generation forms of a fused launch take (PsoFused::tail), by waves per workgroup
+    auto tail_fits = [&](unsigned tail, int w) {
+        return tail != 0u && S <= (int64_t)kDeferredPerLane * kWave * w;
+    };
     auto copies = [&](int w, int *slices, int *rows) {
         const bool one_particle = kOneWorkgroupParticle && (nseg % w == 0);   // (objective_body: `shared`)
         *slices = one_particle ? 1 : w;
-        *rows = !fused_rows ? 0 : !one_particle ? w : (fused->tail != 0u && nseg == w && S <= kFusedTailMaxS) ? 3 : 1;
+        *rows = !fused_rows ? 0 : !one_particle ? w : (nseg == w && tail_fits(fused->tail, w)) ? 3 : 1;
     };
     int wpb = kWavesPerBlock, slices = 0, rows = 0;
     copies(wpb, &slices, &rows);
@@ -2133,7 +2188,17 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     // buffer and finalize_kernel (or the swarm's select kernel) adds them.  Same summation order in all.
     const bool direct_f = (nseg == 1 || (kOneWorkgroupParticle && nseg == wpb));
     if (!kOneWorkgroupParticle || nseg != wpb) upd.pbest = 0u;   // (only when ONE workgroup holds the whole particle; else the caller's kernel)
-    if (upd.pbest == 0u || S > kFusedTailMaxS) upd.tail = 0u;    // (the whole generation in this launch: only on top of the personal bests)
+    if (upd.pbest == 0u || !tail_fits(upd.tail, wpb)) upd.tail = 0u;   // (the whole generation in this launch: only on top of the personal bests)
+    if (fused && fused->tail != 0u && fused->pending != 0u && upd.tail == 0u) {
+        // a generation waits to be folded and this launch cannot do it (the variant or fit_im changed between two
+        // generations): nothing is launched, the caller folds in a launch of its own and comes back
+        if (!defer) {
+            set_error("launch_objective: pending fold without a deferred-launch record");
+            return NMRFIT_E_STATE;
+        }
+        defer->need_flush = true;
+        return NMRFIT_OK;
+    }
     double *out = df;
     if (!direct_f) {
         int rc = ensure(ctx, &ctx->d_partial, &ctx->cap_partial, S * n_blocks * (fit_im ? 2 : 1));

@@ -20,11 +20,14 @@
 //
 // Every launch costs ~4.8 us on this part however little it does, so the phases are packed
 // into as few launches as the data dependences allow:
-//   S*D <= 2560 (e.g. 50 particles x 6 peaks): objective + ONE single-workgroup kernel for
-//       everything else (pso_tail_kernel)                                        -> 2 launches
-//   four grid segments per particle (one workgroup = one particle: e.g. 512 or 1024 x 4096 x 6, 4096 x 65536 x 24):
-//       the objective launch does the particle's WHOLE step -- update, evaluate, personal best -- and ONE
-//       workgroup finishes (argmin over fp, candidate, fold)                       -> 2 launches
+//   one workgroup = one particle (its four or eight grid segments are the workgroup's waves: the reference's
+//       default 204 x 4096 x 6, 1024 x 4096 x 6, 4096 x 65536 x 24): the objective launch does the particle's
+//       WHOLE step -- update, evaluate, personal best.  Single rank and up to 1024 (eight-wave workgroups: 2048)
+//       particles, the rest of the generation (argmin over fp, candidate record, fold) is DEFERRED into the next
+//       objective launch's prologue, every workgroup for itself (pso_update.h, PsoFused::tail)  -> 1 launch
+//       otherwise ONE workgroup finishes in its own launch (pso_tail_kernel)       -> 2 launches
+//   S*D <= 2560 in any other geometry: objective + ONE single-workgroup kernel for everything else
+//       (pso_tail_kernel)                                                          -> 2 launches
 //   otherwise, S <= 1024: objective (with the position update in its prologue), pso_select_kernel (the
 //       objective's block sums + pbest + argmin [+ apply] in a many-workgroup kernel finished by
 //       its last-ticket workgroup)                                                -> 2 launches
@@ -59,7 +62,12 @@ struct nmrfit_pso {
     unsigned *d_ticket = nullptr;
     int handover = NMRFIT_HANDOVER_FAST;   // nmrfit_pso_set_handover: how the select kernel's workgroups hand over
     bool fused_pbest = true;               // nmrfit_pso_set_fused_pbest: personal bests inside the objective launch
-    bool fused_tail = true;                // ... and the rest of a single-rank generation (NMRFIT_NO_FUSED_TAIL: A/B knob)
+    bool fused_tail = true;                // ... and the rest of a single-rank generation, as a fold deferred into the next
+                                           // objective launch's prologue (PsoFused::tail; NMRFIT_NO_FUSED_TAIL: A/B knob)
+    double *d_best_alt = nullptr;          // the other (g, fg, best | flags) block of the deferred form's double buffer
+    double *d_p_alt = nullptr;             // ... and the other (p, fp) buffer
+    long long *d_flags_alt = nullptr;
+    bool fold_pending = false;             // deferred form: the last launch's personal bests have not been folded yet
     int last_launches = 0;                 // kernel launches of the last generation's evaluate-and-select (diagnostics)
     nmrfit_comm *comm = nullptr;       // attached communicator (sharded swarm): the exchange runs inside nmrfit_pso_step
     bool initialized = false;    // nmrfit_pso_init has run
@@ -536,10 +544,26 @@ int launch_update(nmrfit_pso *pso)
 // [position update +] objective + personal bests + local candidate [+ fold].
 //   advance: move the swarm one generation first (fused into the objective launch when possible)
 //   more:    kTailApply folds this rank's own candidate in the same launch (single-rank runs)
+// Deferred form: fold the generation whose personal bests are still waiting (argmin over fp, candidate record,
+// pyswarm's acceptance / stopping rule) in ONE single-workgroup launch, in place on the current state block.
+// Every entry point that shows the swarm's state to the outside, or continues it in another way, comes here first.
+int flush_fold(nmrfit_pso *pso)
+{
+    if (!pso->fold_pending) return NMRFIT_OK;
+    pso->fold_pending = false;
+    TailArgs a = tail_args(pso, ObjectiveDeferred{}, kTailArgmin | kTailApply);
+    return launch_tail(pso, a);
+}
+
 int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init = 0)
 {
     nmrfit_ctx *ctx = pso->ctx;
     const int64_t S = pso->S, D = pso->D;
+    // the whole generation in the objective launch (single rank: this rank's candidate is the swarm's), its fold deferred
+    // into the next launch's prologue -- if the launch geometry allows, which launch_objective decides
+    const bool want_deferred = advance && fuse_update(pso) && pso->fused_pbest && pso->fused_tail && (more & kTailApply) && !is_init;
+    int rc;
+    if (!want_deferred && (rc = flush_fold(pso)) != NMRFIT_OK) return rc;
     if (S == 0) {
         // an empty shard still posts its (+inf, zeros) candidate
         hipLaunchKernelGGL(pso_argmin_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, D, pso->d_flags, pso->d_fp,
@@ -548,7 +572,6 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
         return NMRFIT_OK;
     }
     ObjectiveDeferred def;
-    int rc;
     if (advance && fuse_update(pso)) {
         PsoFused f;
         f.x_in = pso->d_x;
@@ -568,18 +591,38 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
         // personal bests in the same launch when one workgroup holds a whole particle (the launch decides from
         // its geometry and says so in def.pbest_done); d_fp == d_p + S*D, see nmrfit_pso_create
         if (pso->fused_pbest) f.pbest = 1u;
-        // ... and, single rank with the fence-free hand-over, the rest of the generation too (candidate record + fold
-        // by the workgroup that draws the last ticket): ONE launch per generation
-        if (pso->fused_pbest && pso->fused_tail && (more & kTailApply) && !is_init &&
-            pso->handover == NMRFIT_HANDOVER_FAST) {
+        // ... and, single rank, the rest of the generation too (argmin over fp, candidate record, fold), deferred into the
+        // NEXT launch's prologue: ONE launch per generation
+        if (want_deferred) {
             f.tail = 1u;
             f.cand = pso->d_cand;
-            f.ticket = pso->d_ticket;
             f.minstep = pso->prm.minstep;
             f.minfunc = pso->prm.minfunc;
+            f.pending = pso->fold_pending ? 1u : 0u;   // this launch first folds the generation before it, if one is waiting
+            f.flip = (int)(pso->d_best_alt - pso->d_best);
+            f.pflip = (int)(pso->d_p_alt - pso->d_p);
         }
         rc = launch_objective(ctx, S, pso->P, pso->d_x2, pso->d_fx, nullptr, &def, &f);
         if (rc != NMRFIT_OK) return rc;
+        if (def.need_flush) {   // (nothing was launched: the geometry changed under a waiting fold)
+            if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;
+            f.pending = 0u;
+            rc = launch_objective(ctx, S, pso->P, pso->d_x2, pso->d_fx, nullptr, &def, &f);
+            if (rc != NMRFIT_OK) return rc;
+        }
+        if (def.tail_done) {
+            std::swap(pso->d_p, pso->d_p_alt);   // every particle's personal best went to the other buffer
+            pso->d_fp = pso->d_p + S * D;
+            if (f.pending != 0u) {   // workgroup 0 wrote the folded state into the other block
+                std::swap(pso->d_best, pso->d_best_alt);
+                std::swap(pso->d_flags, pso->d_flags_alt);
+            }
+            pso->fold_pending = true;   // this launch's own generation waits for the next launch (or flush_fold)
+        } else if (pso->fold_pending) {
+            // (cannot happen: a launch that does not fold a waiting generation reports need_flush above)
+            set_error("internal: deferred fold lost");
+            return NMRFIT_E_STATE;
+        }
         std::swap(pso->d_x, pso->d_x2);   // d_x / d_v: the state the kernel has just written
         std::swap(pso->d_v, pso->d_v2);
     } else {
@@ -681,9 +724,13 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
     // personal-best step finds fp from p without another pointer argument, objective.hip).
     {
         const size_t nposts = (size_t)kSelectMaxPosts;
+        // (fg, best_f, g[D], best_x[D] | generations, stop code): two copies, 256-byte aligned, the flags right behind
+        // the doubles -- the deferred fold of a fused launch reads one and writes the other (PsoFused::flip)
+        const size_t state_bytes = (((size_t)(2 + 2 * D) * sizeof(double) + 2 * sizeof(long long)) + 255) & ~(size_t)255;
         const size_t sizes[] = {(size_t)D * sizeof(double), (size_t)D * sizeof(double), sd, sd, sd, sd,
                                 (size_t)std::max<int64_t>(S_local * D, 0) * sizeof(double) + s1, s1,
-                                (size_t)(D + 1) * sizeof(double), 2 * sizeof(long long), (size_t)(2 + 2 * D) * sizeof(double),
+                                (size_t)(D + 1) * sizeof(double), 2 * state_bytes,
+                                (size_t)std::max<int64_t>(S_local * D, 0) * sizeof(double) + s1,
                                 nposts * sizeof(double), nposts * sizeof(long long), 256};
         size_t off[sizeof(sizes) / sizeof(sizes[0])], total = 0;
         for (size_t i = 0; i < sizeof(sizes) / sizeof(sizes[0]); ++i) {
@@ -703,8 +750,12 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
         pso->d_fx = reinterpret_cast<double *>(base + off[7]);
         pso->d_cand_own = reinterpret_cast<double *>(base + off[8]);
         pso->d_cand = pso->d_cand_own;
-        pso->d_flags = reinterpret_cast<long long *>(base + off[9]);
-        pso->d_best = reinterpret_cast<double *>(base + off[10]);
+        pso->d_best = reinterpret_cast<double *>(base + off[9]);
+        pso->d_flags = reinterpret_cast<long long *>(pso->d_best + 2 + 2 * D);
+        pso->d_p_alt = reinterpret_cast<double *>(base + off[10]);
+        pso->d_best_alt = reinterpret_cast<double *>(base + off[9] + state_bytes);
+        pso->d_flags_alt = reinterpret_cast<long long *>(pso->d_best_alt + 2 + 2 * D);
+        PSO_HIP(hipMemsetAsync(pso->d_best, 0, 2 * state_bytes, ctx->stream));
         pso->d_part_val = reinterpret_cast<double *>(base + off[11]);
         pso->d_part_idx = reinterpret_cast<long long *>(base + off[12]);
         pso->d_ticket = reinterpret_cast<unsigned *>(base + off[13]);
@@ -715,8 +766,6 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
     }
     PSO_HIP(hipMemcpyAsync(pso->d_lb, lower, (size_t)D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PSO_HIP(hipMemcpyAsync(pso->d_ub, upper, (size_t)D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    PSO_HIP(hipMemsetAsync(pso->d_flags, 0, 2 * sizeof(long long), ctx->stream));
-    PSO_HIP(hipMemsetAsync(pso->d_best, 0, (size_t)(2 + 2 * D) * sizeof(double), ctx->stream));
     PSO_HIP(hipStreamSynchronize(ctx->stream));
 #undef PSO_HIP
     *out = pso;
@@ -743,6 +792,7 @@ int nmrfit_pso_init(nmrfit_pso *pso)
     if (rc != NMRFIT_OK) return rc;
     nmrfit_ctx *ctx = pso->ctx;
     const int64_t n = pso->S * pso->D;
+    pso->fold_pending = false;   // (a new swarm: whatever generation was waiting to be folded is gone with the old one)
     NMRFIT_HIP(hipMemsetAsync(pso->d_flags, 0, 2 * sizeof(long long), ctx->stream));
     if (n > 0) {
         hipLaunchKernelGGL(pso_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pso->S, pso->D,
@@ -773,6 +823,9 @@ int nmrfit_pso_candidate_dev(nmrfit_pso *pso, double **dptr)
         set_error("null argument");
         return NMRFIT_E_INVALID;
     }
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;   // (the record of the LAST generation, on the stream before any copy)
     *dptr = pso->d_cand;
     return NMRFIT_OK;
 }
@@ -781,6 +834,7 @@ int nmrfit_pso_set_candidate_dev(nmrfit_pso *pso, double *dptr)
 {
     int rc = bind_pso(pso);
     if (rc != NMRFIT_OK) return rc;
+    if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;
     NMRFIT_HIP(hipStreamSynchronize(pso->ctx->stream));
     double *next = dptr ? dptr : pso->d_cand_own;
     if (next != pso->d_cand) {   // carry the current record over
@@ -802,6 +856,7 @@ int nmrfit_pso_apply_global_dev(nmrfit_pso *pso, const double *d_candidates, int
         set_error("nmrfit_pso_apply_global_dev before nmrfit_pso_init");
         return NMRFIT_E_STATE;
     }
+    if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;
     const int is_init = pso->seeded ? 0 : 1;   // first fold after init sets (g, fg) with no stop test
     hipLaunchKernelGGL(pso_apply_kernel, dim3(1), dim3(kWave), 0, pso->ctx->stream, pso->D, (int)nranks, is_init,
                        pso->prm.minstep, pso->prm.minfunc, d_candidates, pso->d_flags, pso->d_best);
@@ -820,6 +875,7 @@ int nmrfit_pso_set_comm(nmrfit_pso *pso, nmrfit_comm *comm)
         set_error("nmrfit_pso_set_comm: the communicator was created on a different context than the swarm");
         return NMRFIT_E_INVALID;
     }
+    if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;
     NMRFIT_HIP(hipStreamSynchronize(pso->ctx->stream));
     if (pso->comm) comm_attach(pso->comm, -1);
     pso->comm = comm;
@@ -904,6 +960,7 @@ int nmrfit_pso_status(nmrfit_pso *pso, int64_t *iteration, int32_t *stop_code, d
 {
     int rc = bind_pso(pso);
     if (rc != NMRFIT_OK) return rc;
+    if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;
     long long flags[2];
     double head[2];
     hipStream_t st = pso->ctx->stream;
@@ -920,6 +977,7 @@ int nmrfit_pso_best(nmrfit_pso *pso, double *x_best, double *f_best)
 {
     int rc = bind_pso(pso);
     if (rc != NMRFIT_OK) return rc;
+    if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;
     hipStream_t st = pso->ctx->stream;
     if (x_best)
         NMRFIT_HIP(hipMemcpyAsync(x_best, pso->d_best + 2 + pso->D, (size_t)pso->D * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -961,6 +1019,7 @@ int nmrfit_pso_get_state(nmrfit_pso *pso, double *x, double *v, double *p, doubl
 {
     int rc = bind_pso(pso);
     if (rc != NMRFIT_OK) return rc;
+    if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;
     hipStream_t st = pso->ctx->stream;
     const size_t sd = (size_t)(pso->S * pso->D) * sizeof(double), s1 = (size_t)pso->S * sizeof(double);
     if (sd) {

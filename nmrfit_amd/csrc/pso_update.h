@@ -85,20 +85,34 @@ struct PsoFused {
     // pointers (the headline kernel has no scalar register to spare): the swarm keeps fp[S] right behind
     // p[S x D] in one allocation, so fp = p + S*D.
     unsigned pbest = 0;                               // 1: do it (sits in the padding after xrow_off)
-    // ... and, single rank, the REST of the generation too (round 4): every workgroup (= particle) draws a ticket
-    // once its personal best is complete in memory; the one that draws the last reads all of fp, writes the
-    // candidate record and folds it with pyswarm's acceptance / stopping rule -- the generation is ONE launch.
-    // Same hand-over as pso_select_kernel's fence-free form (write-through agent-scope stores completed with
-    // s_waitcnt vmcnt(0) before the ticket, agent-scope loads on the reading side).
-    unsigned tail = 0;                                // 1: do it (swarms of up to kFusedTailMaxS particles)
+    // ... and, single rank, the REST of the generation too (round 4), as a DEFERRED fold (swarms of up to kDeferredPerLane
+    // x 64 x waves-per-workgroup particles): a launch ends with the personal bests and nothing else; the NEXT launch's
+    // prologue -- every workgroup for itself, redundantly, from the same memory -- takes the argmin over fp, reads
+    // the winner's row and folds it with pyswarm's rule before it moves its particle: the generation is ONE launch.
+    // No hand-over inside a launch (the kernel boundary orders everything), and the two memory round trips of
+    // argmin -> row sit at the START of a kernel, next to the loads of the particle's own state, instead of at its
+    // end behind the slowest workgroup.  (g, fg, best, flags) are double-buffered: every workgroup reads the current
+    // block, workgroup 0 writes the other one (`flip` 8-byte words away) and the host swaps them after the launch.
+    // Whoever reads the swarm's state from outside first folds the last generation in a launch of its own (pso.hip,
+    // flush_fold).  (First built with a ticket: every workgroup drew one once its personal best was complete in
+    // memory and the last finished the generation -- 204 x 4096 x 6: 13.4 us per generation against 11.7 this way,
+    // 256: 14.4 / 11.7, and beyond 256 particles the serialised tickets cost more than the launch they saved.)
+    unsigned tail = 0;                                // 1: do it
+    unsigned pending = 0;                             // a generation's personal bests are waiting to be folded
+    int flip = 0;                                     // (other block) - (current block) of best / flags, in 8-byte words
+    // The personal bests are double-buffered too: a workgroup that starts late (a grid of several rounds, a CU busy
+    // with something else) must still see every particle's fp and p of the generation BEFORE this launch, so this
+    // launch reads (p, fp) and writes every particle's row and value -- improved or carried over -- to the other
+    // buffer, `pflip` 8-byte words away; the host swaps after the launch.
+    int pflip = 0;
     double *cand = nullptr;                           // (D+1): candidate record
-    unsigned *ticket = nullptr;
     double minstep = 0.0, minfunc = 0.0;
 };
-// Up to 256 particles: every workgroup's ticket is one returning atomic on ONE address, and they serialise at a
-// few nanoseconds each (measured per generation, one launch against two: 50 particles 11.7 / 14.7 us, 204: 13.9 /
-// 14.9, 512: 19.0 / 17.2, 1024: 30.2 / 25.5) -- the same limit as pso_select_kernel's last-ticket form.
-constexpr int64_t kFusedTailMaxS = 256;
+// fp entries a lane of the deferred fold's argmin looks at, at most: swarms of up to 4 x 64 x waves-per-workgroup
+// particles (1024 with four-wave workgroups: the grids that are resident at once).  Beyond, every workgroup of
+// every round pays the prologue's two memory round trips and the gain is gone (4096 x 65536 x 24 with 16 per
+// lane: 1180 us per generation against 1177 with the separate launch)
+constexpr int kDeferredPerLane = 4;
 
 // Wait until every global store this wave has issued has completed.  For the agent-scope (sc1,
 // write-through) atomic stores used to hand data to other workgroups of a running launch that means:

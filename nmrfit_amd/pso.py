@@ -460,9 +460,10 @@ class DeviceSwarm:
         _cabi.check(self._lib.nmrfit_pso_set_fused_pbest(self._h, 1 if enable else 0))
 
     def set_fused_tail(self, enable=True):
-        """The whole generation in the objective launch (single rank, up to 256 particles, one workgroup per
-        particle, fence-free hand-over): default on; off restores the separate one-workgroup launch for the
-        candidate record and the fold (A/B knob, bit-identical results)."""
+        """The whole generation as one launch (single rank, up to 1024 particles, one workgroup per particle): the
+        objective launch ends with the personal bests and the fold is deferred into the next launch's prologue
+        (csrc/pso_update.h).  Default on; off restores the separate one-workgroup launch for the candidate record
+        and the fold (A/B knob, bit-identical results)."""
         _cabi.check(self._lib.nmrfit_pso_set_fused_tail(self._h, 1 if enable else 0))
 
     def last_launches(self):

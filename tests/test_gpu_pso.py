@@ -476,9 +476,9 @@ def test_handover_stress_short(S, N, P):
             b.set_handover("two_launch")      # ADVICE r3 -- a driver or toolchain change that broke FAST's ordering
             d.set_fused_pbest(False)          # would show here as a difference between a and d)
             d.set_handover("fenced")
-            for sw in (a, b, c, d):           # c: the defaults (where a workgroup is a particle: the whole generation in the objective launch)
+            for sw in (a, b, c, d):           # c: the defaults (a workgroup is a particle: the whole generation in the objective launch, fold deferred)
                 sw.run(gens, check_every=250)
-            assert c.last_launches() == (1 if S <= 256 else 2) and a.last_launches() == 2
+            assert c.last_launches() == 1 and a.last_launches() == 2   # (defaults: the deferred fold, up to 1024 particles)
             sa, sb, sc, sd = a.state(), b.state(), c.state(), d.state()
             for k in ("x", "v", "p", "fx", "fp"):
                 np.testing.assert_array_equal(sa[k], sb[k], err_msg="%s (seed %d)" % (k, seed))
@@ -603,7 +603,7 @@ def test_device_swarm_equals_the_restated_pyswarm_bit_for_bit(problem, S, maxite
     convention for the objective -- ONE particle per call, through the scalar shim -- which gives the batch's
     values bit for bit because f does not depend on the launch geometry.  Same stop generation, same reason,
     same returned (x, f), same final positions and personal bests.  Every select path: one-workgroup tail
-    (64), ticket hand-over (204), personal bests in the objective launch (512), two launches (1500)."""
+    (64), the whole generation in the objective launch with its fold deferred (204, 512), two launches (1500)."""
     from oracle import nmrfit_oracle as onp
     sp, ev = problem
     seed = 4242 + S
@@ -724,14 +724,16 @@ def test_lds_budget_on_both_sides_of_every_threshold(P, fit_im):
 
 
 @pytest.mark.parametrize("S,N,P,variant", [(50, 4096, 6, "default"), (204, 4096, 6, "default"), (204, 16384, 12, "farfield"),
-                                           (256, 2048, 3, "norec"), (257, 4096, 6, "default"), (1024, 4096, 6, "default")])
+                                           (256, 2048, 3, "norec"), (257, 4096, 6, "default"), (1024, 4096, 6, "default"),
+                                           (1025, 4096, 6, "default")])
 def test_one_launch_generation(S, N, P, variant):
-    """Round 4: a single-rank generation of up to 256 particles is ONE launch where a workgroup is a particle -- the
-    objective kernel updates the position, evaluates, updates the personal best, and the workgroup that draws the
-    last ticket makes the candidate record and folds it with pyswarm's rule (the body of pyswarm.pso's loop,
-    nmrfit/utils.py:176-182).  Bit-identical to the two-launch form and to the numpy mirror, with the stopping rule
-    armed (same stop generation, same returned best) and disarmed; larger swarms keep the separate launch (every
-    workgroup's ticket is a returning atomic on one address: beyond ~256 they cost more than the launch saved)."""
+    """Round 4: a single-rank generation of up to 1024 particles (2048 with eight-wave workgroups) is ONE launch where
+    a workgroup is a particle -- the objective kernel updates the position, evaluates and updates the personal best,
+    and the rest of the generation (argmin over fp, candidate record, pyswarm's acceptance / stopping rule: the body
+    of pyswarm.pso's loop, nmrfit/utils.py:176-182) is deferred into the NEXT launch's prologue, every workgroup for
+    itself (csrc/pso_update.h, PsoFused::tail).  Bit-identical to the two-launch form and to the numpy mirror, with
+    the stopping rule armed (same stop generation, same returned best) and disarmed, polled at odd intervals (every
+    poll folds the waiting generation in a launch of its own); larger swarms keep the separate launch."""
     from nmrfit_amd import equations
     sp = synth.make_spectrum(N, P, seed=11)
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
@@ -744,7 +746,7 @@ def test_one_launch_generation(S, N, P, variant):
                 dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=41, **kw)
                 dev.set_fused_tail(fused)
                 dev.run(gens, check_every=9)
-                assert dev.last_launches() == (1 if (fused and S <= 256) else 2), (S, fused, dev.last_launches())
+                assert dev.last_launches() == (1 if (fused and S <= 1024) else 2), (S, fused, dev.last_launches())
                 st = dev.state()
                 for k in ("x", "v", "p", "fx", "fp"):
                     np.testing.assert_array_equal(st[k], getattr(host, k), err_msg="%s fused=%s" % (k, fused))
@@ -757,3 +759,78 @@ def test_one_launch_generation(S, N, P, variant):
                 dev.close()
             if not kw:
                 assert res[True]["stop"] in (1, 2)          # pyswarm's defaults do stop these searches
+
+
+@pytest.mark.parametrize("S,N,P", [(204, 4096, 6), (1024, 4096, 6)])
+def test_deferred_fold_is_invisible_from_outside(S, N, P):
+    """The deferred fold (test_one_launch_generation) leaves the last generation unfolded on the device until the
+    next launch -- or until somebody looks: every entry point that shows or continues the swarm's state folds it
+    first (csrc/pso.hip, flush_fold).  One generation at a time through nmrfit_pso_step with a different reader
+    after each (status, best, state, candidate, none at all), against the numpy mirror at every generation."""
+    from nmrfit_amd import equations
+    sp = synth.make_spectrum(N, P, seed=12)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        kw = dict(minfunc=1e-3, minstep=1e-8)                # stops after some tens of generations: the stop is deferred too
+        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=77, **kw)
+        dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=77, **kw)
+        host.init()
+        host.apply_global(host.candidate()[None, :])
+        dev.init()
+        dev.step()                                           # folds generation 0
+        stopped_at = None
+        for gen in range(1, 121):
+            host.step_local()
+            host.apply_global(host.candidate()[None, :])
+            dev.step()
+            assert dev.last_launches() == 1
+            reader = gen % 5
+            if reader == 0:
+                assert dev.status() == dict(iteration=host.iteration, stop=host.stop, fg=host.fg), gen
+            elif reader == 1:
+                xb, fb = dev.best()
+                np.testing.assert_array_equal(xb, host.best_x)
+                assert fb == host.best_f
+            elif reader == 2:
+                st = dev.state()
+                for k in ("x", "v", "p", "fx", "fp"):
+                    np.testing.assert_array_equal(st[k], getattr(host, k), err_msg="%s at generation %d" % (k, gen))
+            elif reader == 3:
+                np.testing.assert_array_equal(dev.candidate(), host.candidate())
+            if host.stop and stopped_at is None:
+                stopped_at = gen
+        assert stopped_at is not None and stopped_at < 110          # ... and ten more no-op generations after it
+        assert dev.status() == dict(iteration=host.iteration, stop=host.stop, fg=host.fg)
+        st = dev.state()
+        for k in ("x", "v", "p", "fx", "fp"):
+            np.testing.assert_array_equal(st[k], getattr(host, k), err_msg=k)
+        dev.close()
+
+
+def test_deferred_fold_survives_a_change_of_kernel_between_generations():
+    """A generation is waiting to be folded and the next objective launch cannot do it: the caller switched to a
+    kernel variant without the eight-wave workgroup form (204 x 4096 x 6 is then no longer one workgroup per
+    particle).  launch_objective reports it before launching anything, the swarm folds in a launch of its own and
+    goes on in the two-launch form; switching back resumes the one-launch form.  Against the numpy mirror."""
+    from nmrfit_amd import equations
+    S, N, P = 204, 4096, 6
+    sp = synth.make_spectrum(N, P, seed=13)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        kw = dict(minfunc=-1.0, minstep=-1.0)
+        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=5, **kw)
+        dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=5, **kw)
+        host.init()
+        host.apply_global(host.candidate()[None, :])
+        dev.init()
+        dev.step()
+        for variant, launches in (("default", 1), ("quad", 2), ("default", 1), ("single", 2), ("farfield", 1)):
+            ev.set_variant(_cabi.variant_id(variant))
+            for _ in range(7):
+                host.step_local()
+                host.apply_global(host.candidate()[None, :])
+                dev.step()
+                assert dev.last_launches() == launches, (variant, dev.last_launches())
+        st = dev.state()
+        for k in ("x", "v", "p", "fx", "fp"):
+            np.testing.assert_array_equal(st[k], getattr(host, k), err_msg=k)
+        assert dev.status() == dict(iteration=host.iteration, stop=host.stop, fg=host.fg)
+        dev.close()

@@ -41,9 +41,9 @@ SHAPES = {"204": (204, 4096, 6), "256": (256, 4096, 6), "512": (512, 4096, 6), "
 def run(ev, sp, S, seed, gens, mode):
     sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
     if mode == "one_launch":
-        # round 4: the product default for single-rank swarms of up to 256 particles where a workgroup is a particle --
-        # personal best, ticket, candidate record and fold inside the objective launch (--one-launch: this against
-        # TWO_LAUNCH with everything after the objective in kernels of its own)
+        # round 4: the product default for single-rank swarms of up to 1024 particles where a workgroup is a particle --
+        # personal bests inside the objective launch, the fold deferred into the next launch's prologue (--one-launch:
+        # this against TWO_LAUNCH with everything after the objective in kernels of its own)
         pass
     else:
         # the select kernel must run at every shape here: where a workgroup is a particle the product default does the
@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--fenced-every", type=int, default=25)
     ap.add_argument("--seed0", type=int, default=1000)
     ap.add_argument("--one-launch", action="store_true", help="mode A = the one-launch generation (product default, "
-                    "<= 256 particles) instead of the select kernel's fence-free hand-over")
+                    "<= 1024 particles) instead of the select kernel's fence-free hand-over")
     a = ap.parse_args()
     mode_a = "one_launch" if a.one_launch else "fast"
     total_ex = total_posts = total_bad = 0

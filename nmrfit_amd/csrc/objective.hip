@@ -803,6 +803,10 @@ __device__ __forceinline__ void objective_body(
     if constexpr (FIT_IM != 0)   // kTab[16][19], then kFar[12]
         for (int i = threadIdx.x; i < kDawTabCount; i += WPB * kWave)
             dtab[i] = (i < kDawTabFar) ? (&dawson::kTab[0][0])[i] : dawson::kFar[i - kDawTabFar];
+#if defined(NMRFIT_DIAG_NOLOAD) && NMRFIT_DIAG_NOLOAD == 3
+    if constexpr (FIT_IM == 0)   // (the region the diagnostic loads read: zeros; a barrier follows the staging below)
+        for (int i = threadIdx.x; i < 4 * kChunk; i += WPB * kWave) reinterpret_cast<double *>(lds_raw + aux_off)[i] = 0.0;
+#endif
     phase_stamp(clk, 0);
     if (clk && g == 0 && lane == 0) {   // nmrfit_prof_*: ticks of the core clock and of the 100 MHz reference
         clk[0] = __builtin_amdgcn_s_memtime();
@@ -1289,7 +1293,15 @@ __device__ __forceinline__ void objective_body(
                 }
             }
         } else if (full) {
-#if defined(NMRFIT_DIAG_NOLOAD) && NMRFIT_DIAG_NOLOAD >= 2   // diagnostic: no grid loads (values are wrong on purpose)
+#if defined(NMRFIT_DIAG_NOLOAD) && NMRFIT_DIAG_NOLOAD == 3   // diagnostic: the loads come from LDS (garbage) instead of memory
+            const double2 *wp = reinterpret_cast<const double2 *>(lds_raw + aux_off) + lane;
+#pragma unroll
+            for (int m = 0; m < kPointsPerLane / 2; ++m) {
+                const double2 d = wp[m * kWave];
+                wv[2 * m] = d.x + (double)(jl + 2 * m * kWave) * (lane_step * (1.0 / 64.0)) - wspan;
+                wv[2 * m + 1] = d.y + (double)(jl + (2 * m + 1) * kWave) * (lane_step * (1.0 / 64.0)) - wspan;
+            }
+#elif defined(NMRFIT_DIAG_NOLOAD) && NMRFIT_DIAG_NOLOAD >= 2   // diagnostic: no grid loads (values are wrong on purpose)
 #pragma unroll
             for (int q = 0; q < kPointsPerLane; ++q) wv[q] = (double)(jl + q * kWave) * (lane_step * (1.0 / 64.0)) - wspan;
 #else
@@ -1658,7 +1670,19 @@ __device__ __forceinline__ void objective_body(
                 tq[q] = stage[2 * kChunk + o];
             }
         } else if (full) {
-#if defined(NMRFIT_DIAG_NOLOAD) && NMRFIT_DIAG_NOLOAD >= 1   // diagnostic: no data loads (values are wrong on purpose)
+#if defined(NMRFIT_DIAG_NOLOAD) && NMRFIT_DIAG_NOLOAD == 3   // diagnostic: the loads come from LDS (garbage) instead of memory
+            const double2 *up = reinterpret_cast<const double2 *>(lds_raw + aux_off) + kChunk / 2 + lane, *vp = up + kChunk / 2, *tp = vp + kChunk / 2;
+#pragma unroll
+            for (int m = 0; m < kPointsPerLane / 2; ++m) {
+                const double2 du = up[m * kWave], dv = vp[m * kWave], dt = tp[m * kWave];
+                uq[2 * m] = du.x + (double)(lane + 2 * m) * 1.0e-3;
+                uq[2 * m + 1] = du.y + (double)(lane + 2 * m + 1) * 1.0e-3;
+                vq[2 * m] = dv.x + (double)(lane - 2 * m) * 1.0e-3;
+                vq[2 * m + 1] = dv.y + (double)(lane - 2 * m - 1) * 1.0e-3;
+                tq[2 * m] = dt.x + 1.0;
+                tq[2 * m + 1] = dt.y + 1.125;
+            }
+#elif defined(NMRFIT_DIAG_NOLOAD) && NMRFIT_DIAG_NOLOAD >= 1   // diagnostic: no data loads (values are wrong on purpose)
 #pragma unroll
             for (int q = 0; q < kPointsPerLane; ++q) {
                 uq[q] = (double)(lane + q) * 1.0e-3;
@@ -2069,6 +2093,13 @@ static size_t resolve_variant(const nmrfit_ctx *ctx, int32_t P, bool residual, i
                  ((variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_DEFAULT) ? lds_rec : 0) +
                  (variant == NMRFIT_VARIANT_DEFAULT ? lds_fast : 0);
     *aux_off = 0;
+#if defined(NMRFIT_DIAG_NOLOAD) && NMRFIT_DIAG_NOLOAD == 3   // diagnostic: one chunk of the four arrays' worth of LDS to read from
+    if (!lds_tab) {
+        lds = (lds + 15) & ~(size_t)15;
+        *aux_off = (unsigned)lds;
+        lds += 4 * kChunk * sizeof(double);
+    }
+#endif
     if (lds_tab) {
         lds = (lds + 15) & ~(size_t)15;
         *aux_off = (unsigned)lds;

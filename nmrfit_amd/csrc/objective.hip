@@ -230,6 +230,30 @@ __device__ __forceinline__ void phase_stamp(unsigned long long *clk, int i)
 #endif
 }
 
+// A wave-uniform pointer / value moved to VECTOR registers once, opaquely: what the swarm-generation prologue does with
+// the ~20 pointers and constants of PsoFused.  Left to itself the compiler keeps all of them in scalar registers from the
+// kernel's first instruction, runs out, and parks the grid-array pointers of the CHUNK LOOP in VGPR lanes instead -- a
+// v_readlane per pointer per chunk (+1.9 % VALU instructions in every launch, swarm generation or not; measured).
+template <class T>
+__device__ __forceinline__ const T __attribute__((address_space(1))) *vector_ptr(const T *p)
+{
+    unsigned lo = (unsigned)(uintptr_t)p, hi = (unsigned)((uintptr_t)p >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return reinterpret_cast<const T __attribute__((address_space(1))) *>(((uintptr_t)hi << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ T __attribute__((address_space(1))) *vector_ptr_rw(const T *p)
+{
+    unsigned lo = (unsigned)(uintptr_t)p, hi = (unsigned)((uintptr_t)p >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return reinterpret_cast<T __attribute__((address_space(1))) *>(((uintptr_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double vector_f64(double x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // Address of a lane's 16-byte pair in a chunk: wave-uniform base + 16 * lane, with the lane part made opaque at the
 // point of use -- otherwise the compiler hoists `array + lane` out of the chunk loop as a 64-bit per-lane pointer for
 // each of the four arrays (8 VGPRs held across the loop, a v_lshl_add_u64 per array per chunk) instead of using the
@@ -907,6 +931,15 @@ __device__ __forceinline__ void objective_body(
             stage_peaks(X + particle * D, first_pass, pass_stride);
     };
     if (fused) {
+        // (see vector_ptr: the swarm's pointers and constants live in vector registers for the length of this block)
+        const auto gx_in = vector_ptr(upd.x_in), gv_in = vector_ptr(upd.v_in), gp = vector_ptr(upd.p);
+        const auto gbest = vector_ptr(upd.best), glb = vector_ptr(upd.lb), gub = vector_ptr(upd.ub);
+        const auto gflags = vector_ptr(upd.flags);
+        const auto gx_out = vector_ptr_rw(upd.x_out), gv_out = vector_ptr_rw(upd.v_out), gp_rw = vector_ptr_rw(upd.p);
+        const auto gbest_rw = vector_ptr_rw(upd.best), gcand = vector_ptr_rw(upd.cand);
+        const auto gflags_rw = vector_ptr_rw(upd.flags);
+        const double q_omega = vector_f64(upd.omega), q_phip = vector_f64(upd.phip), q_phig = vector_f64(upd.phig);
+        const double q_minstep = vector_f64(upd.minstep), q_minfunc = vector_f64(upd.minfunc);
         // Swarm generation: the velocity / position update of this particle happens HERE, in the
         // prologue of the kernel that evaluates it (one launch fewer per generation).  Every wave of
         // the particle computes the same new row into its own LDS slice; the wave of segment 0 also
@@ -924,18 +957,18 @@ __device__ __forceinline__ void objective_body(
         const int64_t idx0 = particle * D + lane;
         double x0 = 0.0, v0 = 0.0, pold0 = 0.0, lo0 = 0.0, hi0 = 0.0, g0 = 0.0, fg = 0.0;
         if (updater || !deferred) {   // (deferred form: wave 0 tells the workgroup what the fold said, through LDS)
-            gen_done = upd.flags[0];
-            stop_code = upd.flags[1];
+            gen_done = gflags[0];
+            stop_code = gflags[1];
         }
         if (updater) {
-            if (deferred) fg = upd.best[0];
+            if (deferred) fg = gbest[0];
             if (have0) {
-                x0 = upd.x_in[idx0];
-                v0 = upd.v_in[idx0];
-                pold0 = upd.p[idx0];
-                lo0 = upd.lb[lane];
-                hi0 = upd.ub[lane];
-                g0 = upd.best[2 + lane];
+                x0 = gx_in[idx0];
+                v0 = gv_in[idx0];
+                pold0 = gp[idx0];
+                lo0 = glb[lane];
+                hi0 = gub[lane];
+                g0 = gbest[2 + lane];
             }
         }
         double rp0 = 0.0, rg0 = 0.0;   // the first entry's uniforms (deferred form: drawn while the winner's row is on its way)
@@ -945,7 +978,7 @@ __device__ __forceinline__ void objective_body(
             // particle moves, its workgroup works out what the swarm's best is NOW -- as every other workgroup does,
             // from the same memory with the same operations (pso_update.h apply_wave, pso.hip argmin_block).
             if (upd.pending != 0u) {   // every wave: first index of the minimum over its share of fp
-                const double *fpb = upd.p + S * D;
+                const auto fpb = gp + S * D;
                 const int kper = (int)((S + WPB * kWave - 1) / (WPB * kWave));   // <= kDeferredPerLane (launch_objective)
                 const int64_t base = (int64_t)wave * kper * kWave + lane;
                 double vv[kDeferredPerLane];
@@ -992,7 +1025,7 @@ __device__ __forceinline__ void objective_body(
                         }
                     }
                     if (bi >= S) bi = 0;   // every fp is +inf: np.argmin -> 0, and the row is x[0] (pso.hip, argmin_block)
-                    const double *src = (fc < INFINITY) ? upd.p + bi * D : upd.x_in;
+                    const auto src = (fc < INFINITY) ? gp + bi * D : gx_in;
                     const double c0 = have0 ? src[lane] : 0.0;   // the second (and last) round trip of the prologue
                     if (stop_code == 0) gen_done += 1;   // (after a stop nothing folds and nothing counts: pso_apply_kernel)
                     if (have0 && stop_code == 0) {       // meanwhile: this generation's uniforms of entry `lane`
@@ -1010,7 +1043,7 @@ __device__ __forceinline__ void objective_body(
                             acc += df * df;
                         }
                         for (int64_t d = lane + kWave; d < D; d += kWave) {
-                            const double c = src[d], gd = upd.best[2 + d];
+                            const double c = src[d], gd = gbest[2 + d];
                             crow[d] = c;
                             grow[d] = gd;
                             const double df = gd - c;
@@ -1020,9 +1053,9 @@ __device__ __forceinline__ void objective_body(
                             for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
                             acc = __shfl(acc, 0, 64);
                             const double stepsize = sqrt(acc);
-                            if (fabs(fg - fc) <= upd.minfunc)
+                            if (fabs(fg - fc) <= q_minfunc)
                                 code = 1;
-                            else if (stepsize <= upd.minstep)
+                            else if (stepsize <= q_minstep)
                                 code = 2;
                             else
                                 code = 3;
@@ -1031,20 +1064,20 @@ __device__ __forceinline__ void objective_body(
                     }
                     wave_lds_fence();
                     if (particle == 0) {   // ONE writer of the other state block (nobody reads it in this launch)
-                        double *bo = const_cast<double *>(upd.best) + upd.flip;
-                        long long *fo = const_cast<long long *>(upd.flags) + upd.flip;
+                        auto bo = gbest_rw + upd.flip;
+                        auto fo = gflags_rw + upd.flip;
                         for (int64_t d = lane; d < D; d += kWave) {
                             const double c = crow[d];
                             bo[2 + d] = (code == 3) ? c : grow[d];
-                            bo[2 + D + d] = (code != 0) ? c : upd.best[2 + D + d];
-                            upd.cand[1 + d] = c;
+                            bo[2 + D + d] = (code != 0) ? c : gbest[2 + D + d];
+                            gcand[1 + d] = c;
                         }
                         if (lane == 0) {
                             bo[0] = (code == 3) ? fc : fg;
-                            bo[1] = (code != 0) ? fc : upd.best[1];
+                            bo[1] = (code != 0) ? fc : gbest[1];
                             fo[0] = gen_done;
                             fo[1] = stop_code;
-                            upd.cand[0] = fc;
+                            gcand[0] = fc;
                         }
                     }
                     if (code == 3) {
@@ -1053,7 +1086,7 @@ __device__ __forceinline__ void objective_body(
                     }
                     wave_lds_fence();
                 } else {
-                    for (int64_t d = lane + kWave; d < D; d += kWave) grow[d] = upd.best[2 + d];
+                    for (int64_t d = lane + kWave; d < D; d += kWave) grow[d] = gbest[2 + d];
                     wave_lds_fence();
                 }
                 if (lane == 0) wsums[2 * kMaxBlocks + 6] = (stop_code != 0) ? 1.0 : 0.0;
@@ -1070,31 +1103,31 @@ __device__ __forceinline__ void objective_body(
         for (int64_t d = lane; d < D; d += kWave) {
             const int64_t idx = particle * D + d;
             const bool first = d < kWave;
-            double xn = first ? x0 : upd.x_in[idx], vn = first ? v0 : upd.v_in[idx];
-            const double pold = first ? pold0 : upd.p[idx];
+            double xn = first ? x0 : gx_in[idx], vn = first ? v0 : gv_in[idx];
+            const double pold = first ? pold0 : gp[idx];
             // (two loads and a select of VALUES: a select between an LDS and a global address crashes this compiler)
             double g_lds = 0.0, g_mem = 0.0;
             if (!first && deferred) g_lds = grow[d];
-            if (!first && !deferred) g_mem = upd.best[2 + d];
+            if (!first && !deferred) g_mem = gbest[2 + d];
             const double gd = first ? g0 : deferred ? g_lds : g_mem;
-            const double lo = first ? lo0 : upd.lb[d], hi = first ? hi0 : upd.ub[d];
+            const double lo = first ? lo0 : glb[d], hi = first ? hi0 : gub[d];
             if (deferred) {   // the personal best as it stands: for the kernel's end (row 2 is free again), or carried over now
                 crow[d] = pold;
-                if (stopped) const_cast<double *>(upd.p)[upd.pflip + idx] = pold;
+                if (stopped) gp_rw[upd.pflip + idx] = pold;
             }
             if (!stopped) {
                 double rp = rp0, rg = rg0;
                 if (!(first && drawn0)) uniform2(upd.seed, gen, (uint32_t)d, (uint64_t)(upd.offset + particle), &rp, &rg);
-                xn = update_value(xn, vn, pold, gd, lo, hi, rp, rg, upd.omega, upd.phip, upd.phig, &vn);
+                xn = update_value(xn, vn, pold, gd, lo, hi, rp, rg, q_omega, q_phip, q_phig, &vn);
             }
             xrow[d] = xn;
             if (active && seg == 0) {
-                upd.x_out[idx] = xn;
-                upd.v_out[idx] = vn;
+                gx_out[idx] = xn;
+                gv_out[idx] = vn;
             }
         }
         if (deferred && stopped && wave == 0 && lane == 0)   // (after a stop: the value is carried over like the rows)
-            const_cast<double *>(upd.p)[upd.pflip + S * D + particle] = upd.p[S * D + particle];
+            gp_rw[upd.pflip + S * D + particle] = gp[S * D + particle];
         if (!deferred && stopped) return;   // the same for every wave of the grid
         phase_stamp(clk, 1);   // position update done
         if (shared) __syncthreads();   // wave 0's row is every wave's input
@@ -1816,13 +1849,14 @@ __device__ __forceinline__ void objective_body(
                 const double *row = reinterpret_cast<const double *>(lds_raw + (unsigned)__double_as_longlong(wsums[2 * kMaxBlocks + 4]));
                 const int ln = threadIdx.x & (kWave - 1);
                 const double fp_old = wsums[2 * kMaxBlocks + 5];   // (requested by the kernel's first instructions)
-                if (upd.tail != 0u) {
+                const long long pflip = __double_as_longlong(wsums[2 * kMaxBlocks + 7]);   // (0: no deferred fold)
+                if (pflip != 0) {
                     // deferred form: the other (p, fp) buffer gets this particle's row and value whether it improved
                     // or not (PsoFused::pflip; the old row was parked in row 2 of the LDS area by the prologue)
                     const bool better = f < fp_old;
                     const double *keep = row + 2 * D2;
-                    for (int64_t d = ln; d < D2; d += kWave) pb[upd.pflip + part * D2 + d] = better ? row[d] : keep[d];
-                    if (ln == 0) fpb[upd.pflip + part] = better ? f : fp_old;
+                    for (int64_t d = ln; d < D2; d += kWave) pb[pflip + part * D2 + d] = better ? row[d] : keep[d];
+                    if (ln == 0) fpb[pflip + part] = better ? f : fp_old;
                     phase_stamp(clk, 5);   // personal best on its way to memory
                 } else if (f < fp_old) {
                     for (int64_t d = ln; d < D2; d += kWave) pb[part * D2 + d] = row[d];
@@ -1889,6 +1923,8 @@ __global__ __launch_bounds__(kWave *WPB, (WPB == kWavesPerBlock) ? NMRFIT_OBJECT
         // this particle's personal-best value, requested NOW: a memory round trip off the end of the kernel's
         // critical path (nobody else writes it in this launch)
         if (pbest && nseg == WPB) wsums[2 * kMaxBlocks + 5] = upd.p[S * (4 + 3 * (int64_t)P) + blockIdx.x];
+        // deferred fold: where the other (p, fp) buffer is (never 0 then) -- read back by the personal-best step
+        wsums[2 * kMaxBlocks + 7] = __longlong_as_double((pbest && upd.tail != 0u) ? (long long)upd.pflip : 0LL);
     }
 #ifdef NMRFIT_DIAG_REMAP
     // block b, wave w -> particle 4*(b / nseg) + w, segment b % nseg (S a multiple of 4)

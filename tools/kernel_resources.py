@@ -54,7 +54,7 @@ def main():
     extra = [a for a in sys.argv[1:] if a != "--check"]
     rows = resources(extra)
     bad = []
-    print("%-58s %5s %5s %8s %6s %8s" % ("kernel", "VGPR", "AGPR", "scratch", "waves", "LDS"))
+    print("%-58s %5s %5s %8s %6s %8s %8s" % ("kernel", "VGPR", "AGPR", "scratch", "waves", "LDS", "s-spill"))
     for r in rows:
         name = r["pretty"]
         m = re.match(r"objective_kernel<(\d+), (true|false), (\d+), (\d+)>", name)
@@ -66,8 +66,11 @@ def main():
                                                             ",8 waves" if m.group(4) == "8" else "")
             selectable = v in (0, 6, 7)
         scratch = int(r.get("ScratchSize [bytes/lane]", "0"))
-        print("%-58s %5s %5s %8d %6s %8s" % (label[:58], r.get("VGPRs", "?"), r.get("AGPRs", "?"), scratch,
-                                            r.get("Occupancy [waves/SIMD]", "?"), r.get("LDS Size [bytes/block]", "?")))
+        # (s-spill: scalar registers parked in VGPR lanes -- v_writelane / v_readlane, which are VALU instructions: in a
+        # loop they cost issue slots like arithmetic does)
+        print("%-58s %5s %5s %8d %6s %8s %8s" % (label[:58], r.get("VGPRs", "?"), r.get("AGPRs", "?"), scratch,
+                                                r.get("Occupancy [waves/SIMD]", "?"), r.get("LDS Size [bytes/block]", "?"),
+                                                r.get("SGPRs Spill", "?")))
         if selectable and scratch:
             bad.append(label)
     if check and bad:

@@ -184,6 +184,53 @@ def usable_cores():
     return max(1, min(n, 16))     # a one-GPU box's CPU share
 
 
+class PowerProbe:
+    """Socket power and shader clock of ONE device from its hwmon files (plain reads of sysfs, no child process):
+    /sys/bus/pci/devices/<pci id>/hwmon/hwmon*/{power1_input (or power1_average), power1_cap, freq1_input}.  Sampled by
+    the main thread between batches of the pre-heat launches: under this fp64 load an MI355X sits at its power cap
+    and the clock is what is left -- the line should say so with this run's own numbers."""
+
+    def __init__(self, pci):
+        import glob
+        self.dir, self.samples = None, []
+        try:
+            cand = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % pci.strip().lower())
+            self.dir = cand[0] if cand else None
+        except Exception:
+            self.dir = None
+
+    def _read(self, *names):
+        for n in names:
+            try:
+                with open(os.path.join(self.dir, n)) as f:
+                    return float(f.read().strip())
+            except Exception:
+                continue
+        return None
+
+    def sample(self):
+        if self.dir is None:
+            return
+        w, hz = self._read("power1_input", "power1_average"), self._read("freq1_input")
+        if w is not None and hz is not None:
+            self.samples.append((w * 1e-6, hz * 1e-6))
+
+    def summary(self):
+        if self.dir is None or not self.samples:
+            return None
+        cap = self._read("power1_cap")
+        tail = self.samples[len(self.samples) // 2:]          # the second half of the pre-heat: the loaded state
+        return {"socket_power_w": sum(q[0] for q in tail) / len(tail), "socket_power_w_max": max(q[0] for q in self.samples),
+                "power_cap_w": None if cap is None else cap * 1e-6,
+                "sclk_mhz": sum(q[1] for q in tail) / len(tail), "sclk_mhz_nominal": 2400.0, "samples": len(self.samples),
+                "source": self.dir,
+                "note": "hwmon readings between batches of the pre-heat launches (the same kernel on the same positions, "
+                        "right before the timed region; the power reading is a running average that is still rising after "
+                        "half a second -- it settles at 1320-1380 W, profiles/r04/power_and_clock_under_load.txt): the part "
+                        "is power-limited under this fp64 load and the clock is what is left, which is why the kernel time "
+                        "differs from box to box"}
+
+
 def cpu_baseline(spec, P, budget_s, pool_procs):
     """Reference-plumbing baseline: the numpy oracle, one particle per call, 1 core; then the
     reference's parallel mode (Pool.map over particles) and the plain-C OpenMP oracle."""
@@ -445,7 +492,7 @@ def main():
     if device_note:
         sys.stderr.write("bench.py rank %d/%d: %s\n" % (rank, world, device_note))
     try:      # looked up now: the watchdog thread must not make HIP calls while the main thread is stuck in one
-        pci = _cabi.device_pci_bus_id(device) if use_dist else "-"
+        pci = _cabi.device_pci_bus_id(device)
     except _cabi.NmrfitError as e:
         pci = "unknown (%s)" % e
     place.update(device=device, pci=pci, note=device_note)
@@ -543,11 +590,13 @@ def main():
     ev.upload(d_x, sw.state()["x"])
     t0 = time.perf_counter()
     heat_launches = 0
+    power = PowerProbe(pci)
     while time.perf_counter() - t0 < args.preheat_seconds:
         for _ in range(8):
             ev.objective_batch_dev(S_local, P, d_x, d_f)
         ev.synchronize()
         heat_launches += 8
+        power.sample()
     ev.prof_enable(args.steps)
 
     dog.phase = "barrier before the timed region"
@@ -848,6 +897,7 @@ def main():
         elif world > 1 and rccl_info is not None and rccl_info["ranks_counted_by_all_reduce"] != world:
             line["error"] = "RCCL counted %d ranks, expected %d" % (rccl_info["ranks_counted_by_all_reduce"], world)
             rc = 5
+        line["power"] = power.summary()      # (null where the hwmon files are not readable)
         if ranks is not None:
             line["ranks"] = ranks
         if variants is not None:

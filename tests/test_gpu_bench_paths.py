@@ -69,6 +69,13 @@ def test_bench_paths_agree():
     ds = plain["dense_spectrum"]
     assert ds["kernel_ms"] > 0 and ds["units_per_s"] == pytest.approx(512 * 4096 * 6 / (ds["kernel_ms"] * 1e-3))
     assert ds["farfield"]["kernel_ms"] > 0 and "broad overlapping" in ds["spectrum"]
+    # socket power and shader clock from the device's hwmon files (null where they are not readable): this run's own
+    # evidence that the part sits at its power cap under the fp64 load and the clock is what is left
+    assert "power" in plain
+    if plain["power"] is not None:
+        pw = plain["power"]
+        assert pw["samples"] >= 1 and 50.0 < pw["socket_power_w"] <= 1.1 * (pw["power_cap_w"] or 2000.0)
+        assert 90.0 < pw["sclk_mhz"] < 3000.0 and "/hwmon" in pw["source"]
     rccl = _run([sys.executable, "bench.py", "--swarm-per-gpu", "512"] + common, {"NMRFIT_BENCH_FORCE_DIST": "1"})
     assert rccl["config"]["swarm_best_f"] == plain["config"]["swarm_best_f"]
     assert "ncclAllGather" in rccl["config"]["exchange"]

@@ -834,3 +834,78 @@ def test_deferred_fold_survives_a_change_of_kernel_between_generations():
             np.testing.assert_array_equal(st[k], getattr(host, k), err_msg=k)
         assert dev.status() == dict(iteration=host.iteration, stop=host.stop, fg=host.fg)
         dev.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_walk_over_the_swarm_interface_matches_the_mirror(seed):
+    """Differential fuzz of the C-ABI's swarm entry points around the deferred fold: a random sequence of generations
+    (one call, several calls, nmrfit_pso_run, host-staged step_local + apply_global), readers (status, best, state,
+    candidate), knob changes (fused tail / fused personal bests / hand-over mode) and kernel-variant changes on ONE
+    swarm -- after every operation that reads, the device must equal the numpy mirror bit for bit, and at the end
+    everything must.  Whatever the order, no entry point may see, or continue from, an unfolded generation."""
+    from nmrfit_amd import equations
+    rng = np.random.default_rng(seed)
+    S, N, P = (204, 4096, 6) if seed != 3 else (640, 4096, 6)
+    sp = synth.make_spectrum(N, P, seed=20 + seed)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        kw = dict(minfunc=-1.0, minstep=-1.0) if seed != 2 else dict(minfunc=3e-4, minstep=1e-8)
+        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=900 + seed, **kw)
+        dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=900 + seed, **kw)
+        host.init()
+        host.apply_global(host.candidate()[None, :])
+        dev.init()
+        dev.step()
+
+        def host_generations(n):
+            for _ in range(n):
+                host.step_local()
+                host.apply_global(host.candidate()[None, :])
+
+        def check_all(tag):
+            st = dev.state()
+            for k in ("x", "v", "p", "fx", "fp"):
+                np.testing.assert_array_equal(st[k], getattr(host, k), err_msg="%s after %s" % (k, tag))
+            assert dev.status() == dict(iteration=host.iteration, stop=host.stop, fg=host.fg), tag
+            xb, fb = dev.best()
+            np.testing.assert_array_equal(xb, host.best_x, err_msg=tag)
+            assert fb == host.best_f, tag
+
+        log = []
+        for op_i in range(160):
+            op = int(rng.integers(0, 14))
+            log.append(op)
+            tag = "op %d (#%d of %s)" % (op, op_i, log[-12:])
+            if op <= 3:                       # one generation, one call
+                dev.step()
+                host_generations(1)
+            elif op == 4:                     # a few generations through the run loop (polls every 2 or 5)
+                n = int(rng.integers(1, 9))
+                if not host.stop:             # (nmrfit_pso_run counts its own iterations: after a stop it returns at the first poll)
+                    dev.run(n, check_every=int(rng.choice([2, 5])))
+                    host_generations(n)
+            elif op == 5:                     # the host-staged form of a generation
+                dev.step_local()
+                dev.apply_global(dev.candidate()[None, :])
+                host_generations(1)
+            elif op == 6:
+                assert dev.status() == dict(iteration=host.iteration, stop=host.stop, fg=host.fg), tag
+            elif op == 7:
+                xb, fb = dev.best()
+                np.testing.assert_array_equal(xb, host.best_x, err_msg=tag)
+                assert fb == host.best_f, tag
+            elif op == 8:
+                np.testing.assert_array_equal(dev.candidate(), host.candidate(), err_msg=tag)
+            elif op == 9:
+                check_all(tag)
+            elif op == 10:
+                dev.set_fused_tail(bool(rng.integers(0, 2)))
+            elif op == 11:
+                dev.set_fused_pbest(bool(rng.integers(0, 2)))
+            elif op == 12:
+                dev.set_handover(str(rng.choice(["fast", "fenced", "two_launch"])))
+            elif op == 13:                    # another kernel for the generations that follow (the mirror evaluates through the same context)
+                ev.set_variant(_cabi.variant_id(str(rng.choice(["default", "farfield", "norec", "quad", "staged"]))))
+        check_all("the end (%s)" % log[-12:])
+        if seed == 2:
+            assert host.stop in (1, 2)        # this one stops on the way: the no-op generations after it are part of the walk
+        dev.close()

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 namespace nmrfit {
@@ -37,6 +39,57 @@ int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need)
     NMRFIT_HIP(hipMalloc((void **)buf, (size_t)n * sizeof(double)));
     *cap = n;
     return NMRFIT_OK;
+}
+
+// A context's own stream, recycled: a new HIP stream costs about 4 ms on this stack when it is first used (the hardware
+// queue behind it is made then; measured, tools/archive/hip_call_costs.hip) and a whole default fit is 25 ms -- a fit
+// that pyswarm's rule stops after a few hundred generations 3 ms.  Contexts that come and go (one per fitted spectrum)
+// hand their idle stream to the next one on the same device instead.  NMRFIT_NO_STREAM_CACHE=1 turns it off.
+namespace {
+struct StreamPool {
+    std::mutex lock;
+    std::vector<std::pair<int, hipStream_t>> idle;
+};
+StreamPool &stream_pool()
+{
+    static StreamPool *pool = new StreamPool;   // (never destroyed: no order-of-destruction trouble at process exit)
+    return *pool;
+}
+constexpr size_t kMaxIdleStreams = 16;
+bool stream_cache_on()
+{
+    static const bool on = getenv("NMRFIT_NO_STREAM_CACHE") == nullptr;
+    return on;
+}
+}  // namespace
+
+static hipError_t take_stream(int device, hipStream_t *out)
+{
+    if (stream_cache_on()) {
+        StreamPool &pool = stream_pool();
+        std::lock_guard<std::mutex> guard(pool.lock);
+        for (size_t i = 0; i < pool.idle.size(); ++i)
+            if (pool.idle[i].first == device) {
+                *out = pool.idle[i].second;
+                pool.idle.erase(pool.idle.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+// (the caller has synchronised the stream: nothing is queued on it)
+static void give_stream(int device, hipStream_t s)
+{
+    if (stream_cache_on()) {
+        StreamPool &pool = stream_pool();
+        std::lock_guard<std::mutex> guard(pool.lock);
+        if (pool.idle.size() < kMaxIdleStreams) {
+            pool.idle.emplace_back(device, s);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(s);
 }
 
 static int bind(const nmrfit_ctx *ctx)
@@ -220,7 +273,7 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
             return _rc;                                                            \
         }                                                                          \
     } while (0)
-    CTX_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    CTX_HIP(take_stream(device, &ctx->own_stream));
     ctx->stream = ctx->own_stream;
     CTX_HIP(hipEventCreate(&ctx->ev0));
     CTX_HIP(hipEventCreate(&ctx->ev1));
@@ -263,14 +316,17 @@ int nmrfit_ctx_destroy(nmrfit_ctx *ctx)
 {
     if (!ctx) return NMRFIT_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    }
     void *bufs[] = {ctx->d_block /* wc, u, v, weights, chunk table, landing buffer */, ctx->d_X, ctx->d_f, ctx->d_partial, ctx->d_R};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     (void)nmrfit_prof_enable(ctx, 0);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->own_stream) give_stream(ctx->device, ctx->own_stream);   // (synchronised above)
     delete ctx;
     return NMRFIT_OK;
 }

@@ -280,14 +280,25 @@ def test_non_finite_parameters_do_not_crash(eq):
 
 
 def test_context_churn_does_not_leak(eq):
+    """Contexts that come and go (one per fitted spectrum) while another stays: the library recycles a closed
+    context's idle HIP stream for the next one on the device (a new stream costs ~4 ms at first use, a default fit
+    ~25 ms; csrc/cabi.hip) -- never a stream that a live context still owns."""
     sp = synth.make_spectrum(4096, 2, seed=81)
     X = synth.make_swarm(sp["lower"], sp["upper"], 8, seed=82)
+    sp2 = synth.make_spectrum(3000, 5, seed=83)
+    X2 = synth.make_swarm(sp2["lower"], sp2["upper"], 40, seed=84)
     f0 = None
-    for _ in range(200):
-        with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
-            f = ev.objective_batch(X)
-        f0 = f if f0 is None else f0
-        np.testing.assert_array_equal(f, f0)
+    with eq.Evaluator(sp2["w"], sp2["u"], sp2["v"], sp2["weights"]) as stays:
+        g0 = stays.objective_batch(X2)
+        for it in range(200):
+            with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+                d2 = stays.dev_alloc(X2.nbytes) if it % 7 == 0 else None      # (work queued on the long-lived context's stream
+                f = ev.objective_batch(X)                                      # while the short-lived one runs on its own)
+                np.testing.assert_array_equal(stays.objective_batch(X2), g0)
+                if d2 is not None:
+                    stays.dev_free(d2)
+            f0 = f if f0 is None else f0
+            np.testing.assert_array_equal(f, f0)
 
 
 def test_farfield_variant_full_size_and_geometry(eq):

@@ -27,3 +27,26 @@ def fit(data, lower, upper, expon=0.5, dynamic_weighting=True, fit_im=False, pro
     f = utils.FitUtility(data, lower, upper, expon, dynamic_weighting, fit_im, processes, summary, options)
     f.fit()
     return f
+
+
+def fit_many(jobs, threads=4, **kwargs):
+    """Fit several spectra at once: ``jobs`` is a sequence of ``(data, lower, upper)`` triples (or dicts of ``fit``'s
+    arguments), each fitted by ``fit`` with the same keyword arguments, on ``threads`` host threads.  Not in the
+    reference (its users loop over ``nmrfit.fit``, nmrfit/core.py:64); here a 204-particle swarm fills a fraction
+    of an MI355X, every fit has its own context and HIP stream and the library releases the GIL inside its calls,
+    so independent fits overlap on the device: about 2.2x the fits per second of a plain loop with four threads
+    (tools/concurrent_fits.py).  Results come back in the order of ``jobs`` and are the ones the plain loop gives
+    (the swarm's random numbers depend on ``options['seed']`` only).  ``summary`` defaults to False here."""
+    from concurrent.futures import ThreadPoolExecutor
+    kwargs.setdefault("summary", False)
+
+    def one(job):
+        if isinstance(job, dict):
+            return fit(**dict(kwargs, **job))
+        data, lower, upper = job
+        return fit(data, lower, upper, **kwargs)
+    jobs = list(jobs)
+    if threads <= 1 or len(jobs) <= 1:
+        return [one(j) for j in jobs]
+    with ThreadPoolExecutor(max_workers=int(threads)) as pool:
+        return list(pool.map(one, jobs))

@@ -909,3 +909,24 @@ def test_random_walk_over_the_swarm_interface_matches_the_mirror(seed):
         if seed == 2:
             assert host.stop in (1, 2)        # this one stops on the way: the no-op generations after it are part of the walk
         dev.close()
+
+
+def test_fit_many_matches_the_plain_loop():
+    """nmrfit_amd.fit_many: several spectra fitted at once on host threads (one context and HIP stream per fit, the
+    GIL released inside the library's calls) -- the same results, in order, as looping over nmrfit_amd.fit like the
+    reference's users loop over nmrfit.fit (nmrfit/core.py:64)."""
+    import nmrfit_amd
+    jobs = []
+    for k in range(5):
+        sp = synth.make_spectrum(2048 + 512 * k, 3 + k, seed=300 + k)
+        jobs.append((synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"]), list(sp["lower"]), list(sp["upper"])))
+    opts = {"swarmsize": 120, "maxiter": 150, "seed": 11}
+    plain = [nmrfit_amd.fit(d, lo, hi, summary=False, options=opts) for d, lo, hi in jobs]
+    many = nmrfit_amd.fit_many(jobs, threads=3, options=opts)
+    as_dicts = nmrfit_amd.fit_many([dict(data=d, lower=lo, upper=hi) for d, lo, hi in jobs], threads=5, options=opts)
+    assert len(many) == len(as_dicts) == len(jobs)
+    for a, b, c in zip(plain, many, as_dicts):
+        np.testing.assert_array_equal(a.params, b.params)
+        np.testing.assert_array_equal(a.params, c.params)
+        assert a.error == b.error == c.error
+        np.testing.assert_array_equal(a.weights, b.weights)

@@ -267,8 +267,9 @@ int nmrfit_comm_broadcast_host(nmrfit_comm *comm, void *buf, int64_t bytes, int3
 int nmrfit_comm_barrier(nmrfit_comm *comm);
 /* Attach a communicator to a sharded swarm (NULL detaches).  With one attached,
  * nmrfit_pso_step / nmrfit_pso_run include the exchange: every rank of the communicator must
- * make the same calls.  The communicator must have been created on the swarm's own context
- * (NMRFIT_E_INVALID otherwise: the all-gather is enqueued on that context's stream). */
+ * make the same calls.  The communicator may have been created on any context of the swarm's DEVICE
+ * (NMRFIT_E_INVALID otherwise): the all-gather is enqueued on the swarm's own context's stream, so one
+ * ncclCommInitRank serves fit after fit, each with a context of its own -- one swarm at a time. */
 int nmrfit_pso_set_comm(nmrfit_pso *pso, nmrfit_comm *comm);
 /* One whole generation in one call, no Python in the loop: position update -> objective ->
  * personal bests -> local candidate -> [all-gather over the attached communicator] -> fold with

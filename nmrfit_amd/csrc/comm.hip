@@ -132,21 +132,23 @@ void comm_attach(nmrfit_comm *c, int delta)
     if (c) c->attached += delta;
 }
 
-// used by pso.hip: gather every rank's (D+1)-double record on the context's stream.
+// used by pso.hip: gather every rank's (D+1)-double record on `stream` -- the stream of the swarm's context, which
+// need not be the context the communicator was created on (same device: one communicator serves fit after fit, each
+// with a context of its own, without another ncclCommInitRank).  One swarm at a time per communicator.
 // d_send may be any device buffer; *d_all receives a pointer to nranks x n doubles in rank order.
-int comm_all_gather(nmrfit_comm *c, const double *d_send, int64_t n, const double **d_all)
+int comm_all_gather(nmrfit_comm *c, hipStream_t stream, const double *d_send, int64_t n, const double **d_all)
 {
     int rc = bind_comm(c);
     if (rc != NMRFIT_OK) return rc;
     if (c->gather_cap < n * c->nranks) {
-        NMRFIT_HIP(hipStreamSynchronize(c->ctx->stream));
+        NMRFIT_HIP(hipDeviceSynchronize());   // (rare: whoever used the old buffer, on whichever stream, is done)
         if (c->d_gather) NMRFIT_HIP(hipFree(c->d_gather));
         c->d_gather = nullptr;
         c->gather_cap = 0;
         NMRFIT_HIP(hipMalloc((void **)&c->d_gather, (size_t)(n * c->nranks) * sizeof(double)));
         c->gather_cap = n * c->nranks;
     }
-    NMRFIT_RCCL(g_rccl.AllGather(d_send, c->d_gather, (size_t)n, ncclDouble, c->comm, c->ctx->stream));
+    NMRFIT_RCCL(g_rccl.AllGather(d_send, c->d_gather, (size_t)n, ncclDouble, c->comm, stream));
     *d_all = c->d_gather;
     return NMRFIT_OK;
 }

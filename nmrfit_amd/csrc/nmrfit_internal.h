@@ -139,8 +139,8 @@ int ensure(nmrfit_ctx *ctx, double **buf, int64_t *cap, int64_t need);
 int prepare_grid(nmrfit_ctx *ctx, const double *d_w_raw);
 // d_dst[grid_slot(j)] = d_src[j], j < N (d_dst: n_chunks * kChunk doubles, padding untouched)
 int scatter_grid(nmrfit_ctx *ctx, const double *d_src, double *d_dst);
-// gather every rank's n-double record over the communicator (comm.hip), on the context's stream
-int comm_all_gather(nmrfit_comm *c, const double *d_send, int64_t n, const double **d_all);
+// gather every rank's n-double record over the communicator (comm.hip), on `stream` (the swarm's context's)
+int comm_all_gather(nmrfit_comm *c, hipStream_t stream, const double *d_send, int64_t n, const double **d_all);
 nmrfit_ctx *comm_ctx(const nmrfit_comm *c);       // the context a communicator was created on
 void comm_attach(nmrfit_comm *c, int delta);      // swarms attached to it (destroy order guard)
 // per-peak real/imag contributions on a (centred) output grid resident on the device

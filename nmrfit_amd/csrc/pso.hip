@@ -869,10 +869,10 @@ int nmrfit_pso_set_comm(nmrfit_pso *pso, nmrfit_comm *comm)
 {
     int rc = bind_pso(pso);
     if (rc != NMRFIT_OK) return rc;
-    // the all-gather is enqueued on the communicator's context's stream, between this swarm's select
-    // and fold kernels: it has to be the same context (same device, same stream)
-    if (comm && comm_ctx(comm) != pso->ctx) {
-        set_error("nmrfit_pso_set_comm: the communicator was created on a different context than the swarm");
+    // the all-gather is enqueued on THIS swarm's context's stream, between its select and fold kernels; the
+    // communicator may come from another context of the same device (one ncclCommInitRank serves fit after fit)
+    if (comm && (!comm_ctx(comm) || comm_ctx(comm)->device != pso->ctx->device)) {
+        set_error("nmrfit_pso_set_comm: the communicator was created on another device than the swarm's context");
         return NMRFIT_E_INVALID;
     }
     if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;
@@ -933,7 +933,7 @@ static int exchange_and_fold(nmrfit_pso *pso)
     if (!pso->comm) return nmrfit_pso_apply_global_dev(pso, pso->d_cand, 1);
     const double *d_all = nullptr;
     int32_t nranks = 1;
-    int rc = comm_all_gather(pso->comm, pso->d_cand, pso->D + 1, &d_all);
+    int rc = comm_all_gather(pso->comm, pso->ctx->stream, pso->d_cand, pso->D + 1, &d_all);
     if (rc != NMRFIT_OK) return rc;
     if ((rc = nmrfit_comm_info(pso->comm, nullptr, &nranks, nullptr)) != NMRFIT_OK) return rc;
     return nmrfit_pso_apply_global_dev(pso, d_all, nranks);

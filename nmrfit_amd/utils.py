@@ -168,8 +168,8 @@ class FitUtility:
         # Multi-GPU fits (one process per GPU, every rank makes the same fit() call):
         # options['exchange'] = "rccl" builds the RCCL communicator from the launcher's
         # environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; nmrfit_amd.rendezvous), or pass a
-        # ready pso.RcclExchange (its channel and device are reused; the communicator is rebuilt on this
-        # fit's own context) / SocketExchange / TorchExchange.
+        # ready pso.RcclExchange (used as it is, fit after fit: a communicator serves any context of its
+        # device) / SocketExchange / TorchExchange.
         exchange = opt.get('exchange')
         own_exchange = False
         if isinstance(exchange, str) and exchange.lower() != "rccl":
@@ -182,14 +182,12 @@ class FitUtility:
                 exchange = pso.RcclExchange(ev)
                 own_exchange = True
             elif isinstance(exchange, pso.RcclExchange) and exchange.ev is not ev:
-                # A communicator belongs to the context it was created on (its all-gather runs on that
-                # context's stream), and this fit has its own context for its own spectrum: make this
-                # fit's communicator over the ready one's channel, on the same device.  Collective, like
-                # the fit itself -- every rank passes its exchange object.
-                if exchange.channel is None:
+                # A ready communicator, made on another context of the same device (self._device() took the
+                # exchange's): it serves this fit's swarm as it is -- the all-gather runs on the stream of the
+                # swarm's own context (csrc/comm.hip), so ONE ncclCommInitRank covers fit after fit.  Collective,
+                # like the fit itself: every rank passes its exchange object.
+                if exchange.channel is None or not exchange.handle.value:
                     raise ValueError("options['exchange']: this RcclExchange has been closed")
-                exchange = pso.RcclExchange(ev, channel=exchange.channel)
-                own_exchange = True
             ev.set_fit_im(self.fit_im)     # True: the reference's imaginary term (equations.py:197-209)
             # kernel variant: by name or number, default by problem size (default_variant above)
             n_peaks = (len(self.lower) - 4) // 3

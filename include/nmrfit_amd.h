@@ -180,7 +180,10 @@ int nmrfit_pso_destroy(nmrfit_pso *pso);
 int nmrfit_pso_init(nmrfit_pso *pso);
 /* one generation on this rank's shard; leaves the local candidate in the buffer */
 int nmrfit_pso_step_local(nmrfit_pso *pso);
-/* device pointer to this rank's candidate record: (D+1) doubles = [f_best, x_best[0..D)] */
+/* device pointer to this rank's candidate record: (D+1) doubles = [f_best, x_best[0..D)].  The record is
+ * the LAST generation's once the work queued on the context's stream up to this call has run (a single-rank
+ * swarm folds a generation in the next one's launch, nmrfit_pso_set_fused_tail: this call -- like every entry
+ * point that shows or continues the swarm's state -- first enqueues the fold that is still waiting). */
 int nmrfit_pso_candidate_dev(nmrfit_pso *pso, double **dptr);
 /* make the swarm write its candidate record into caller-owned device memory ((D+1) doubles,
  * e.g. the send buffer of an all-gather); NULL restores the internal buffer */

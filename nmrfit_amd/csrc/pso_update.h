@@ -97,7 +97,7 @@ struct PsoFused {
     // flush_fold).  (First built with a ticket: every workgroup drew one once its personal best was complete in
     // memory and the last finished the generation -- 204 x 4096 x 6: 13.4 us per generation against 11.7 this way,
     // 256: 14.4 / 11.7, and beyond 256 particles the serialised tickets cost more than the launch they saved.)
-    unsigned tail = 0;                                // 1: do it
+    unsigned tail = 0;                                // 1: this launch's generation is folded by the next launch (or flush_fold)
     unsigned pending = 0;                             // a generation's personal bests are waiting to be folded
     int flip = 0;                                     // (other block) - (current block) of best / flags, in 8-byte words
     // The personal bests are double-buffered too: a workgroup that starts late (a grid of several rounds, a CU busy

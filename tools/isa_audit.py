@@ -118,7 +118,7 @@ def main():
     meta = {}
     for n in range(end, len(lines)):
         if ".name:" in lines[n] and kernel in lines[n]:
-            for k in range(n - 40, n + 40):
+            for k in range(max(0, n - 40), min(len(lines), n + 40)):
                 m = re.match(r"\s*\.(vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|group_segment_fixed_size|private_segment_fixed_size):\s*(\d+)", lines[k])
                 if m:
                     meta[m.group(1)] = int(m.group(2))

@@ -7,6 +7,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nmrfit_amd import synth, pso
 from nmrfit_amd.equations import Evaluator
 
+if len(sys.argv) > 1:      # another build of the library (A/B): tools/small_swarm_timing.py nmrfit_amd/lib/libab_x.so
+    import ctypes
+    from nmrfit_amd import _cabi
+    L = ctypes.CDLL(os.path.abspath(sys.argv[1]))
+    for name, argtypes in _cabi.SIGNATURES.items():
+        if not hasattr(L, name): continue
+        fn = getattr(L, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
+    L.nmrfit_last_error.argtypes = []; L.nmrfit_last_error.restype = ctypes.c_char_p
+    _cabi._LIB = L
+    print("library:", sys.argv[1])
 SHAPES = [(50, 4096, 6), (204, 4096, 6), (204, 16384, 12), (512, 4096, 6), (1024, 4096, 6), (204, 65536, 24), (4096, 65536, 24)]
 for (S, N, P) in SHAPES:
     sp = synth.make_spectrum(N, P, seed=1)

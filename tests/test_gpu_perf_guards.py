@@ -36,3 +36,26 @@ def test_farfield_is_not_slower_where_it_cannot_help(case):
         ev.dev_free(df)
     print("farfield adversarial %s: default %.1f us, farfield %.1f us" % (case, ms["default"] * 1e3, ms["farfield"] * 1e3))
     assert ms["farfield"] <= 1.25 * ms["default"], ms
+
+
+@pytest.mark.xfail(strict=False, reason="wall-clock guard, non-gating")
+@pytest.mark.parametrize("S,N,P,limit_us", [(204, 4096, 6, 13.0), (1024, 4096, 6, 22.0)])
+def test_one_launch_generations_stay_fast(S, N, P, limit_us):
+    """Per-generation wall time of nmrfit_pso_run with the stopping tests off: the reference's default swarm
+    (round 4: 11.7 us with the fold deferred into the next launch's prologue; 13.4 with the last-ticket form, 15.6 in
+    round 3) and C2 (19.6 us; round 3: 27.3)."""
+    import time
+    from nmrfit_amd import equations, pso, synth
+    sp = synth.make_spectrum(N, P, seed=1)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=3, minfunc=-1.0, minstep=-1.0)
+        sw.run(100, check_every=1000)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sw.run(1000, check_every=1000)
+            best = min(best, (time.perf_counter() - t0) / 1000 * 1e6)
+        assert sw.last_launches() == 1
+        sw.close()
+    print("generation %d x %d x %d: %.2f us" % (S, N, P, best))
+    assert best <= limit_us, best

@@ -616,12 +616,22 @@ def main():
         dt_local = dt
         dt = float(ex.all_reduce([dt], "max")[0])
         km = float(np.mean(k_ms)) if len(k_ms) else 0.0
-        lo = ex.all_reduce([km, dt_local, clock_mhz], "min")
-        hi = ex.all_reduce([km, dt_local, clock_mhz], "max")
+        pw = power.summary() or {}
+        mine = [km, dt_local, clock_mhz, float(pw.get("socket_power_w") or 0.0), float(pw.get("sclk_mhz") or 0.0)]
+        lo = ex.all_reduce(mine, "min")
+        hi = ex.all_reduce(mine, "max")
         ranks = {"kernel_ms_mean": {"min": float(lo[0]), "max": float(hi[0])},
                  "timed_region_s": {"min": float(lo[1]), "max": float(hi[1])},
                  "clock_mhz_in_run": {"min": float(lo[2]), "max": float(hi[2])},
-                 "note": "spread over the ranks (every rank evaluates the same amount of work; `value` uses the slowest)"}
+                 # (0: the hwmon files of that rank's device were not readable)
+                 "socket_power_w_preheat": {"min": float(lo[3]), "max": float(hi[3])},
+                 "sclk_mhz_preheat": {"min": float(lo[4]), "max": float(hi[4])},
+                 # what a generation costs beyond its objective kernel: the candidate launch, the all-gather, the fold
+                 # -- and waiting for the slowest rank in the all-gather
+                 "step_minus_slowest_kernel_ms": dt / args.steps * 1e3 - float(hi[0]),
+                 "note": "spread over the ranks (every rank evaluates the same amount of work; `value` uses the slowest: "
+                         "the ranks meet in the all-gather of every generation, so a GPU that holds a lower clock at its "
+                         "power cap sets the pace)"}
     ms_per_step = dt / args.steps * 1e3
     st = sw.status()
     geom = ev.last_launch()

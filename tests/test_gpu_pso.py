@@ -937,3 +937,28 @@ def test_fit_many_matches_the_plain_loop():
         np.testing.assert_array_equal(a.params, c.params)
         assert a.error == b.error == c.error
         np.testing.assert_array_equal(a.weights, b.weights)
+
+
+@pytest.mark.parametrize("fit_im", [True, "sum"])
+def test_one_launch_generation_with_the_imaginary_channel(fit_im):
+    """The deferred fold rides in every objective instantiation whose workgroup is the particle -- also the ones with
+    the imaginary channel (four-wave workgroups only): 1024 x 4096 x 4 with fit_im=True / "sum" against the numpy mirror
+    evaluating through the same context."""
+    from nmrfit_amd import equations
+    S, N, P = 1024, 4096, 4
+    sp = synth.make_spectrum(N, P, seed=31)
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        ev.set_fit_im(fit_im)
+        kw = dict(minfunc=-1.0, minstep=-1.0)
+        host = pso.HostSwarm(lambda X: ev.objective_batch(X, fit_im=fit_im), sp["lower"], sp["upper"], S, seed=17, **kw)
+        xh, fh = pso.run_sharded(host, pso.LocalExchange(), 40)
+        dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=17, **kw)
+        dev.run(40, check_every=7)
+        assert dev.last_launches() == 1
+        st = dev.state()
+        for k in ("x", "v", "p", "fx", "fp"):
+            np.testing.assert_array_equal(st[k], getattr(host, k), err_msg=k)
+        xb, fb = dev.best()
+        np.testing.assert_array_equal(xb, xh)
+        assert fb == fh
+        dev.close()

@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "nmrfit_amd.h"
+#include "nmrfit_amd_diag.h" /* A/B knobs and diagnostics exercised below; a binding needs nmrfit_amd.h only */
 
 #define N 3000
 #define P 3
@@ -202,6 +203,37 @@ int main(int argc, char **argv)
         CHECK(nmrfit_pso_set_comm(sw, NULL));
         CHECK(nmrfit_pso_destroy(sw));
         CHECK(nmrfit_comm_destroy(comm));
+    }
+
+    /* Device-batched fits (nmrfit_batch_*): the same spectrum three times with three seeds, ONE launch per generation
+     * for all three swarms.  Fit 0 has the lone swarm's seed: its answer is the lone swarm's, bit for bit. */
+    {
+        enum { K = 3 };
+        static double wK[K * N], uK[K * N], vK[K * N], wtK[K * N];
+        double loK[K * D], hiK[K * D], xK[K * D], fK[K];
+        int32_t PK[K], stopK[K];
+        int64_t itK[K];
+        nmrfit_pso_params prmK[K];
+        for (int k = 0; k < K; ++k) {
+            memcpy(wK + k * N, w, sizeof w);
+            memcpy(uK + k * N, u, sizeof u);
+            memcpy(vK + k * N, v, sizeof v);
+            memcpy(wtK + k * N, wt, sizeof wt);
+            memcpy(loK + k * D, lo, sizeof lo);
+            memcpy(hiK + k * D, hi, sizeof hi);
+            PK[k] = P;
+            prmK[k] = prm;
+            prmK[k].seed = prm.seed + (uint64_t)k;
+        }
+        nmrfit_batch *batch = NULL;
+        CHECK(nmrfit_batch_create(0, K, N, wK, uK, vK, wtK, PK, loK, hiK, 204, prmK, NMRFIT_VARIANT_DEFAULT, &batch));
+        CHECK(nmrfit_batch_run(batch, 1000, 100));
+        CHECK(nmrfit_batch_status(batch, itK, stopK, NULL));
+        CHECK(nmrfit_batch_best(batch, xK, fK));
+        printf("batch of %d fits: %lld generations each, best f = %.3e %.3e %.3e\n", K, (long long)itK[0], fK[0], fK[1], fK[2]);
+        if (fK[0] != fb || memcmp(xK, xb, sizeof xb) != 0) return 10;
+        CHECK(nmrfit_batch_destroy(batch));
+        if (nmrfit_batch_run(NULL, 1, 1) != NMRFIT_E_INVALID) return 10;
     }
 
     /* errors come back as codes, never as crashes */

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NMRFIT_ABI_VERSION 4
+#define NMRFIT_ABI_VERSION 5
 
 enum {
     NMRFIT_OK = 0,
@@ -45,7 +45,10 @@ enum {
     NMRFIT_E_COMM = -6          /* an RCCL call failed; see nmrfit_last_error()             */
 };
 
-/* Kernel variants (numerics identical to <= 1e-12 relative; for A/B measurement). */
+/* Kernel variants (numerics identical to <= 1e-12 relative).  DEFAULT, FARFIELD and NOREC are in every build of the
+ * library; BASELINE, NOSKIP, SINGLE, QUAD and STAGED are A/B forms the tuned kernels are measured and checked
+ * against: they exist in libnmrfit_amd_ab.so only (nmrfit_amd/csrc/build.sh --ab), and nmrfit_ctx_set_variant
+ * answers NMRFIT_E_UNSUPPORTED for them in the product library. */
 enum {
     NMRFIT_VARIANT_DEFAULT = 0,   /* tuned fp64: 8 Lorentzians x 4 points per reciprocal (scaled pair form
                                      for positive amplitudes) + Gaussian window skip (+ Gaussian
@@ -89,9 +92,6 @@ const char *nmrfit_last_error(void);
 int nmrfit_device_count(int *count);
 /* name (<= len-1 chars), compute units, and gcnArchName of a device */
 int nmrfit_device_info(int device, char *name, int name_len, int *compute_units, char *arch, int arch_len);
-/* PCI bus id ("0000:c1:00.0") of a device: what a multi-GPU launch prints per rank so that a
- * failed first contact can be traced to a card (len >= 16) */
-int nmrfit_device_pci_bus_id(int device, char *buf, int len);
 
 /* ---- context: the per-fit constant arrays ---------------------------------------------
  * Replaces the `args=(data.w, data.u, data.v, weights, fit_im)` tuple that
@@ -105,10 +105,6 @@ int nmrfit_ctx_destroy(nmrfit_ctx *ctx);
  * nmrfit/utils.py:171-173) */
 int nmrfit_ctx_set_weights(nmrfit_ctx *ctx, const double *weights);
 int nmrfit_ctx_synchronize(nmrfit_ctx *ctx);
-/* Run this context's launches on an externally owned HIP stream (a hipStream_t passed as
- * void*; NULL restores the context's own stream).  Lets the caller order the swarm kernels
- * with an RCCL collective on the same stream with no host synchronisation. */
-int nmrfit_ctx_set_stream(nmrfit_ctx *ctx, void *hip_stream);
 int nmrfit_ctx_set_variant(nmrfit_ctx *ctx, int variant);
 /* imaginary-part mode (NMRFIT_FIT_IM_*) for the device-pointer objective calls and the swarm */
 int nmrfit_ctx_set_fit_im(nmrfit_ctx *ctx, int fit_im);
@@ -142,20 +138,11 @@ int nmrfit_objective_batch_dev(nmrfit_ctx *ctx, int64_t S, int32_t P, const doub
 int nmrfit_residual_batch_dev(nmrfit_ctx *ctx, int64_t B, int32_t P, const double *dX, double *dR_out,
                               double *df_out);
 
-/* ---- device memory + timing helpers (so callers need no HIP binding of their own) ------ */
+/* ---- device memory helpers (so callers need no HIP binding of their own) --------------- */
 int nmrfit_dev_alloc(nmrfit_ctx *ctx, int64_t bytes, void **dptr);
 int nmrfit_dev_free(nmrfit_ctx *ctx, void *dptr);
 int nmrfit_memcpy_h2d(nmrfit_ctx *ctx, void *dst_dev, const void *src_host, int64_t bytes);
 int nmrfit_memcpy_d2h(nmrfit_ctx *ctx, void *dst_host, const void *src_dev, int64_t bytes);
-/* HIP events recorded on the context's stream; elapsed_ms covers everything enqueued
- * between begin and end (end synchronizes). */
-int nmrfit_timer_begin(nmrfit_ctx *ctx);
-int nmrfit_timer_end(nmrfit_ctx *ctx, double *elapsed_ms);
-/* launch geometry the last objective/residual launch used (for reports) */
-int nmrfit_last_launch(const nmrfit_ctx *ctx, int64_t *waves, int32_t *segments, int64_t *segment_len);
-/* ... and how many waves its workgroups had (ABI 4): 4, or 8 when a particle cut into eight segments was one
- * eight-wave workgroup (small swarms on short grids -- the reference's default 204 particles, nmrfit/utils.py:177) */
-int nmrfit_last_launch_workgroup(const nmrfit_ctx *ctx, int32_t *waves_per_workgroup);
 
 /* ---- swarm loop ---------------------------------------------------------------------------
  * Replaces pyswarm.pso as FitUtility.fit calls it (nmrfit/utils.py:176-182): the swarm
@@ -178,20 +165,6 @@ int nmrfit_pso_destroy(nmrfit_pso *pso);
 /* generation 0: x ~ U(lb,ub), evaluate, personal bests, v ~ U(-|ub-lb|,|ub-lb|);
  * leaves this rank's candidate in the candidate buffer. */
 int nmrfit_pso_init(nmrfit_pso *pso);
-/* one generation on this rank's shard; leaves the local candidate in the buffer */
-int nmrfit_pso_step_local(nmrfit_pso *pso);
-/* device pointer to this rank's candidate record: (D+1) doubles = [f_best, x_best[0..D)].  The record is
- * the LAST generation's once the work queued on the context's stream up to this call has run (a single-rank
- * swarm folds a generation in the next one's launch, nmrfit_pso_set_fused_tail: this call -- like every entry
- * point that shows or continues the swarm's state -- first enqueues the fold that is still waiting). */
-int nmrfit_pso_candidate_dev(nmrfit_pso *pso, double **dptr);
-/* make the swarm write its candidate record into caller-owned device memory ((D+1) doubles,
- * e.g. the send buffer of an all-gather); NULL restores the internal buffer */
-int nmrfit_pso_set_candidate_dev(nmrfit_pso *pso, double *dptr);
-/* fold `nranks` gathered candidate records (device pointer, nranks x (D+1) doubles, rank
- * order) into the global best with pyswarm's rule (lowest rank wins ties) and evaluate
- * the minfunc / minstep stopping tests.  Single-rank callers pass their own candidate. */
-int nmrfit_pso_apply_global_dev(nmrfit_pso *pso, const double *d_candidates, int32_t nranks);
 /* status: iteration counter, stop code (0 running, 1 minfunc, 2 minstep), current fg */
 int nmrfit_pso_status(nmrfit_pso *pso, int64_t *iteration, int32_t *stop_code, double *fg);
 /* best position (D doubles) and value; after a stop these are pyswarm's return values */
@@ -200,41 +173,6 @@ int nmrfit_pso_best(nmrfit_pso *pso, double *x_best, double *f_best);
  * generations (generations after a stop are no-ops on the GPU); with a communicator attached
  * every rank makes the same call. */
 int nmrfit_pso_run(nmrfit_pso *pso, int64_t maxiter, int32_t check_every);
-/* How the workgroups of the personal-best / argmin kernel hand their results to the workgroup that
- * finishes the reduction (swarms of up to 1024 particles do it inside ONE launch; the swarm loop
- * replacing nmrfit/utils.py:176-182).  Results are bit-identical in every mode.
- *   FAST (default)  agent-scope write-through atomic stores ordered by s_waitcnt vmcnt(0): no L2
- *                   write-back per workgroup (6.7 us instead of 8.8 us per select at 51 workgroups)
- *   FENCED          release / acquire fences at agent scope: the textbook form, kept as the A/B
- *                   reference for FAST (tools/handover_stress.py); NMRFIT_SAFE_HANDOVER=1 in the
- *                   environment makes it the default of every swarm created afterwards
- *   TWO_LAUNCH      no hand-over inside a launch: the reduction is its own launch (what larger
- *                   swarms use anyway)
- * Never switched automatically. */
-enum { NMRFIT_HANDOVER_FAST = 0, NMRFIT_HANDOVER_FENCED = 1, NMRFIT_HANDOVER_TWO_LAUNCH = 2 };
-int nmrfit_pso_set_handover(nmrfit_pso *pso, int mode);
-/* When the launch geometry puts a whole particle into one workgroup (four grid segments per particle: e.g.
- * 512 or 1024 particles x 4096 points, 4096 x 65536), the objective launch also updates the personal bests
- * (pyswarm: where fx < fp: p = x, fp = fx) and a single workgroup finishes the generation (argmin over fp,
- * candidate record, fold) -- no many-workgroup personal-best / argmin kernel at all, nothing handed over
- * inside a launch: 512 x 4096 x 6: 19.5 -> 17.0 us per generation, 1024 x 4096 x 6: 30.2 -> 26.8 us.  On by
- * default; enable = 0 restores the separate kernel (an A/B knob: results are bit-identical either way). */
-int nmrfit_pso_set_fused_pbest(nmrfit_pso *pso, int enable);
-/* ABI 4.  On top of that, a single-rank swarm of up to 1024 particles (2048 where the workgroup has eight waves) runs a
- * whole generation as ONE launch (what pyswarm.pso's loop body, nmrfit/utils.py:176-182, becomes): the objective launch
- * ends with the personal bests, and the rest -- argmin over fp, candidate record, pyswarm's acceptance / stopping rule --
- * is deferred into the NEXT launch's prologue, where every workgroup works it out for itself before it moves its
- * particle (nothing is handed over inside a launch; the state blocks are double-buffered).  Every entry point that
- * shows or continues the swarm's state first folds the waiting generation in a launch of its own, so the deferral is
- * not observable through this interface (204 x 4096 x 6: 13.4 -> 11.7 us per generation).  On by
- * default; enable = 0 restores the separate one-workgroup launch (an A/B knob: results are bit-identical either
- * way).  nmrfit_pso_last_launches: how many kernel launches the evaluate-and-select part of the last generation
- * took (1, 2 or 3). */
-int nmrfit_pso_set_fused_tail(nmrfit_pso *pso, int enable);
-int nmrfit_pso_last_launches(const nmrfit_pso *pso, int32_t *launches);
-/* copy swarm state to host for inspection/tests (any pointer may be NULL):
- * x, v, p are S_local x D; fx, fp are S_local */
-int nmrfit_pso_get_state(nmrfit_pso *pso, double *x, double *v, double *p, double *fx, double *fp);
 
 /* ---- multi-GPU: the candidate exchange (RCCL over xGMI) -------------------------------------
  * Replaces the reference's only parallel mode, `processes=self.processes` handed to pyswarm,
@@ -259,15 +197,9 @@ int nmrfit_comm_create(nmrfit_ctx *ctx, int32_t rank, int32_t nranks, const void
 int nmrfit_comm_destroy(nmrfit_comm *comm);
 /* rank, size and the RCCL version code (any pointer may be NULL) */
 int nmrfit_comm_info(const nmrfit_comm *comm, int32_t *rank, int32_t *nranks, int32_t *rccl_version);
-/* one line for logs: "rank R of N, HIP device D, PCI 0000:xx:00.0, RCCL V" */
-int nmrfit_comm_describe(const nmrfit_comm *comm, char *buf, int len);
-/* all-gather of n doubles per rank between device buffers, asynchronous on the context's stream */
-int nmrfit_comm_all_gather_dev(nmrfit_comm *comm, const double *d_send, double *d_recv, int64_t n);
-/* bookkeeping collectives on HOST values (1..64 doubles; op 0 sum, 1 max, 2 min), a broadcast
- * of up to 512 bytes from `root`, and a barrier; synchronous, every rank calls them */
-int nmrfit_comm_all_reduce_host(nmrfit_comm *comm, double *inout, int32_t n, int32_t op);
+/* broadcast of up to 512 bytes of HOST memory from `root` (the seed of a multi-rank fit: every rank must run the
+ * same swarm); synchronous, every rank calls it */
 int nmrfit_comm_broadcast_host(nmrfit_comm *comm, void *buf, int64_t bytes, int32_t root);
-int nmrfit_comm_barrier(nmrfit_comm *comm);
 /* Attach a communicator to a sharded swarm (NULL detaches).  With one attached,
  * nmrfit_pso_step / nmrfit_pso_run include the exchange: every rank of the communicator must
  * make the same calls.  The communicator may have been created on any context of the swarm's DEVICE
@@ -280,18 +212,30 @@ int nmrfit_pso_set_comm(nmrfit_pso *pso, nmrfit_comm *comm);
  * Asynchronous on the context's stream. */
 int nmrfit_pso_step(nmrfit_pso *pso);
 
-/* ---- in-run timing of the hot kernel ----------------------------------------------------------
- * With profiling enabled every objective/residual kernel launch of the context is bracketed by
- * HIP events on the context's stream, and nmrfit_prof_mark records a step boundary; reading
- * synchronizes and returns the per-launch kernel durations and the durations between
- * consecutive marks, both in milliseconds and in launch order.  capacity = the number of
- * launches / marks to keep (0 disables and frees the events).  clock_mhz (may be NULL) is the
- * shader clock the first workgroup of the last profiled objective kernel saw while the chip
- * was loaded (s_memtime ticks per s_memrealtime tick x 100 MHz), 0 if unknown. */
-int nmrfit_prof_enable(nmrfit_ctx *ctx, int64_t capacity);
-int nmrfit_prof_mark(nmrfit_ctx *ctx);
-int nmrfit_prof_read(nmrfit_ctx *ctx, double *kernel_ms, int64_t kernel_cap, int64_t *n_kernel,
-                     double *step_ms, int64_t step_cap, int64_t *n_step, double *clock_mhz);
+
+/* ---- device-batched fits: K independent fits, ONE launch per swarm generation for all of them (ABI 5) ---------
+ * The reference's users fit spectrum after spectrum -- `nmrfit.fit(data, lb, ub)` per spectrum (nmrfit/core.py:64,
+ * README.md:64-66), each a 204-particle swarm (nmrfit/utils.py:177-178) -- and a lone swarm of that size fills a
+ * fraction of an MI355X.  A batch holds K spectra of EQUAL length N (each one the `args=(w, u, v, weights)` tuple of
+ * nmrfit/utils.py:176) and K swarms of EQUAL size; peak counts, bounds, seeds and swarm constants are per fit.  Every
+ * generation of every swarm that has not stopped is one launch of the objective kernel whose workgroups look their
+ * fit up by blockIdx; each fit follows exactly the trajectory nmrfit_pso_run gives it alone (bit-identical params and
+ * error for the same seed) and stops by its own pyswarm rule.
+ *   w, u, v, weights   K x N, row-major (fit k's arrays at offset k*N)
+ *   P                  K peak counts; lower / upper: the K boxes concatenated, sum_k (4 + 3 P[k]) doubles each
+ *   params             K records (omega, phip, phig, minstep, minfunc, seed)
+ *   variant            NMRFIT_VARIANT_DEFAULT or NMRFIT_VARIANT_FARFIELD for the whole batch (fit_im = 0)
+ * nmrfit_batch_run: generation 0 (if needed) + up to maxiter generations, polling the K stop flags every
+ * `check_every`; returns when every fit has stopped or maxiter is reached.  nmrfit_batch_status / _best: K values
+ * each (any pointer may be NULL); x_best receives the K best positions concatenated like `lower`. */
+typedef struct nmrfit_batch nmrfit_batch;
+int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
+                        const double *weights, const int32_t *P, const double *lower, const double *upper,
+                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, nmrfit_batch **out);
+int nmrfit_batch_destroy(nmrfit_batch *batch);
+int nmrfit_batch_run(nmrfit_batch *batch, int64_t maxiter, int32_t check_every);
+int nmrfit_batch_status(nmrfit_batch *batch, int64_t *iteration, int32_t *stop_code, double *fg);
+int nmrfit_batch_best(nmrfit_batch *batch, double *x_best, double *f_best);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrfit_amd.so")
+# the A/B library: the product + the A/B kernel variants (BASELINE, NOSKIP, SINGLE, QUAD, STAGED); what the reference
+# kernels of the parity tests, tools/ab.py and bench.py's `variants` entry load.  NMRFIT_LIB=<path> makes it (or any
+# other build) the library of this process.
+AB_LIB_PATH = os.path.join(_HERE, "lib", "libnmrfit_amd_ab.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
 OK = 0
@@ -20,7 +24,7 @@ FIT_IM_OFF, FIT_IM_REFERENCE, FIT_IM_SUM = 0, 1, 2
 VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED, VARIANT_FARFIELD = 0, 1, 2, 3, 4, 5, 6
 VARIANT_NOREC = 7
 HANDOVER_FAST, HANDOVER_FENCED, HANDOVER_TWO_LAUNCH = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 _VARIANT_NAMES = {"default": 0, "baseline": 1, "noskip": 2, "single": 3, "quad": 4, "staged": 5, "farfield": 6,
                   "norec": 7}
 
@@ -51,10 +55,11 @@ class PsoParams(ctypes.Structure):
                 ("minstep", ctypes.c_double), ("minfunc", ctypes.c_double), ("seed", ctypes.c_uint64)]
 
 
-# name -> (argtypes) ; every entry returns int except nmrfit_last_error
+# name -> (argtypes) ; every entry returns int except nmrfit_last_error.  SIGNATURES: include/nmrfit_amd.h (the product
+# interface); DIAG_SIGNATURES: include/nmrfit_amd_diag.h (diagnostics, A/B knobs, the phases of a generation one by one)
 _I64, _I32, _INT = ctypes.c_int64, ctypes.c_int32, ctypes.c_int
 _VP = ctypes.c_void_p
-SIGNATURES = {
+ALL_SIGNATURES = {
     "nmrfit_abi_version": [],
     "nmrfit_device_count": [ctypes.POINTER(_INT)],
     "nmrfit_device_info": [_INT, ctypes.c_char_p, _INT, ctypes.POINTER(_INT), ctypes.c_char_p, _INT],
@@ -110,35 +115,81 @@ SIGNATURES = {
     "nmrfit_prof_enable": [_VP, _I64],
     "nmrfit_prof_mark": [_VP],
     "nmrfit_prof_read": [_VP, _VP, _I64, ctypes.POINTER(_I64), _VP, _I64, ctypes.POINTER(_I64), _c_double_p],
+    "nmrfit_diag_ab_build": [],
+    "nmrfit_batch_create": [_INT, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _INT, _c_void_pp],
+    "nmrfit_batch_destroy": [_VP],
+    "nmrfit_batch_run": [_VP, _I64, _I32],
+    "nmrfit_batch_status": [_VP, _VP, _VP, _VP],
+    "nmrfit_batch_best": [_VP, _VP, _VP],
+    "nmrfit_batch_step": [_VP],
+    "nmrfit_batch_synchronize": [_VP],
+    "nmrfit_batch_set_geometry": [_VP, _INT],
+    "nmrfit_batch_geometry": [_VP, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64)],
+    "nmrfit_batch_get_state": [_VP, _I32, _VP, _VP, _VP, _VP, _VP],
 }
+
+_DIAG_NAMES = (
+    "nmrfit_device_pci_bus_id", "nmrfit_ctx_set_stream", "nmrfit_timer_begin", "nmrfit_timer_end", "nmrfit_last_launch",
+    "nmrfit_last_launch_workgroup", "nmrfit_prof_enable", "nmrfit_prof_mark", "nmrfit_prof_read", "nmrfit_pso_step_local",
+    "nmrfit_pso_candidate_dev", "nmrfit_pso_set_candidate_dev", "nmrfit_pso_apply_global_dev", "nmrfit_pso_set_handover",
+    "nmrfit_pso_set_fused_pbest", "nmrfit_pso_set_fused_tail", "nmrfit_pso_last_launches", "nmrfit_pso_get_state",
+    "nmrfit_comm_describe", "nmrfit_comm_all_gather_dev", "nmrfit_comm_all_reduce_host", "nmrfit_comm_barrier",
+    "nmrfit_diag_ab_build", "nmrfit_batch_step", "nmrfit_batch_synchronize", "nmrfit_batch_set_geometry",
+    "nmrfit_batch_geometry", "nmrfit_batch_get_state")
+DIAG_SIGNATURES = {k: ALL_SIGNATURES[k] for k in _DIAG_NAMES}
+SIGNATURES = {k: v for k, v in ALL_SIGNATURES.items() if k not in DIAG_SIGNATURES}
 
 _LIB = None
 
 
-def build(verbose=False):
-    """Compile libnmrfit_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    out = subprocess.run(["bash", BUILD_SCRIPT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+def build(verbose=False, ab=False):
+    """Compile libnmrfit_amd.so (``ab``: libnmrfit_amd_ab.so, the A/B library) for gfx950 with hipcc (cross-compiles
+    without a GPU)."""
+    out = subprocess.run(["bash", BUILD_SCRIPT] + (["--ab"] if ab else []), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True)
     if verbose or out.returncode != 0:
         print(out.stdout)
     if out.returncode != 0:
-        raise RuntimeError("building libnmrfit_amd.so failed")
-    return LIB_PATH
+        raise RuntimeError("building %s failed" % ("libnmrfit_amd_ab.so" if ab else "libnmrfit_amd.so"))
+    return AB_LIB_PATH if ab else LIB_PATH
+
+
+def lib_path():
+    """The library this process loads: NMRFIT_LIB if set (e.g. the A/B library), else the product library."""
+    return os.environ.get("NMRFIT_LIB") or LIB_PATH
+
+
+def has_ab_variants():
+    """True when the loaded library is an A/B build (the BASELINE / NOSKIP / SINGLE / QUAD / STAGED kernels exist)."""
+    return bool(lib().nmrfit_diag_ab_build())
+
+
+PRODUCT_VARIANTS = (VARIANT_DEFAULT, VARIANT_FARFIELD, VARIANT_NOREC)
+
+
+def available_variants():
+    """Kernel variants of the loaded library: the three product kernels, plus the A/B forms in an A/B build."""
+    if has_ab_variants():
+        return [VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED,
+                VARIANT_FARFIELD, VARIANT_NOREC]
+    return list(PRODUCT_VARIANTS)
 
 
 def lib():
     """The loaded library.  Raises (never falls back) when it is not built."""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
+        path = lib_path()
+        if not os.path.exists(path):
             raise NmrfitError(E_NO_DEVICE, "%s not found: build it with nmrfit_amd/csrc/build.sh "
-                              "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+                              "(or __graft_entry__.build()); there is no CPU fallback" % path)
         # One process per GPU, several per node: the ROCm driver of the machines this runs on offers
         # dmabuf IPC only, and RCCL's intra-node transport (hipIpcGetMemHandle) fails with "invalid
         # argument" unless the HSA runtime is told so BEFORE it initialises -- i.e. before the first
         # HIP call this library makes.  A value the user exported wins.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        L = ctypes.CDLL(LIB_PATH)
-        for name, argtypes in SIGNATURES.items():
+        L = ctypes.CDLL(path)
+        for name, argtypes in ALL_SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int

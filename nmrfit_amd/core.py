@@ -4,6 +4,8 @@ value, executed on the MI355X.  ``load`` (instrument file parsing through nmrglu
 core.py:9-61) is outside the hot-path scope: build a ``Data``-like object (attributes
 w, u, v, peaks) with the reference package or ``nmrfit_amd.synth`` and pass it in.
 """
+import numpy as np
+
 from . import utils
 
 
@@ -29,24 +31,136 @@ def fit(data, lower, upper, expon=0.5, dynamic_weighting=True, fit_im=False, pro
     return f
 
 
-def fit_many(jobs, threads=4, **kwargs):
-    """Fit several spectra at once: ``jobs`` is a sequence of ``(data, lower, upper)`` triples (or dicts of ``fit``'s
-    arguments), each fitted by ``fit`` with the same keyword arguments, on ``threads`` host threads.  Not in the
-    reference (its users loop over ``nmrfit.fit``, nmrfit/core.py:64); here a 204-particle swarm fills a fraction
-    of an MI355X, every fit has its own context and HIP stream and the library releases the GIL inside its calls,
-    so independent fits overlap on the device: about 2.2x the fits per second of a plain loop with four threads
-    (tools/concurrent_fits.py).  Results come back in the order of ``jobs`` and are the ones the plain loop gives
-    (the swarm's random numbers depend on ``options['seed']`` only).  ``summary`` defaults to False here."""
-    from concurrent.futures import ThreadPoolExecutor
-    kwargs.setdefault("summary", False)
+def fit_many(jobs, threads=4, batch=True, shard=False, **kwargs):
+    """Fit several spectra: ``jobs`` is a sequence of ``(data, lower, upper)`` triples (or dicts of ``fit``'s
+    arguments); every job is fitted as ``fit`` would fit it with the same keyword arguments, and the list of
+    FitUtility objects comes back in the order of ``jobs``.  Not in the reference (its users loop over
+    ``nmrfit.fit``, nmrfit/core.py:64; its only parallel mode spreads ONE fit's particles over processes,
+    nmrfit/utils.py:182).  ``summary`` defaults to False here.
 
-    def one(job):
-        if isinstance(job, dict):
-            return fit(**dict(kwargs, **job))
-        data, lower, upper = job
-        return fit(data, lower, upper, **kwargs)
-    jobs = list(jobs)
-    if threads <= 1 or len(jobs) <= 1:
-        return [one(j) for j in jobs]
+    How the jobs run:
+
+    * ``batch=True`` (default): jobs of equal grid length, swarm size and kernel variant, real part only, are fitted as
+      ONE device batch -- one kernel launch per swarm generation for all of them (nmrfit_amd.batch.FitBatch,
+      csrc/batch.hip).  A 204-particle swarm fills a fraction of an MI355X; a batch fills it.  Each fit's ``params`` and
+      ``error`` are bit-identical to what ``fit`` returns for it alone with the same ``options['seed']``.
+    * whatever cannot be batched (``fit_im``, ``polish``, a lone shape) runs through ``fit`` on ``threads`` host
+      threads, each fit with its own context and HIP stream -- serially when ``options['exchange']`` is given: a
+      communicator serves one swarm at a time.
+    * ``shard=True`` in a multi-GPU launch (one process per GPU, RANK / WORLD_SIZE / LOCAL_RANK set by the launcher):
+      the JOBS are divided over the ranks -- rank r takes jobs r, r + world, ... on its own GPU -- and the results are
+      gathered so that every rank returns the full list.  Replicas: no collective touches the fits themselves.  This is
+      the multi-GPU mode for many small fits (sharding one 204-particle swarm over GPUs is slower than one GPU)."""
+    kwargs.setdefault("summary", False)
+    jobs = [dict(job) if isinstance(job, dict) else dict(zip(("data", "lower", "upper"), job)) for job in jobs]
+    if shard:
+        from . import rendezvous
+        rank, _, world = rendezvous.env_rank_world()
+        if world > 1:
+            return _fit_many_sharded(jobs, threads, batch, kwargs, rank, world)
+    return _fit_many_local(jobs, threads, batch, kwargs)
+
+
+def _result_record(f):
+    """What travels between ranks for one finished fit."""
+    return dict(params=list(map(float, f.params)), error=float(f.error), seed=getattr(f, "seed", None))
+
+
+def _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, channel=None, local=None):
+    """Jobs r, r + world, ... on this rank's GPU; every rank returns every result (the other ranks' as FitUtility
+    objects holding ``params`` / ``error`` / ``seed``; their ``weights`` are recomputed on demand only by ``fit``)."""
+    import pickle
+    from . import rendezvous
+    mine = list(range(rank, len(jobs), world))
+    if local is None:
+        device, note = rendezvous.pick_device(_cabi_device_count())
+        if note:
+            import sys
+            sys.stderr.write("nmrfit: %s\n" % note)
+
+        def local(my_jobs):
+            opts = dict(kwargs.get("options", {}))
+            opts.setdefault("device", device)
+            return _fit_many_local(my_jobs, threads, batch, dict(kwargs, options=opts))
+    done = local([jobs[i] for i in mine])
+    own = channel is None
+    if own:
+        channel = rendezvous.Channel()
+    try:
+        parts = channel.all_gather(pickle.dumps([(i, _result_record(f)) for i, f in zip(mine, done)]))
+    finally:
+        if own:
+            channel.close()
+    out = [None] * len(jobs)
+    for i, f in zip(mine, done):
+        out[i] = f
+    for r, blob in enumerate(parts):
+        if r == rank:
+            continue
+        for i, rec in pickle.loads(blob):
+            job = jobs[i]
+            args = {k: v for k, v in dict(kwargs, **job).items() if k not in ("data", "lower", "upper")}
+            f = utils.FitUtility(job["data"], job["lower"], job["upper"], **args)
+            f.params, f.error, f.seed = np.array(rec["params"]), rec["error"], rec["seed"]
+            out[i] = f
+    return out
+
+
+def _cabi_device_count():
+    from . import _cabi
+    return _cabi.device_count()
+
+
+def _fit_many_local(jobs, threads, batch, kwargs):
+    from concurrent.futures import ThreadPoolExecutor
+    fits = []
+    for job in jobs:
+        args = dict(kwargs, **job)
+        fits.append(utils.FitUtility(args.pop("data"), args.pop("lower"), args.pop("upper"), **args))
+    alone = list(range(len(fits)))
+    if batch and len(fits) > 1:
+        plans = [f._plan() for f in fits]
+        groups = {}
+        for i, (f, plan) in enumerate(zip(fits, plans)):
+            key = f._batch_key(plan)
+            if key is not None:
+                groups.setdefault(key, []).append(i)
+        alone = []
+        batched = set()
+        for key, idx in groups.items():
+            if len(idx) > 1:
+                _fit_batch([fits[i] for i in idx], [plans[i] for i in idx], key)
+                batched.update(idx)
+        alone = [i for i in range(len(fits)) if i not in batched]
+    if not alone:
+        return fits
+    with_exchange = any(fits[i].options.get("exchange") is not None for i in alone)
+    if threads <= 1 or len(alone) <= 1 or with_exchange:
+        for i in alone:
+            fits[i].fit()
+        return fits
     with ThreadPoolExecutor(max_workers=int(threads)) as pool:
-        return list(pool.map(one, jobs))
+        list(pool.map(lambda i: fits[i].fit(), alone))
+    return fits
+
+
+def _fit_batch(fits, plans, key):
+    """One device batch: FitBatch over the fits' spectra, run to the common maxiter, results into the FitUtility objects
+    (what FitUtility.fit does for one, utils.py:164-189)."""
+    from .batch import FitBatch
+    from .pso import STOP_MESSAGES
+    device, _, swarmsize, variant, maxiter, check_every = key
+    spectra = [(f.data.w, f.data.u, f.data.v, f.weights) for f in fits]
+    kw = {name: [p['kw'][name] for p in plans] for name in ("omega", "phip", "phig", "minstep", "minfunc")}
+    with FitBatch(spectra, [f.lower for f in fits], [f.upper for f in fits], swarmsize=swarmsize,
+                  seeds=[p['seed'] for p in plans], variant=variant, device=device, **kw) as fb:
+        fb.run(maxiter, check_every)
+        status = fb.status()
+        best = fb.best()
+    for f, p, st, (x, fx) in zip(fits, plans, status, best):
+        # (pyswarm's closing line, once per fit like the plain loop prints it)
+        if st["stop"]:
+            print(STOP_MESSAGES[st["stop"]].format(minfunc=p['kw']['minfunc'], minstep=p['kw']['minstep']))
+        else:
+            print('Stopping search: maximum iterations reached --> {:}'.format(maxiter))
+        f._finish(x, fx)

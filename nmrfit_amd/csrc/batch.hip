@@ -1,0 +1,744 @@
+// batch.hip -- device-batched fits: K independent nmrfit fits advanced together, ONE kernel launch per swarm generation
+// for all of them (the nmrfit_batch_* entry points of include/nmrfit_amd.h).
+//
+// The reference's users call `nmrfit.fit` once per spectrum (nmrfit/core.py:64, README.md:64-66), each with a
+// 204-particle swarm (nmrfit/utils.py:177).  A lone swarm of that size occupies a fraction of an MI355X and its
+// generation is one wave's critical path (11.7 us for ~0.9 us of throughput-bound work); host threads driving one
+// context each saturate at ~95 fits/s.  Here the K spectra are prepared into ONE device allocation, the K swarms live
+// next to them, and a generation of every swarm is one launch of the objective kernel whose workgroups find their fit's
+// record (BatchFit) from blockIdx (objective_batch.hip).  Each fit keeps its own (g, fg), stop flags and random stream
+// (Philox keyed by its seed), runs exactly the operations a lone `nmrfit_amd.fit` runs in the same order, and stops by
+// its own pyswarm rule: the K results are bit-identical to K lone fits.
+//
+// State machine (the deferred fold of pso.hip, for K swarms in lock step): after generation 0 every launch moves, evaluates
+// and personal-bests every particle and leaves its generation to be folded by the NEXT launch's prologue; x / v and
+// (p, fp) ping-pong every launch, the (g, fg | flags) blocks whenever a launch folded.  The kernel reads which buffer is
+// which from one of 8 + 1 descriptor tables built once at creation (phase of x / p, phase of the state block, fold
+// pending or not; + plain evaluation), so a generation costs the host one launch and no copies.
+#include "batch_internal.h"
+#include "nmrfit_amd_diag.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+struct nmrfit_batch {
+    int device = -1;
+    int compute_units = 0;
+    hipStream_t stream = nullptr;
+    int32_t K = 0;
+    int64_t N = 0, S = 0, n_chunks = 0;
+    int variant = NMRFIT_VARIANT_DEFAULT;
+    int32_t Pmax = 0;
+    std::vector<int32_t> P;
+    std::vector<int64_t> D, boff;        // per fit: 4 + 3P, offset of its bounds / best row in the concatenated arrays
+    int64_t Dsum = 0;
+    void *d_block = nullptr;             // the one allocation behind everything below
+    nmrfit::BatchFit *d_tables = nullptr;   // [9][K]: t = xp + 2 b + 4 pending (fused generations), 8 = plain evaluation
+    double *d_summary = nullptr;         // [K][4]: generations, stop code, fg, best_f   (written by batch_tail_kernel)
+    double *d_bestx = nullptr;           // [Dsum]: best_x rows, concatenated
+    // launch geometry: [0] workgroup = particle, [1] wave = particle
+    nmrfit::BatchLaunch geom[2];
+    bool geom_ok[2] = {false, false};
+    int mode = 0;                        // 0 workgroup form, 1 wave form (chosen at creation; nmrfit_batch_set_geometry)
+    // phases
+    int xp = 0, b = 0;
+    bool fold_pending = false;
+    bool initialized = false;
+    int64_t launches = 0;
+};
+
+namespace nmrfit {
+namespace {
+
+#pragma clang fp contract(off)
+
+struct PrepareArgs {
+    int K;
+    int64_t N, n_chunks;
+    const double *raw;       // [4][K][N]: w, u, v, weights as uploaded
+    const BatchFit *fits;    // any table: wc, u, v, wt, chunk, w0
+};
+
+// centred grid + scatter of the four arrays into the pair-interleaved order the kernels read (nmrfit_internal.h,
+// grid_slot), for every fit of the batch at once; the padding up to whole chunks was zeroed before
+__global__ void batch_prepare_kernel(PrepareArgs a)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)a.K * a.N) return;
+    const int k = (int)(idx / a.N);
+    const int64_t j = idx - (int64_t)k * a.N;
+    const BatchFit &f = a.fits[k];
+    const int64_t slot = grid_slot(j);
+    const int64_t plane = (int64_t)a.K * a.N;
+    const_cast<double *>(f.wc)[slot] = a.raw[idx] - f.w0;
+    const_cast<double *>(f.u)[slot] = a.raw[plane + idx];
+    const_cast<double *>(f.v)[slot] = a.raw[2 * plane + idx];
+    const_cast<double *>(f.wt)[slot] = a.raw[3 * plane + idx];
+}
+
+// per-chunk (min, max) of every fit's centred grid: one wave per (fit, chunk)
+__global__ void batch_chunk_minmax_kernel(PrepareArgs a)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t gc = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
+    if (gc >= (int64_t)a.K * a.n_chunks) return;
+    const int k = (int)(gc / a.n_chunks);
+    const int64_t c = gc - (int64_t)k * a.n_chunks;
+    const BatchFit &f = a.fits[k];
+    double lo = INFINITY, hi = -INFINITY;
+    for (int q = 0; q < kPointsPerLane; ++q) {
+        const int64_t j = c * kChunk + q * kWave + lane;
+        if (j < a.N) {
+            const double x = f.wc[grid_slot(j)];
+            lo = fmin(lo, x);
+            hi = fmax(hi, x);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, off, kWave));
+        hi = fmax(hi, __shfl_down(hi, off, kWave));
+    }
+    if (lane == 0) const_cast<double2 *>(f.chunk)[c] = make_double2(lo, hi);
+}
+
+// generation 0 of every swarm: x ~ U(lb, ub), v ~ U(-|ub - lb|, |ub - lb|), p = 0, fp = +inf (pso.hip, pso_init_kernel)
+__global__ void batch_init_kernel(const BatchFit *__restrict__ fits, int K, int64_t S, int64_t Dmax)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_fit = S * Dmax;
+    if (idx >= (int64_t)K * per_fit) return;
+    const int k = (int)(idx / per_fit);
+    const int64_t r = idx - (int64_t)k * per_fit;
+    const int64_t i = r / Dmax;
+    const int d = (int)(r - i * Dmax);
+    const BatchFit &f = fits[k];
+    const int64_t D = 4 + 3 * (int64_t)f.P;
+    if (d >= D) return;
+    const PsoFused &u = f.upd;
+    double r0, r1;
+    uniform2(u.seed, 0u, (uint32_t)d, (uint64_t)i, &r0, &r1);
+    const double lo = u.lb[d], hi = u.ub[d];
+    const double vhigh = fabs(hi - lo), vlow = -vhigh;
+    const int64_t e = i * D + d;
+    const_cast<double *>(u.x_in)[e] = lo + r0 * (hi - lo);
+    const_cast<double *>(u.v_in)[e] = vlow + r1 * (vhigh - vlow);
+    double *p = const_cast<double *>(u.p);
+    p[e] = 0.0;
+    if (d == 0) p[S * D + i] = INFINITY;
+    if (idx - (int64_t)k * per_fit == 0) {
+        const_cast<long long *>(u.flags)[0] = 0;
+        const_cast<long long *>(u.flags)[1] = 0;
+    }
+}
+
+enum { kBatchPbest = 1, kBatchArgmin = 2, kBatchApply = 4 };
+
+// One workgroup per fit: what follows an objective launch that did not finish the generation itself -- personal bests
+// (generation 0), argmin over fp -> candidate record, fold with pyswarm's rule -- and the fit's line of the summary
+// the host reads (generations, stop code, fg, best value, best position).  Same device bodies as pso_tail_kernel.
+__global__ __launch_bounds__(1024) void batch_tail_kernel(const BatchFit *__restrict__ fits, int64_t S, int phases, int is_init,
+                                                          double *__restrict__ summary, double *__restrict__ bestx,
+                                                          const int64_t *__restrict__ boff)
+{
+    const BatchFit &f = fits[blockIdx.x];
+    const PsoFused &u = f.upd;
+    const int64_t D = 4 + 3 * (int64_t)f.P;
+    long long *flags = const_cast<long long *>(u.flags);
+    double *best = const_cast<double *>(u.best);
+    double *p = const_cast<double *>(u.p), *fp = p + S * D;
+    __shared__ double s_val[16];
+    __shared__ long long s_idx[16];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, nw = blockDim.x / kWave;
+    if (flags[1] == 0) {   // (after a stop nothing moves: pso_tail_kernel returns at once)
+        if (phases & kBatchPbest) {
+            for (int64_t i = wave; i < S; i += nw) pbest_particle(i, lane, D, u.x_in, f.fx, p, fp);
+            __syncthreads();
+        }
+        if (phases & kBatchArgmin) {
+            argmin_block(S, D, fp, p, u.x_in, u.cand, s_val, s_idx);
+            __syncthreads();
+        }
+        if (phases & kBatchApply) {
+            if (wave == 0) apply_wave(lane, D, 1, is_init, u.minstep, u.minfunc, u.cand, flags, best);
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        double *s = summary + 4 * (int64_t)blockIdx.x;
+        s[0] = (double)flags[0];
+        s[1] = (double)flags[1];
+        s[2] = best[0];
+        s[3] = best[1];
+    }
+    for (int64_t d = threadIdx.x; d < D; d += blockDim.x) bestx[boff[blockIdx.x] + d] = best[2 + D + d];
+}
+
+int bind_batch(const nmrfit_batch *b)
+{
+    if (!b) {
+        set_error("null batch handle");
+        return NMRFIT_E_INVALID;
+    }
+    NMRFIT_HIP(hipSetDevice(b->device));
+    return NMRFIT_OK;
+}
+
+const BatchFit *table(const nmrfit_batch *b, int t) { return b->d_tables + (size_t)t * (size_t)b->K; }
+
+int launch_tail(nmrfit_batch *b, int phases, int is_init)
+{
+    // the table of the CURRENT phases: x_in / p are the buffers the last launch wrote, best / flags the current block
+    const BatchFit *t = table(b, b->xp + 2 * b->b);
+    hipLaunchKernelGGL(batch_tail_kernel, dim3((unsigned)b->K), dim3(1024), 0, b->stream, t, b->S, phases, is_init,
+                       b->d_summary, b->d_bestx, reinterpret_cast<const int64_t *>(b->d_bestx + b->Dsum));
+    NMRFIT_HIP(hipGetLastError());
+    return NMRFIT_OK;
+}
+
+// fold the generation whose personal bests are still waiting, in a launch of its own (pso.hip, flush_fold)
+int flush_fold(nmrfit_batch *b)
+{
+    if (!b->fold_pending) return NMRFIT_OK;
+    const int rc = launch_tail(b, kBatchArgmin | kBatchApply, 0);
+    if (rc == NMRFIT_OK) b->fold_pending = false;
+    return rc;
+}
+
+// the two launch geometries of a batch (objective.hip's launch_objective picks among the same forms for a lone swarm)
+void plan_geometry(nmrfit_batch *b)
+{
+    const int64_t N = b->N;
+    const int64_t n_chunks = (N + kChunk - 1) / kChunk;
+    const int blk_chunks = (int)((n_chunks + kMaxBlocks - 1) / kMaxBlocks);
+    const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
+    const int64_t blk_len = (int64_t)blk_chunks * kChunk;
+    const int64_t Dmax = 4 + 3 * (int64_t)b->Pmax;
+    for (int m = 0; m < 2; ++m) {
+        BatchLaunch &g = b->geom[m];
+        g = BatchLaunch{};
+        g.stream = b->stream;
+        g.K = b->K;
+        g.S = b->S;
+        g.N = N;
+        g.blk_chunks = blk_chunks;
+        g.variant = b->variant;
+        b->geom_ok[m] = false;
+        int slices, rows;
+        size_t row_bytes;
+        if (m == 0) {
+            // workgroup = particle: eight segments (an eight-wave workgroup) when the grid cuts into exactly eight, else
+            // four; the deferred fold's argmin covers kDeferredPerLane x 64 entries per wave (pso_update.h)
+            int wpb = 0;
+            int64_t seg_len = 0;
+            for (int w : {kWideWaves, kWavesPerBlock}) {
+                if (n_blocks < w) continue;
+                const int64_t sl = ((n_blocks + w - 1) / w) * blk_len;
+                if ((N + sl - 1) / sl != w) continue;
+                if (b->S > (int64_t)kDeferredPerLane * kWave * w) continue;
+                wpb = w;
+                seg_len = sl;
+                break;
+            }
+            if (!wpb) continue;
+            g.wpb = wpb;
+            g.nseg = wpb;
+            g.seg_len = seg_len;
+            g.wave_swarm = false;
+            g.blocks_per_fit = b->S;
+            slices = 1;
+            rows = 3;
+            row_bytes = 3 * (size_t)Dmax * sizeof(double);
+        } else {
+            // wave = particle: one segment, four particles per workgroup (the last workgroup of a fit padded with idle waves,
+            // so that a workgroup never spans two fits)
+            g.wpb = kWavesPerBlock;
+            g.nseg = 1;
+            g.seg_len = n_blocks * blk_len;
+            g.wave_swarm = true;
+            g.blocks_per_fit = (b->S + kWavesPerBlock - 1) / kWavesPerBlock;
+            slices = kWavesPerBlock;
+            rows = 14;   // >= 4 x (3 D + 2) doubles for every D >= 4
+            row_bytes = (size_t)kWavesPerBlock * (3 * (size_t)Dmax + 2) * sizeof(double);
+        }
+        int v = b->variant;
+        unsigned aux = 0;
+        size_t lds = objective_lds(b->variant, b->Pmax, false, 0, &v, &aux, g.wpb, slices, rows);
+        if (v != b->variant) continue;   // (would run another kernel than a lone fit: not bit-identical)
+        lds = (lds + 15) & ~(size_t)15;   // the row copies come last (their offset, xrow_offset below, travels in the
+        lds += row_bytes;                 // descriptor tables: PsoFused::xrow_off, re-stamped when the geometry changes)
+        if (lds + kObjectiveStaticLds + 16 > 160 * 1024) continue;
+        g.lds = lds;
+        g.aux_off = aux;
+        b->geom_ok[m] = true;
+    }
+}
+
+unsigned xrow_offset(const nmrfit_batch *b, int m)
+{
+    const BatchLaunch &g = b->geom[m];
+    const int64_t Dmax = 4 + 3 * (int64_t)b->Pmax;
+    const size_t row_bytes = g.wave_swarm ? (size_t)kWavesPerBlock * (3 * (size_t)Dmax + 2) * sizeof(double)
+                                          : 3 * (size_t)Dmax * sizeof(double);
+    return (unsigned)(g.lds - row_bytes);
+}
+
+}  // namespace
+}  // namespace nmrfit
+
+using namespace nmrfit;
+
+namespace {
+
+// per-fit device memory, carved out of the one allocation
+struct FitMem {
+    double *wc, *u, *v, *wt;
+    double2 *chunk;
+    double *lb, *ub, *x, *vel, *x2, *vel2, *p, *p_alt, *fx, *cand, *best, *best_alt;
+};
+
+struct Carver {
+    size_t total = 0;
+    size_t take(size_t bytes)
+    {
+        const size_t at = total;
+        total += (bytes + 255) & ~(size_t)255;
+        return at;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
+                        const double *weights, const int32_t *P, const double *lower, const double *upper,
+                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, nmrfit_batch **out)
+{
+    if (!out) {
+        set_error("null out pointer");
+        return NMRFIT_E_INVALID;
+    }
+    *out = nullptr;
+    if (K <= 0 || N <= 0 || swarmsize <= 0 || !w || !u || !v || !weights || !P || !lower || !upper || !params) {
+        set_error("nmrfit_batch_create: K, N, swarmsize must be > 0 and every array non-null");
+        return NMRFIT_E_INVALID;
+    }
+    if (variant != NMRFIT_VARIANT_DEFAULT && variant != NMRFIT_VARIANT_FARFIELD) {
+        set_error("nmrfit_batch_create: device-batched fits run the DEFAULT and FARFIELD kernels");
+        return NMRFIT_E_UNSUPPORTED;
+    }
+    if (swarmsize > 0x7fffffffLL / 8) {
+        set_error("nmrfit_batch_create: swarm too large");
+        return NMRFIT_E_INVALID;
+    }
+    int n = 0;
+    int rc = nmrfit_device_count(&n);
+    if (rc != NMRFIT_OK) return rc;
+    if (n == 0) {
+        set_error("no HIP device visible: libnmrfit_amd has no CPU fallback");
+        return NMRFIT_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device index out of range");
+        return NMRFIT_E_NO_DEVICE;
+    }
+    NMRFIT_HIP(hipSetDevice(device));
+    DeviceInfo prop;
+    if ((rc = device_info_cached(device, &prop)) != NMRFIT_OK) return rc;
+    if (strncmp(prop.arch, "gfx950", 6) != 0) {
+        set_error(std::string("device is ") + prop.arch + ", this library is built for gfx950 only");
+        return NMRFIT_E_NO_DEVICE;
+    }
+    nmrfit_batch *b = new (std::nothrow) nmrfit_batch();
+    if (!b) {
+        set_error("out of host memory");
+        return NMRFIT_E_INVALID;
+    }
+    b->device = device;
+    b->compute_units = prop.cus;
+    b->K = K;
+    b->N = N;
+    b->S = swarmsize;
+    b->n_chunks = (N + kChunk - 1) / kChunk;
+    b->variant = variant;
+    b->P.assign(P, P + K);
+    b->D.resize((size_t)K);
+    b->boff.resize((size_t)K);
+    for (int32_t k = 0; k < K; ++k) {
+        if (P[k] < 0 || 4 + 3 * (int64_t)P[k] > kFusedMaxD) {
+            set_error("nmrfit_batch_create: peak counts must be 0 <= P and 4 + 3 P <= " + std::to_string(kFusedMaxD));
+            delete b;
+            return NMRFIT_E_INVALID;
+        }
+        b->D[(size_t)k] = 4 + 3 * (int64_t)P[k];
+        b->boff[(size_t)k] = b->Dsum;
+        b->Dsum += b->D[(size_t)k];
+        b->Pmax = std::max(b->Pmax, P[k]);
+    }
+    for (int64_t d = 0; d < b->Dsum; ++d)
+        if (!(upper[d] > lower[d])) {   // pyswarm: assert np.all(ub > lb)
+            set_error("All upper-bound values must be greater than lower-bound values");
+            delete b;
+            return NMRFIT_E_INVALID;
+        }
+#define BATCH_HIP(call)                                                \
+    do {                                                               \
+        hipError_t _e = (call);                                        \
+        if (_e != hipSuccess) {                                        \
+            int _rc = hip_fail(_e, #call, __FILE__, __LINE__);         \
+            nmrfit_batch_destroy(b);                                   \
+            return _rc;                                                \
+        }                                                              \
+    } while (0)
+    BATCH_HIP(take_stream(device, &b->stream));
+    plan_geometry(b);
+    if (!b->geom_ok[0] && !b->geom_ok[1]) {
+        set_error("nmrfit_batch_create: too many peaks for the kernel's LDS records in a batched launch");
+        nmrfit_batch_destroy(b);
+        return NMRFIT_E_UNSUPPORTED;
+    }
+    // ---- one allocation: per fit the four padded grid arrays + chunk table + swarm state; then the summary, the best
+    // rows (+ their offsets), the descriptor tables, and the landing buffer of the upload
+    const int64_t S = b->S;
+    const size_t padded = (size_t)b->n_chunks * kChunk * sizeof(double);
+    Carver c;
+    std::vector<size_t> o_grid((size_t)K), o_chunk((size_t)K), o_lb((size_t)K), o_x((size_t)K), o_p((size_t)K), o_fx((size_t)K),
+        o_cand((size_t)K), o_state((size_t)K);
+    std::vector<size_t> state_bytes((size_t)K);
+    for (int32_t k = 0; k < K; ++k) {
+        const size_t D = (size_t)b->D[(size_t)k];
+        o_grid[(size_t)k] = c.take(4 * ((padded + 255) & ~(size_t)255));
+        o_chunk[(size_t)k] = c.take((size_t)b->n_chunks * sizeof(double2));
+        o_lb[(size_t)k] = c.take(2 * ((D * sizeof(double) + 255) & ~(size_t)255));
+        o_x[(size_t)k] = c.take(4 * (((size_t)S * D * sizeof(double) + 255) & ~(size_t)255));
+        o_p[(size_t)k] = c.take(2 * ((((size_t)S * D + (size_t)S) * sizeof(double) + 255) & ~(size_t)255));
+        o_fx[(size_t)k] = c.take((size_t)S * sizeof(double));
+        o_cand[(size_t)k] = c.take((D + 1) * sizeof(double));
+        // (fg, best_f, g[D], best_x[D] | generations, stop code): two copies, the flags right behind the doubles (pso.hip)
+        state_bytes[(size_t)k] = (((2 + 2 * D) * sizeof(double) + 2 * sizeof(long long)) + 255) & ~(size_t)255;
+        o_state[(size_t)k] = c.take(2 * state_bytes[(size_t)k]);
+    }
+    const size_t grid_state_end = c.total;
+    const size_t o_summary = c.take((size_t)K * 4 * sizeof(double));
+    const size_t o_bestx = c.take((size_t)b->Dsum * sizeof(double) + (size_t)K * sizeof(int64_t));
+    const size_t o_tables = c.take((size_t)9 * (size_t)K * sizeof(BatchFit));
+    const size_t o_raw = c.take((size_t)4 * (size_t)K * (size_t)N * sizeof(double));
+    BATCH_HIP(hipMalloc(&b->d_block, c.total));
+    unsigned char *base = reinterpret_cast<unsigned char *>(b->d_block);
+    BATCH_HIP(hipMemsetAsync(base, 0, grid_state_end, b->stream));   // padding of the grid arrays (weight 0), state blocks
+    b->d_summary = reinterpret_cast<double *>(base + o_summary);
+    b->d_bestx = reinterpret_cast<double *>(base + o_bestx);
+    b->d_tables = reinterpret_cast<BatchFit *>(base + o_tables);
+    double *d_raw = reinterpret_cast<double *>(base + o_raw);
+    // ---- descriptor tables (host copy, uploaded once)
+    std::vector<FitMem> mem((size_t)K);
+    std::vector<BatchFit> tabs((size_t)9 * (size_t)K);
+    for (int32_t k = 0; k < K; ++k) {
+        const size_t D = (size_t)b->D[(size_t)k];
+        FitMem &m = mem[(size_t)k];
+        const size_t pad_al = (padded + 255) & ~(size_t)255;
+        m.wc = reinterpret_cast<double *>(base + o_grid[(size_t)k]);
+        m.u = reinterpret_cast<double *>(base + o_grid[(size_t)k] + pad_al);
+        m.v = reinterpret_cast<double *>(base + o_grid[(size_t)k] + 2 * pad_al);
+        m.wt = reinterpret_cast<double *>(base + o_grid[(size_t)k] + 3 * pad_al);
+        m.chunk = reinterpret_cast<double2 *>(base + o_chunk[(size_t)k]);
+        const size_t d_al = (D * sizeof(double) + 255) & ~(size_t)255;
+        m.lb = reinterpret_cast<double *>(base + o_lb[(size_t)k]);
+        m.ub = reinterpret_cast<double *>(base + o_lb[(size_t)k] + d_al);
+        const size_t sd_al = ((size_t)S * D * sizeof(double) + 255) & ~(size_t)255;
+        m.x = reinterpret_cast<double *>(base + o_x[(size_t)k]);
+        m.vel = reinterpret_cast<double *>(base + o_x[(size_t)k] + sd_al);
+        m.x2 = reinterpret_cast<double *>(base + o_x[(size_t)k] + 2 * sd_al);
+        m.vel2 = reinterpret_cast<double *>(base + o_x[(size_t)k] + 3 * sd_al);
+        const size_t p_al = ((((size_t)S * D + (size_t)S) * sizeof(double)) + 255) & ~(size_t)255;
+        m.p = reinterpret_cast<double *>(base + o_p[(size_t)k]);
+        m.p_alt = reinterpret_cast<double *>(base + o_p[(size_t)k] + p_al);
+        m.fx = reinterpret_cast<double *>(base + o_fx[(size_t)k]);
+        m.cand = reinterpret_cast<double *>(base + o_cand[(size_t)k]);
+        m.best = reinterpret_cast<double *>(base + o_state[(size_t)k]);
+        m.best_alt = reinterpret_cast<double *>(base + o_state[(size_t)k] + state_bytes[(size_t)k]);
+        BatchFit f{};
+        f.wc = m.wc;
+        f.u = m.u;
+        f.v = m.v;
+        f.wt = m.wt;
+        f.chunk = m.chunk;
+        double grid_dev = 0.0;
+        analyse_grid(w + (size_t)k * (size_t)N, N, &f.w0, &f.wspan, &f.lane_step, &grid_dev);
+        f.rec_devk = grid_dev * 11.0e10;   // (as launch_variant passes it: objective_kernel.h)
+        f.fx = m.fx;
+        f.P = b->P[(size_t)k];
+        const nmrfit_pso_params &prm = params[k];
+        for (int t = 0; t < 9; ++t) {
+            BatchFit e = f;
+            PsoFused &q = e.upd;
+            if (t == 8) {
+                e.X = m.x;   // plain evaluation of generation 0's positions
+                // (what batch_init_kernel and the generation-0 tail need travels in table 0)
+            } else {
+                const int xp = t & 1, bb = (t >> 1) & 1, pending = (t >> 2) & 1;
+                q.x_in = xp ? m.x2 : m.x;
+                q.v_in = xp ? m.vel2 : m.vel;
+                q.x_out = xp ? m.x : m.x2;
+                q.v_out = xp ? m.vel : m.vel2;
+                q.p = xp ? m.p_alt : m.p;
+                q.pflip = (int)((xp ? m.p : m.p_alt) - (xp ? m.p_alt : m.p));
+                q.best = bb ? m.best_alt : m.best;
+                q.flags = reinterpret_cast<const long long *>(q.best + 2 + 2 * D);
+                q.flip = (int)((bb ? m.best : m.best_alt) - (bb ? m.best_alt : m.best));
+                q.lb = m.lb;
+                q.ub = m.ub;
+                q.seed = prm.seed;
+                q.offset = 0;
+                q.omega = prm.omega;
+                q.phip = prm.phip;
+                q.phig = prm.phig;
+                q.minstep = prm.minstep;
+                q.minfunc = prm.minfunc;
+                q.cand = m.cand;
+                q.pbest = 1u;
+                q.tail = 1u;
+                q.pending = (unsigned)pending;
+                q.xrow_off = 0u;   // set per geometry below
+            }
+            tabs[(size_t)t * (size_t)K + (size_t)k] = e;
+        }
+    }
+    // the geometry decides where the row copies sit in LDS: stamp the chosen one's offset into the fused tables
+    b->mode = b->geom_ok[0] ? 0 : 1;
+    {
+        // many particles: the wave form (one prologue per particle instead of one per workgroup of idle waves).
+        // Measured crossover on MI355X: see DESIGN.md 4.5; NMRFIT_BATCH_WAVE_MIN overrides (tuning knob)
+        int64_t wave_min = 1536;
+        if (const char *e = getenv("NMRFIT_BATCH_WAVE_MIN")) wave_min = atoll(e);
+        if (b->geom_ok[1] && (int64_t)K * S >= wave_min) b->mode = 1;
+    }
+    for (int t = 0; t < 8; ++t)
+        for (int32_t k = 0; k < K; ++k) tabs[(size_t)t * (size_t)K + (size_t)k].upd.xrow_off = xrow_offset(b, b->mode);
+    BATCH_HIP(hipMemcpyAsync(b->d_tables, tabs.data(), tabs.size() * sizeof(BatchFit), hipMemcpyHostToDevice, b->stream));
+    BATCH_HIP(hipMemcpyAsync(b->d_bestx + b->Dsum, b->boff.data(), (size_t)K * sizeof(int64_t), hipMemcpyHostToDevice, b->stream));
+    // ---- spectra: four uploads, one scatter kernel, one chunk-table kernel
+    const size_t plane = (size_t)K * (size_t)N * sizeof(double);
+    const double *host_arrays[] = {w, u, v, weights};
+    for (int a = 0; a < 4; ++a)
+        BATCH_HIP(hipMemcpyAsync(reinterpret_cast<unsigned char *>(d_raw) + (size_t)a * plane, host_arrays[a], plane,
+                                 hipMemcpyHostToDevice, b->stream));
+    for (int32_t k = 0; k < K; ++k) {
+        const FitMem &m = mem[(size_t)k];
+        BATCH_HIP(hipMemcpyAsync(m.lb, lower + b->boff[(size_t)k], (size_t)b->D[(size_t)k] * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        BATCH_HIP(hipMemcpyAsync(m.ub, upper + b->boff[(size_t)k], (size_t)b->D[(size_t)k] * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    }
+    {
+        PrepareArgs a{};
+        a.K = K;
+        a.N = N;
+        a.n_chunks = b->n_chunks;
+        a.raw = d_raw;
+        a.fits = b->d_tables;
+        const int64_t n = (int64_t)K * N;
+        hipLaunchKernelGGL(batch_prepare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, a);
+        BATCH_HIP(hipGetLastError());
+        const int64_t nc = (int64_t)K * b->n_chunks;
+        hipLaunchKernelGGL(batch_chunk_minmax_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(kWave * 4), 0, b->stream, a);
+        BATCH_HIP(hipGetLastError());
+    }
+    BATCH_HIP(hipStreamSynchronize(b->stream));   // (the host vectors go out of scope)
+#undef BATCH_HIP
+    *out = b;
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_destroy(nmrfit_batch *b)
+{
+    if (!b) return NMRFIT_OK;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->d_block) (void)hipFree(b->d_block);
+    if (b->stream) give_stream(b->device, b->stream);
+    delete b;
+    return NMRFIT_OK;
+}
+
+// generation 0: positions, velocities, evaluation, personal bests, (g, fg) <- the best of them
+static int batch_init(nmrfit_batch *b)
+{
+    b->xp = b->b = 0;
+    b->fold_pending = false;
+    const int64_t Dmax = 4 + 3 * (int64_t)b->Pmax;
+    const int64_t n = (int64_t)b->K * b->S * Dmax;
+    hipLaunchKernelGGL(batch_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, table(b, 0), (int)b->K, b->S, Dmax);
+    NMRFIT_HIP(hipGetLastError());
+    BatchLaunch g = b->geom[b->mode];
+    g.fits = table(b, 8);
+    int rc = launch_objective_batch(g);
+    if (rc != NMRFIT_OK) return rc;
+    if ((rc = launch_tail(b, kBatchPbest | kBatchArgmin | kBatchApply, 1)) != NMRFIT_OK) return rc;
+    b->initialized = true;
+    return NMRFIT_OK;
+}
+
+// one generation of every swarm that has not stopped: ONE launch
+static int batch_generation(nmrfit_batch *b)
+{
+    BatchLaunch g = b->geom[b->mode];
+    g.fits = table(b, b->xp + 2 * b->b + (b->fold_pending ? 4 : 0));
+    const int rc = launch_objective_batch(g);
+    if (rc != NMRFIT_OK) return rc;
+    b->xp ^= 1;                          // x / v and (p, fp): the buffers the launch has just written
+    if (b->fold_pending) b->b ^= 1;      // it folded the generation before: particle 0 wrote the other state block
+    b->fold_pending = true;              // its own generation waits for the next launch (or flush_fold)
+    ++b->launches;
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_step(nmrfit_batch *b)
+{
+    int rc = bind_batch(b);
+    if (rc != NMRFIT_OK) return rc;
+    if (!b->initialized) return batch_init(b);
+    return batch_generation(b);
+}
+
+static int read_summary(nmrfit_batch *b, std::vector<double> &s)
+{
+    int rc = flush_fold(b);
+    if (rc != NMRFIT_OK) return rc;
+    s.resize((size_t)b->K * 4);
+    NMRFIT_HIP(hipMemcpyAsync(s.data(), b->d_summary, s.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    NMRFIT_HIP(hipStreamSynchronize(b->stream));
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_run(nmrfit_batch *b, int64_t maxiter, int32_t check_every)
+{
+    int rc = bind_batch(b);
+    if (rc != NMRFIT_OK) return rc;
+    if (maxiter < 0 || check_every < 1) {
+        set_error("nmrfit_batch_run: maxiter must be >= 0 and check_every >= 1");
+        return NMRFIT_E_INVALID;
+    }
+    if (!b->initialized && (rc = batch_init(b)) != NMRFIT_OK) return rc;
+    // every fit runs the generations a lone nmrfit_pso_run would: a stopped swarm's workgroups return at once, so the
+    // others' generations do not touch it; the loop ends when every swarm has stopped (polled every check_every)
+    std::vector<double> s;
+    for (int64_t it = 1; it <= maxiter; ++it) {
+        if ((rc = batch_generation(b)) != NMRFIT_OK) return rc;
+        if (it % check_every == 0 || it == maxiter) {
+            if ((rc = read_summary(b, s)) != NMRFIT_OK) return rc;
+            bool all = true;
+            for (int32_t k = 0; k < b->K; ++k) all = all && s[(size_t)k * 4 + 1] != 0.0;
+            if (all) break;
+        }
+    }
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_status(nmrfit_batch *b, int64_t *iteration, int32_t *stop_code, double *fg)
+{
+    int rc = bind_batch(b);
+    if (rc != NMRFIT_OK) return rc;
+    if (!b->initialized) {
+        set_error("nmrfit_batch_status before the first generation");
+        return NMRFIT_E_STATE;
+    }
+    std::vector<double> s;
+    if ((rc = read_summary(b, s)) != NMRFIT_OK) return rc;
+    for (int32_t k = 0; k < b->K; ++k) {
+        if (iteration) iteration[k] = (int64_t)s[(size_t)k * 4];
+        if (stop_code) stop_code[k] = (int32_t)s[(size_t)k * 4 + 1];
+        if (fg) fg[k] = s[(size_t)k * 4 + 2];
+    }
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_best(nmrfit_batch *b, double *x_best, double *f_best)
+{
+    int rc = bind_batch(b);
+    if (rc != NMRFIT_OK) return rc;
+    if (!b->initialized) {
+        set_error("nmrfit_batch_best before the first generation");
+        return NMRFIT_E_STATE;
+    }
+    std::vector<double> s;
+    if ((rc = read_summary(b, s)) != NMRFIT_OK) return rc;
+    if (f_best)
+        for (int32_t k = 0; k < b->K; ++k) f_best[k] = s[(size_t)k * 4 + 3];
+    if (x_best) {
+        NMRFIT_HIP(hipMemcpyAsync(x_best, b->d_bestx, (size_t)b->Dsum * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        NMRFIT_HIP(hipStreamSynchronize(b->stream));
+    }
+    return NMRFIT_OK;
+}
+
+/* ---- diagnostics (include/nmrfit_amd_diag.h) ---- */
+
+int nmrfit_batch_set_geometry(nmrfit_batch *b, int mode)
+{
+    int rc = bind_batch(b);
+    if (rc != NMRFIT_OK) return rc;
+    if (mode < 0 || mode > 1 || !b->geom_ok[mode]) {
+        set_error("nmrfit_batch_set_geometry: 0 (workgroup = particle) or 1 (wave = particle), where the shape allows it");
+        return NMRFIT_E_UNSUPPORTED;
+    }
+    if (mode == b->mode) return NMRFIT_OK;
+    if ((rc = flush_fold(b)) != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipStreamSynchronize(b->stream));
+    // the row copies sit elsewhere in LDS: re-stamp the offset in the eight fused tables
+    std::vector<BatchFit> tabs((size_t)8 * (size_t)b->K);
+    NMRFIT_HIP(hipMemcpy(tabs.data(), b->d_tables, tabs.size() * sizeof(BatchFit), hipMemcpyDeviceToHost));
+    for (BatchFit &f : tabs) f.upd.xrow_off = xrow_offset(b, mode);
+    NMRFIT_HIP(hipMemcpy(b->d_tables, tabs.data(), tabs.size() * sizeof(BatchFit), hipMemcpyHostToDevice));
+    b->mode = mode;
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_geometry(const nmrfit_batch *b, int32_t *mode, int32_t *waves_per_workgroup, int32_t *segments, int64_t *workgroups)
+{
+    if (!b) {
+        set_error("null batch handle");
+        return NMRFIT_E_INVALID;
+    }
+    const BatchLaunch &g = b->geom[b->mode];
+    if (mode) *mode = b->mode;
+    if (waves_per_workgroup) *waves_per_workgroup = g.wpb;
+    if (segments) *segments = g.nseg;
+    if (workgroups) *workgroups = g.blocks_per_fit * b->K;
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_synchronize(nmrfit_batch *b)
+{
+    int rc = bind_batch(b);
+    if (rc != NMRFIT_OK) return rc;
+    NMRFIT_HIP(hipStreamSynchronize(b->stream));
+    return NMRFIT_OK;
+}
+
+// swarm state of fit k (any pointer may be NULL): x, v, p are S x D_k; fx, fp are S
+int nmrfit_batch_get_state(nmrfit_batch *b, int32_t k, double *x, double *v, double *p, double *fx, double *fp)
+{
+    int rc = bind_batch(b);
+    if (rc != NMRFIT_OK) return rc;
+    if (k < 0 || k >= b->K || !b->initialized) {
+        set_error("nmrfit_batch_get_state: fit index out of range, or before the first generation");
+        return NMRFIT_E_INVALID;
+    }
+    if ((rc = flush_fold(b)) != NMRFIT_OK) return rc;
+    BatchFit f;
+    NMRFIT_HIP(hipMemcpy(&f, table(b, b->xp + 2 * b->b) + k, sizeof f, hipMemcpyDeviceToHost));
+    const size_t sd = (size_t)(b->S * b->D[(size_t)k]) * sizeof(double), s1 = (size_t)b->S * sizeof(double);
+    hipStream_t st = b->stream;
+    if (x) NMRFIT_HIP(hipMemcpyAsync(x, f.upd.x_in, sd, hipMemcpyDeviceToHost, st));
+    if (v) NMRFIT_HIP(hipMemcpyAsync(v, f.upd.v_in, sd, hipMemcpyDeviceToHost, st));
+    if (p) NMRFIT_HIP(hipMemcpyAsync(p, f.upd.p, sd, hipMemcpyDeviceToHost, st));
+    if (fx) NMRFIT_HIP(hipMemcpyAsync(fx, f.fx, s1, hipMemcpyDeviceToHost, st));
+    if (fp) NMRFIT_HIP(hipMemcpyAsync(fp, f.upd.p + b->S * b->D[(size_t)k], s1, hipMemcpyDeviceToHost, st));
+    NMRFIT_HIP(hipStreamSynchronize(st));
+    return NMRFIT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// batch_internal.h -- shared by batch.hip (host side of the device-batched fits) and objective_batch.hip (the kernel
+// instantiations): the per-fit descriptor the batched objective kernel reads, and the launch record.
+#pragma once
+#include "objective_launch.h"
+
+namespace nmrfit {
+
+// One fit of a batch, as the kernel sees it: its spectrum (the `args=(w, u, v, weights)` tuple of nmrfit/utils.py:176,
+// prepared like a context's arrays: centred, padded, grid_slot order), its peak count and its swarm.  Lives in device
+// memory, one table of K records per buffer phase (batch.hip): the kernel finds its record from blockIdx alone.
+struct BatchFit {
+    const double *wc, *u, *v, *wt;
+    const double2 *chunk;
+    double w0, wspan, lane_step, rec_devk;
+    const double *X;     // positions to evaluate when the launch does not move the swarm (generation 0)
+    double *fx;          // objective values of this launch [S]
+    int32_t P, pad;
+    PsoFused upd;        // x_in == null: plain evaluation of X
+};
+
+struct BatchLaunch {
+    hipStream_t stream;
+    const BatchFit *fits;   // device, K records
+    int32_t K;
+    int64_t S;              // particles per fit
+    int64_t N;
+    int nseg;
+    int64_t seg_len;
+    int blk_chunks;
+    int wpb;                // 4 or 8 (workgroup = particle), or 4 with one particle per WAVE (wave_swarm)
+    bool wave_swarm;
+    int64_t blocks_per_fit;
+    size_t lds;
+    unsigned aux_off;
+    int variant;            // NMRFIT_VARIANT_DEFAULT or NMRFIT_VARIANT_FARFIELD
+};
+
+int launch_objective_batch(const BatchLaunch &a);   // objective_batch.hip
+
+}  // namespace nmrfit

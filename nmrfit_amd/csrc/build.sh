@@ -1,16 +1,41 @@
 #!/bin/bash
-# Builds libnmrfit_amd.so for gfx950 (cross-compiles without a GPU).
+# Builds libnmrfit_amd.so for gfx950 (cross-compiles without a GPU).  The translation units compile in parallel
+# (the objective kernel's instantiations are one unit per selectable variant) and are then linked.
 # Usage: nmrfit_amd/csrc/build.sh [extra hipcc flags]
-#        NMRFIT_LIBNAME=libab_x.so nmrfit_amd/csrc/build.sh -DNMRFIT_INTERLEAVE=2   (A/B builds for tools/ab.py)
+#        nmrfit_amd/csrc/build.sh --ab      the A/B library libnmrfit_amd_ab.so: the product + the A/B kernel variants
+#                                           (BASELINE, NOSKIP, SINGLE, QUAD, STAGED) and the diagnostic entry points of
+#                                           include/nmrfit_amd_diag.h -- what tools/ab.py, bench.py's `variants` entry
+#                                           and the parity tests' reference kernels use
+#        NMRFIT_LIBNAME=libab_x.so nmrfit_amd/csrc/build.sh -DSOMETHING=2   (one-off A/B builds for tools/ab.py)
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 OUT="$ROOT/nmrfit_amd/lib"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
-    -ffp-contract=on -fno-fast-math \
-    -I"$ROOT/include" -I"$HERE" \
-    "$HERE/objective.hip" "$HERE/pso.hip" "$HERE/cabi.hip" "$HERE/comm.hip" -ldl \
-    -o "$OUT/${NMRFIT_LIBNAME:-libnmrfit_amd.so}" "$@"
-echo "built $OUT/${NMRFIT_LIBNAME:-libnmrfit_amd.so}"
+EXTRA=()
+LIBNAME="${NMRFIT_LIBNAME:-libnmrfit_amd.so}"
+UNITS=(objective objective_default objective_farfield objective_norec objective_batch pso batch cabi comm)
+for arg in "$@"; do
+    if [ "$arg" = "--ab" ]; then
+        EXTRA+=(-DNMRFIT_AB_BUILD)
+        LIBNAME="${NMRFIT_LIBNAME:-libnmrfit_amd_ab.so}"
+        UNITS+=(objective_ab)
+    else
+        EXTRA+=("$arg")
+    fi
+done
+OBJ="$(mktemp -d "${TMPDIR:-/tmp}/nmrfit_build.XXXXXX")"
+trap 'rm -rf "$OBJ"' EXIT
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-fast-math -I"$ROOT/include" -I"$HERE")
+pids=()
+for u in "${UNITS[@]}"; do
+    [ -f "$HERE/$u.hip" ] || continue
+    "$HIPCC" "${FLAGS[@]}" "${EXTRA[@]}" -c "$HERE/$u.hip" -o "$OBJ/$u.o" &
+    pids+=($!)
+done
+fail=0
+for p in "${pids[@]}"; do wait "$p" || fail=1; done
+[ "$fail" = 0 ] || { echo "compilation failed" >&2; exit 1; }
+"$HIPCC" --offload-arch=gfx950 -fPIC -shared "$OBJ"/*.o -ldl -o "$OUT/$LIBNAME"
+echo "built $OUT/$LIBNAME"

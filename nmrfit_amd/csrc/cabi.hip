@@ -2,6 +2,7 @@
 // life-cycle, host-pointer and device-pointer forms of the objective / residual calls,
 // device memory and HIP-event timing helpers.  No exception leaves this file.
 #include "nmrfit_internal.h"
+#include "nmrfit_amd_diag.h"
 
 #include <algorithm>
 #include <cmath>
@@ -63,7 +64,30 @@ bool stream_cache_on()
 }
 }  // namespace
 
-static hipError_t take_stream(int device, hipStream_t *out)
+// What the kernels need to know about a grid besides its values: the centring offset, the span, and -- for the Gaussian
+// recurrence -- whether it is uniformly spaced (np.linspace grids, ascending or descending) and how exactly.
+void analyse_grid(const double *w, int64_t N, double *w0_out, double *wspan_out, double *lane_step_out, double *grid_dev_out)
+{
+    const double w0 = w[N / 2];
+    double wspan = 0.0, lane_step = 0.0, grid_dev = 0.0;
+    for (int64_t j = 0; j < N; ++j) wspan = std::fmax(wspan, std::fabs(w[j] - w0));
+    // Measured on the centred values the kernel sees: deviation of every point from the straight line through the ends.
+    if (N >= 2 * kChunk) {
+        const double first = w[0] - w0, step = ((w[N - 1] - w0) - first) / (double)(N - 1);
+        double dev = 0.0;
+        for (int64_t j = 0; j < N; ++j) dev = std::fmax(dev, std::fabs((w[j] - w0) - (first + (double)j * step)));
+        if (step != 0.0 && dev <= 1.0e-6 * std::fabs(step)) {   // NaN fails the test
+            lane_step = step * kWave;
+            grid_dev = 2.0 * dev;
+        }
+    }
+    *w0_out = w0;
+    *wspan_out = wspan;
+    *lane_step_out = lane_step;
+    *grid_dev_out = grid_dev;
+}
+
+hipError_t take_stream(int device, hipStream_t *out)
 {
     if (stream_cache_on()) {
         StreamPool &pool = stream_pool();
@@ -79,7 +103,7 @@ static hipError_t take_stream(int device, hipStream_t *out)
 }
 
 // (the caller has synchronised the stream: nothing is queued on it)
-static void give_stream(int device, hipStream_t s)
+void give_stream(int device, hipStream_t s)
 {
     if (stream_cache_on()) {
         StreamPool &pool = stream_pool();
@@ -90,6 +114,25 @@ static void give_stream(int device, hipStream_t s)
         }
     }
     (void)hipStreamDestroy(s);
+}
+
+// (hipGetDeviceProperties costs about a millisecond: once per device and PROCESS -- a default fit is 30 ms, and
+// fit_many's worker threads come and go)
+int device_info_cached(int device, DeviceInfo *out)
+{
+    static std::mutex dev_lock;
+    static std::vector<DeviceInfo> dev_cache;
+    std::lock_guard<std::mutex> guard(dev_lock);
+    if ((int)dev_cache.size() <= device) dev_cache.resize((size_t)device + 1);
+    if (!dev_cache[(size_t)device].known) {
+        hipDeviceProp_t hp;
+        NMRFIT_HIP(hipGetDeviceProperties(&hp, device));
+        dev_cache[(size_t)device].cus = hp.multiProcessorCount;
+        strncpy(dev_cache[(size_t)device].arch, hp.gcnArchName, sizeof(dev_cache[0].arch) - 1);
+        dev_cache[(size_t)device].known = true;
+    }
+    *out = dev_cache[(size_t)device];
+    return NMRFIT_OK;
 }
 
 static int bind(const nmrfit_ctx *ctx)
@@ -127,6 +170,15 @@ using namespace nmrfit;
 extern "C" {
 
 int nmrfit_abi_version(void) { return NMRFIT_ABI_VERSION; }
+
+int nmrfit_diag_ab_build(void)
+{
+#ifdef NMRFIT_AB_BUILD
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 const char *nmrfit_last_error(void) { return g_last_error.c_str(); }
 
@@ -212,22 +264,8 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
         return NMRFIT_E_NO_DEVICE;
     }
     NMRFIT_HIP(hipSetDevice(device));
-    // (hipGetDeviceProperties costs about a millisecond: once per device and process -- a default fit is 30 ms)
-    struct DevInfo {
-        bool known = false;
-        int cus = 0;
-        char arch[64] = {0};
-    };
-    static thread_local std::vector<DevInfo> dev_cache;
-    if ((int)dev_cache.size() <= device) dev_cache.resize((size_t)device + 1);
-    if (!dev_cache[(size_t)device].known) {
-        hipDeviceProp_t prop;
-        NMRFIT_HIP(hipGetDeviceProperties(&prop, device));
-        dev_cache[(size_t)device].cus = prop.multiProcessorCount;
-        strncpy(dev_cache[(size_t)device].arch, prop.gcnArchName, sizeof(dev_cache[0].arch) - 1);
-        dev_cache[(size_t)device].known = true;
-    }
-    const DevInfo &prop = dev_cache[(size_t)device];
+    DeviceInfo prop;
+    if ((rc = device_info_cached(device, &prop)) != NMRFIT_OK) return rc;
     if (strncmp(prop.arch, "gfx950", 6) != 0) {
         set_error(std::string("device is ") + prop.arch + ", this library is built for gfx950 only");
         return NMRFIT_E_NO_DEVICE;
@@ -246,21 +284,13 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
     // test knob: run a whole test suite with another kernel variant as every context's default
     if (const char *dv = getenv("NMRFIT_DEFAULT_VARIANT")) {
         const int vnum = atoi(dv);
+#ifdef NMRFIT_AB_BUILD
         if (vnum >= 0 && vnum <= NMRFIT_VARIANT_NOREC) ctx->variant = vnum;
+#else
+        if (vnum == NMRFIT_VARIANT_DEFAULT || vnum == NMRFIT_VARIANT_FARFIELD || vnum == NMRFIT_VARIANT_NOREC) ctx->variant = vnum;
+#endif
     }
-    ctx->w0 = w[N / 2];
-    for (int64_t j = 0; j < N; ++j) ctx->wspan = std::fmax(ctx->wspan, std::fabs(w[j] - ctx->w0));
-    // Uniform spacing (np.linspace grids, ascending or descending)?  Measured on the centred
-    // values the kernel sees: deviation of every point from the straight line through the ends.
-    if (N >= 2 * kChunk) {
-        const double first = w[0] - ctx->w0, step = ((w[N - 1] - ctx->w0) - first) / (double)(N - 1);
-        double dev = 0.0;
-        for (int64_t j = 0; j < N; ++j) dev = std::fmax(dev, std::fabs((w[j] - ctx->w0) - (first + (double)j * step)));
-        if (step != 0.0 && dev <= 1.0e-6 * std::fabs(step)) {   // NaN fails the test
-            ctx->lane_step = step * kWave;
-            ctx->grid_dev = 2.0 * dev;
-        }
-    }
+    analyse_grid(w, N, &ctx->w0, &ctx->wspan, &ctx->lane_step, &ctx->grid_dev);
     const size_t bytes = (size_t)N * sizeof(double);
     const size_t padded = (size_t)ctx->n_chunks * kChunk * sizeof(double);   // whole chunks, grid_slot order
     double *d_w_raw = nullptr;
@@ -369,6 +399,12 @@ int nmrfit_ctx_set_variant(nmrfit_ctx *ctx, int variant)
         set_error("bad context or variant");
         return NMRFIT_E_INVALID;
     }
+#ifndef NMRFIT_AB_BUILD
+    if (variant != NMRFIT_VARIANT_DEFAULT && variant != NMRFIT_VARIANT_FARFIELD && variant != NMRFIT_VARIANT_NOREC) {
+        set_error("this kernel variant is an A/B form: it exists in libnmrfit_amd_ab.so (nmrfit_amd/csrc/build.sh --ab) only");
+        return NMRFIT_E_UNSUPPORTED;
+    }
+#endif
     ctx->variant = variant;
     return NMRFIT_OK;
 }

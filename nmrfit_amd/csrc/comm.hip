@@ -12,12 +12,14 @@
 // the 128-byte unique id travels between the ranks however the caller likes (the Python side
 // uses stdlib sockets, nmrfit_amd/rendezvous.py).
 #include "nmrfit_internal.h"
+#include "nmrfit_amd_diag.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -30,7 +32,9 @@ struct nmrfit_comm {
     int64_t scratch_cap = 0;           // doubles
     double *d_gather = nullptr;        // candidate all-gather: nranks x (D+1), grown on demand
     int64_t gather_cap = 0;
-    int attached = 0;                  // swarms that point at this communicator (nmrfit_pso_set_comm)
+    std::atomic<int> attached{0};      // swarms that point at this communicator (nmrfit_pso_set_comm): at most ONE --
+                                       // the all-gathers of two swarms, issued from two host threads on two streams in
+                                       // whatever order the threads run, would pair up differently on different ranks
 };
 
 namespace nmrfit {
@@ -127,9 +131,14 @@ int bind_comm(const nmrfit_comm *c)
 }  // namespace
 
 nmrfit_ctx *comm_ctx(const nmrfit_comm *c) { return c ? c->ctx : nullptr; }
-void comm_attach(nmrfit_comm *c, int delta)
+bool comm_attach(nmrfit_comm *c)
 {
-    if (c) c->attached += delta;
+    int none = 0;
+    return c && c->attached.compare_exchange_strong(none, 1);   // (fit_many's host threads may race for one communicator)
+}
+void comm_detach(nmrfit_comm *c)
+{
+    if (c) c->attached.store(0);
 }
 
 // used by pso.hip: gather every rank's (D+1)-double record on `stream` -- the stream of the swarm's context, which
@@ -224,7 +233,7 @@ int nmrfit_comm_create(nmrfit_ctx *ctx, int32_t rank, int32_t nranks, const void
 int nmrfit_comm_destroy(nmrfit_comm *c)
 {
     if (!c) return NMRFIT_OK;
-    if (c->attached > 0) {
+    if (c->attached.load() > 0) {
         set_error("nmrfit_comm_destroy: a swarm still uses this communicator (nmrfit_pso_set_comm(pso, NULL) or "
                   "nmrfit_pso_destroy first)");
         return NMRFIT_E_STATE;

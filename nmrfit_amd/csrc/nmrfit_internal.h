@@ -59,6 +59,15 @@ struct PeakWin {
 };
 
 void set_error(const std::string &msg);
+void analyse_grid(const double *w, int64_t N, double *w0, double *wspan, double *lane_step, double *grid_dev);   // cabi.hip
+struct DeviceInfo {
+    bool known = false;
+    int cus = 0;
+    char arch[64] = {0};
+};
+int device_info_cached(int device, DeviceInfo *out);      // cabi.hip: compute units and arch name, once per process
+hipError_t take_stream(int device, hipStream_t *out);     // cabi.hip: a recycled (or new) non-blocking stream
+void give_stream(int device, hipStream_t s);              // ... handed back idle (synchronised)
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 #define NMRFIT_HIP(call)                                                        \
@@ -142,7 +151,8 @@ int scatter_grid(nmrfit_ctx *ctx, const double *d_src, double *d_dst);
 // gather every rank's n-double record over the communicator (comm.hip), on `stream` (the swarm's context's)
 int comm_all_gather(nmrfit_comm *c, hipStream_t stream, const double *d_send, int64_t n, const double **d_all);
 nmrfit_ctx *comm_ctx(const nmrfit_comm *c);       // the context a communicator was created on
-void comm_attach(nmrfit_comm *c, int delta);      // swarms attached to it (destroy order guard)
+bool comm_attach(nmrfit_comm *c);                 // claim it for ONE swarm (false: another swarm holds it); destroy order guard
+void comm_detach(nmrfit_comm *c);
 // per-peak real/imag contributions on a (centred) output grid resident on the device
 // (grid_order: d_wc_out is the context's own centred grid, stored in grid_slot order)
 int launch_contributions(nmrfit_ctx *ctx, int32_t P, const double *dx, int64_t Nout, const double *d_wc_out,

@@ -34,6 +34,7 @@
 //   larger:  the same with the final reduction as its own single-workgroup launch -> 3 launches
 // Multi-rank generations run apply as its own launch after the all-gather.
 #include "nmrfit_internal.h"
+#include "nmrfit_amd_diag.h"
 #include "pso_update.h"
 
 #include <algorithm>
@@ -116,68 +117,7 @@ __device__ __forceinline__ void update_element(int64_t idx, int64_t D, int64_t o
     x[idx] = xn;
 }
 
-// personal best of particle i by one wave (pyswarm: i_update = fx < fp)
-__device__ __forceinline__ void pbest_particle(int64_t i, int lane, int64_t D, const double *x, const double *fx,
-                                               double *p, double *fp)
-{
-    const double f = fx[i];
-    if (!(f < fp[i])) return;
-    for (int64_t d = lane; d < D; d += kWave) p[i * D + d] = x[i * D + d];
-    if (lane == 0) fp[i] = f;
-}
-
-// block-wide first index of the minimum of fp (np.argmin) -> candidate record (fused tail, empty shards).
-// Must be called by every thread of the block (contains a barrier).
-// While no particle has a finite objective yet (every fp still +inf: argmin 0) the record carries x[0] instead
-// of p[0] -- pyswarm seeds g with x[0, :] in that case (its `else` branch after the first evaluation), and the
-// fold's lowest-rank tie-break makes it GLOBAL particle 0's position; tests/test_pso_cpu.py pins this
-// against the restated pyswarm loop.  Later folds ignore a record whose value is +inf.
-__device__ __forceinline__ void argmin_block(int64_t S, int64_t D, const double *fp, const double *p, const double *x,
-                                             double *cand, double *s_val, long long *s_idx)
-{
-    double best = INFINITY;
-    long long bi = 0x7fffffffffffffffLL;
-    for (int64_t i = threadIdx.x; i < S; i += blockDim.x) {
-        const double f = fp[i];
-        if (f < best) {   // strict: the first (lowest) index wins ties within a thread's stride
-            best = f;
-            bi = i;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ob = __shfl_down(best, off, kWave);
-        const long long oi = __shfl_down(bi, off, kWave);
-        if (ob < best || (ob == best && oi < bi)) {
-            best = ob;
-            bi = oi;
-        }
-    }
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    if (lane == 0) {
-        s_val[wave] = best;
-        s_idx[wave] = bi;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const int nw = blockDim.x / kWave;
-        best = (lane < nw) ? s_val[lane] : INFINITY;
-        bi = (lane < nw) ? s_idx[lane] : 0x7fffffffffffffffLL;
-        for (int off = 8; off > 0; off >>= 1) {
-            const double ob = __shfl_down(best, off, kWave);
-            const long long oi = __shfl_down(bi, off, kWave);
-            if (ob < best || (ob == best && oi < bi)) {
-                best = ob;
-                bi = oi;
-            }
-        }
-        bi = __shfl(bi, 0, kWave);
-        if (bi >= S) bi = 0;   // every fp is +inf: np.argmin -> 0
-        const double fbest = (S > 0) ? fp[bi] : INFINITY;
-        const double *row = (fbest < INFINITY) ? p : x;
-        if (lane == 0) cand[0] = fbest;
-        for (int64_t d = lane; d < D; d += kWave) cand[1 + d] = (S > 0) ? row[bi * D + d] : 0.0;
-    }
-}
+// (pbest_particle, argmin_block: pso_update.h -- shared with the device-batched fits, batch.hip)
 
 // ---- stand-alone kernels (large swarms: one launch per phase, many workgroups) ------------
 
@@ -550,9 +490,10 @@ int launch_update(nmrfit_pso *pso)
 int flush_fold(nmrfit_pso *pso)
 {
     if (!pso->fold_pending) return NMRFIT_OK;
-    pso->fold_pending = false;
     TailArgs a = tail_args(pso, ObjectiveDeferred{}, kTailArgmin | kTailApply);
-    return launch_tail(pso, a);
+    const int rc = launch_tail(pso, a);
+    if (rc == NMRFIT_OK) pso->fold_pending = false;   // (a failed launch leaves the generation waiting, as evaluate_and_select does)
+    return rc;
 }
 
 int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init = 0)
@@ -775,7 +716,7 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
 int nmrfit_pso_destroy(nmrfit_pso *pso)
 {
     if (!pso) return NMRFIT_OK;
-    if (pso->comm) comm_attach(pso->comm, -1);
+    if (pso->comm) comm_detach(pso->comm);
     pso->comm = nullptr;
     if (pso->ctx) {
         (void)hipSetDevice(pso->ctx->device);
@@ -875,11 +816,25 @@ int nmrfit_pso_set_comm(nmrfit_pso *pso, nmrfit_comm *comm)
         set_error("nmrfit_pso_set_comm: the communicator was created on another device than the swarm's context");
         return NMRFIT_E_INVALID;
     }
-    if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;
-    NMRFIT_HIP(hipStreamSynchronize(pso->ctx->stream));
-    if (pso->comm) comm_attach(pso->comm, -1);
+    if (comm == pso->comm) return NMRFIT_OK;
+    // ONE swarm at a time per communicator: two swarms' all-gathers -- issued from two host threads on two streams, in
+    // whatever order the threads happen to run -- would pair up differently on different ranks (a hang or mixed-up
+    // records), and both would write the communicator's one gather buffer
+    if (comm && !comm_attach(comm)) {   // (nmrfit_comm_destroy refuses while a swarm still points at it)
+        set_error("nmrfit_pso_set_comm: another swarm is attached to this communicator (one swarm at a time: detach or "
+                  "destroy it first)");
+        return NMRFIT_E_STATE;
+    }
+    if ((rc = flush_fold(pso)) == NMRFIT_OK) {
+        hipError_t e = hipStreamSynchronize(pso->ctx->stream);
+        if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+    }
+    if (rc != NMRFIT_OK) {
+        if (comm) comm_detach(comm);
+        return rc;
+    }
+    if (pso->comm) comm_detach(pso->comm);
     pso->comm = comm;
-    if (comm) comm_attach(comm, +1);   // nmrfit_comm_destroy refuses while a swarm still points at it
     return NMRFIT_OK;
 }
 
@@ -899,6 +854,9 @@ int nmrfit_pso_set_fused_tail(nmrfit_pso *pso, int enable)
         set_error("null swarm handle");
         return NMRFIT_E_INVALID;
     }
+    int rc = bind_pso(pso);
+    if (rc != NMRFIT_OK) return rc;
+    if ((rc = flush_fold(pso)) != NMRFIT_OK) return rc;   // (like its sibling entry points: nothing waits across a change of form)
     pso->fused_tail = enable != 0;
     return NMRFIT_OK;
 }

@@ -226,4 +226,67 @@ __device__ __forceinline__ void apply_wave(int lane, int64_t D, int nranks, int 
     if (lane == 0) flags[0] = flags[0] + 1;
 }
 
+// personal best of particle i by one wave (pyswarm: i_update = fx < fp)
+__device__ __forceinline__ void pbest_particle(int64_t i, int lane, int64_t D, const double *x, const double *fx,
+                                               double *p, double *fp)
+{
+    const double f = fx[i];
+    if (!(f < fp[i])) return;
+    for (int64_t d = lane; d < D; d += kWave) p[i * D + d] = x[i * D + d];
+    if (lane == 0) fp[i] = f;
+}
+
+// block-wide first index of the minimum of fp (np.argmin) -> candidate record (fused tail, empty shards).
+// Must be called by every thread of the block (contains a barrier).
+// While no particle has a finite objective yet (every fp still +inf: argmin 0) the record carries x[0] instead
+// of p[0] -- pyswarm seeds g with x[0, :] in that case (its `else` branch after the first evaluation), and the
+// fold's lowest-rank tie-break makes it GLOBAL particle 0's position; tests/test_pso_cpu.py pins this
+// against the restated pyswarm loop.  Later folds ignore a record whose value is +inf.
+__device__ __forceinline__ void argmin_block(int64_t S, int64_t D, const double *fp, const double *p, const double *x,
+                                             double *cand, double *s_val, long long *s_idx)
+{
+    double best = INFINITY;
+    long long bi = 0x7fffffffffffffffLL;
+    for (int64_t i = threadIdx.x; i < S; i += blockDim.x) {
+        const double f = fp[i];
+        if (f < best) {   // strict: the first (lowest) index wins ties within a thread's stride
+            best = f;
+            bi = i;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_down(best, off, kWave);
+        const long long oi = __shfl_down(bi, off, kWave);
+        if (ob < best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_val[wave] = best;
+        s_idx[wave] = bi;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int nw = blockDim.x / kWave;
+        best = (lane < nw) ? s_val[lane] : INFINITY;
+        bi = (lane < nw) ? s_idx[lane] : 0x7fffffffffffffffLL;
+        for (int off = 8; off > 0; off >>= 1) {
+            const double ob = __shfl_down(best, off, kWave);
+            const long long oi = __shfl_down(bi, off, kWave);
+            if (ob < best || (ob == best && oi < bi)) {
+                best = ob;
+                bi = oi;
+            }
+        }
+        bi = __shfl(bi, 0, kWave);
+        if (bi >= S) bi = 0;   // every fp is +inf: np.argmin -> 0
+        const double fbest = (S > 0) ? fp[bi] : INFINITY;
+        const double *row = (fbest < INFINITY) ? p : x;
+        if (lane == 0) cand[0] = fbest;
+        for (int64_t d = lane; d < D; d += kWave) cand[1 + d] = (S > 0) ? row[bi * D + d] : 0.0;
+    }
+}
+
 }  // namespace nmrfit

@@ -35,6 +35,7 @@ anything else, so a stray connection cannot join the group.
 was where and ends the process, so that the launcher sees a failed rank instead of a hang.
 """
 import hashlib
+import hmac
 import os
 import socket
 import struct
@@ -221,9 +222,23 @@ class Channel:
                     resolved = host
                 multi_node = self.world > int(os.environ.get("LOCAL_WORLD_SIZE", self.world))
                 if multi_node and resolved.startswith("127."):
+                    # rank 0 cannot listen where MASTER_ADDR points: NMRFIT_RDZV_BIND names the address to bind; failing
+                    # that every interface -- but then only behind a secret the launcher set (the derived token is made
+                    # of values anybody on the network can guess)
+                    bind_to = os.environ.get("NMRFIT_RDZV_BIND")
+                    if bind_to:
+                        host = bind_to
+                    elif not os.environ.get("NMRFIT_RDZV_TOKEN"):
+                        ls.close()
+                        raise OSError("rendezvous: MASTER_ADDR=%s resolves to %s on rank 0 but the ranks span several "
+                                      "nodes.  Set NMRFIT_RDZV_BIND to the address of the interface the other nodes "
+                                      "reach, or NMRFIT_RDZV_TOKEN (a shared secret) to listen on every interface"
+                                      % (host, resolved))
+                    else:
+                        host = ""
                     sys.stderr.write("nmrfit rendezvous: MASTER_ADDR=%s resolves to %s on rank 0 but the ranks span "
-                                     "several nodes: listening on every interface, port %s\n" % (host, resolved, port_env))
-                    host = ""
+                                     "several nodes: listening on %s, port %s\n"
+                                     % (os.environ.get("MASTER_ADDR"), resolved, host or "every interface", port_env))
                 elif multi_node:
                     sys.stderr.write("nmrfit rendezvous: rank 0 listening on %s (%s) port %s\n" % (host, resolved, port_env))
                 try:
@@ -255,7 +270,7 @@ class Channel:
                 try:
                     conn.settimeout(10.0)
                     hello = _recv(conn)
-                    ok = hello.startswith(_MAGIC) and hello[len(_MAGIC) + 4:] == tok
+                    ok = hello.startswith(_MAGIC) and hmac.compare_digest(hello[len(_MAGIC) + 4:], tok)
                     peer = struct.unpack("<i", hello[len(_MAGIC):len(_MAGIC) + 4])[0] if ok else -1
                     if not ok or not (0 < peer < self.world) or peer in self._peers:
                         conn.close()

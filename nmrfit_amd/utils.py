@@ -30,25 +30,31 @@ from .peaks import (AutoPeakSelector, BoundsSelector, Peak, Peaks, find_peak, rn
 
 
 def compute_weights(w, peaks, expon=0.5):
-    """FitUtility._compute_weights (utils.py:191-224): ones, then per peak region
-    weights[l:r+1] = (max|height| / |height_i|)**expon (later peaks overwrite earlier ones),
-    then 10 Laplacian smoothing sweeps.  Host code in the reference too (once per fit).
-    np.int (utils.py:201-202) no longer exists in numpy; plain int is the same type."""
-    w = np.asarray(w)
-    n = len(peaks)
-    lIdx = np.zeros(n, dtype=int)
-    rIdx = np.zeros(n, dtype=int)
-    maxabs = np.zeros(n)
-    for i, p in enumerate(peaks):
-        lIdx[i] = np.argmin(np.abs(w - p.bounds[0]))
-        rIdx[i] = np.argmin(np.abs(w - p.bounds[1]))
-        if lIdx[i] > rIdx[i]:
-            lIdx[i], rIdx[i] = rIdx[i], lIdx[i]
-        maxabs[i] = np.abs(p.height)
-    biggest = np.amax(maxabs)
-    weights = np.ones(len(w)) * 1.0
-    for i in range(n):
-        weights[lIdx[i]:rIdx[i] + 1] = np.power(biggest / maxabs[i], expon)
+    """The ``weights`` array of a fit: what FitUtility._compute_weights produces (nmrfit/utils.py:191-224),
+    computed once per fit on the host as the reference does.
+
+    Every peak claims the grid points between the two points nearest to its ``bounds``, at weight
+    ``(tallest |height| / its |height|) ** expon``; where regions overlap the LAST peak in ``peaks`` wins (the
+    reference assigns the slices in list order); unclaimed points weigh 1.  Ten Laplacian sweeps
+    (``equations.laplace1d``) then round the steps off.  Here the claim is resolved for all peaks at once on a
+    (peak, point) membership mask -- which peak owns a point is the highest peak index whose region holds it --
+    and the weights are gathered through that owner index, instead of one slice assignment per peak."""
+    grid = np.asarray(w, dtype=float)
+    if len(peaks) == 0:
+        return equations.laplace1d(np.ones(grid.size))
+    edges = np.array([[pk.bounds[0], pk.bounds[1]] for pk in peaks], dtype=float)           # (P, 2)
+    heights = np.abs(np.array([pk.height for pk in peaks], dtype=float))
+    # nearest grid point to each region edge (first one on ties, like argmin), edges sorted per region
+    nearest = np.abs(grid[None, None, :] - edges[:, :, None]).argmin(axis=2)
+    first, last = nearest.min(axis=1), nearest.max(axis=1)
+    # per-peak level: scalar power, one value per peak (numpy's array power may take a vectorised libm whose last
+    # bit differs from the scalar one the reference's per-peak call goes through)
+    top = heights.max()
+    level = np.array([np.power(top / h, expon) for h in heights])
+    j = np.arange(grid.size)
+    member = (j[None, :] >= first[:, None]) & (j[None, :] <= last[:, None])                # (P, N)
+    owner = len(peaks) - 1 - member[::-1].argmax(axis=0)                                   # highest claiming peak index
+    weights = np.where(member.any(axis=0), level[owner], 1.0)
     return equations.laplace1d(weights)
 
 
@@ -85,29 +91,54 @@ def default_variant(N, P, fit_im=False):
 
 
 def generate_solution_bounds(peaks, p0=0.0, p1=0.0, force_p0=False, force_p1=False):
-    """Parameter box for a fit, as Data.generate_solution_bounds builds it
-    (nmrfit/containers.py:175-217): phases in [-pi, pi] (or the estimate +- 0.001 when forced),
-    r in [0, 1], yoff in [-0.01, 0.01], then per peak width in [0.5, 1.5]*width,
-    loc - 0.1*(loc - bounds[0|1]) and area in [0.5, 1.5]*area.  Returns (lower, upper) lists."""
-    lower, upper = [], []
-    if force_p0 is True:
-        upper.append(p0 + 0.001)
-        lower.append(p0 - 0.001)
-    else:
-        upper.append(np.pi)
-        lower.append(-np.pi)
-    if force_p1 is True:
-        upper.append(p1 + 0.001)
-        lower.append(p1 - 0.001)
-    else:
-        upper.append(np.pi)
-        lower.append(-np.pi)
-    upper.extend([1.0, 0.01])
-    lower.extend([0.0, -0.01])
-    for p in peaks:
-        lower.extend([p.width * 0.5, p.loc - 0.1 * (p.loc - p.bounds[0]), p.area * 0.5])
-        upper.extend([p.width * 1.5, p.loc - 0.1 * (p.loc - p.bounds[1]), p.area * 1.5])
-    return lower, upper
+    """The parameter box of a fit, as Data.generate_solution_bounds lays it out (nmrfit/containers.py:175-217),
+    in the parameter order of the objective (section a4: p0, p1, r, yoff, then width, loc, area per peak):
+
+        p0, p1   [-pi, pi], or the estimate +- 0.001 when ``force_p0`` / ``force_p1`` is True
+        r        [0, 1]            yoff  [-0.01, 0.01]
+        width    [0.5, 1.5] x the peak's width
+        loc      a tenth of the way from the peak's centre to either region bound
+        area     [0.5, 1.5] x the peak's area
+
+    Built as two (4 + 3P) arrays -- the per-peak block is one (P, 3) table per side -- and returned as the plain
+    lists ``(lower, upper)`` the reference returns."""
+    def phase_box(estimate, forced):
+        return (estimate - 0.001, estimate + 0.001) if forced is True else (-np.pi, np.pi)
+    head = np.array([phase_box(p0, force_p0), phase_box(p1, force_p1), (0.0, 1.0), (-0.01, 0.01)])   # (4, 2)
+    if len(peaks) == 0:
+        return head[:, 0].tolist(), head[:, 1].tolist()
+    width = np.array([pk.width for pk in peaks], dtype=float)
+    loc = np.array([pk.loc for pk in peaks], dtype=float)
+    area = np.array([pk.area for pk in peaks], dtype=float)
+    edge = np.array([[pk.bounds[0], pk.bounds[1]] for pk in peaks], dtype=float)           # (P, 2)
+    sides = []
+    for side, scale in ((0, 0.5), (1, 1.5)):
+        block = np.stack([width * scale, loc - 0.1 * (loc - edge[:, side]), area * scale], axis=1)   # (P, 3)
+        sides.append(np.concatenate([head[:, side], block.ravel()]).tolist())
+    return sides[0], sides[1]
+
+
+# A swarm generation costs at least one objective launch plus, sharded, one all-gather and one fold launch (~15-25 us of
+# latency on xGMI whatever the payload): below this much work per rank and generation the exchange costs more than
+# the shard saves, and the fit is FASTER on one GPU (the reference's default 204 x 4096 x 6 is 5e6 units, 11.7 us).
+SMALL_SHARD_UNITS = 1.0e8
+
+
+def small_shard_warning(S_local, N, P, world, rank=0):
+    """Warn (rank 0, once per call) when options['exchange'] shards a swarm whose per-rank generation is shorter than
+    the exchange it adds: independent fits scale across GPUs as REPLICAS -- ``nmrfit_amd.fit_many(jobs, shard=True)``
+    gives each rank its own spectra and needs no collective (nmrfit/utils.py:182 is the reference's counterpart: a
+    process pool over particles).  Returns True when the warning applies."""
+    units = float(S_local) * float(N) * float(max(P, 1))
+    if world <= 1 or units >= SMALL_SHARD_UNITS:
+        return False
+    if rank == 0:
+        import warnings
+        warnings.warn("nmrfit: sharding this swarm over %d GPUs leaves %.2g particle x point x peak units per rank and "
+                      "generation (< %.0e): the per-generation exchange costs more than the shard saves, one GPU is "
+                      "faster.  For many spectra use nmrfit_amd.fit_many(jobs, shard=True): the ranks fit different "
+                      "spectra and exchange nothing." % (world, units, SMALL_SHARD_UNITS), RuntimeWarning, stacklevel=3)
+    return True
 
 
 class FitUtility:
@@ -149,27 +180,56 @@ class FitUtility:
                 self._device_note_shown = True
         return 0 if device is None else int(device)
 
-    def fit(self):
-        """utils.py:164-189: weights, minimise, store params/error, optional summary."""
+    def _plan(self):
+        """What fit() decides before anything touches the GPU (utils.py:164-181): the weights, the swarm's constants and
+        size, the seed, the kernel variant.  Shared by fit() and by core.fit_many's device-batched path."""
         self.weights = self._compute_weights()
         if self.dynamic_weighting is False:
             self.weights = np.ones_like(self.weights)
-
         opt = self.options
-        kw = dict(omega=opt.get('omega', pso.DEFAULTS['omega']), phip=opt.get('phip', pso.DEFAULTS['phip']),
-                  phig=opt.get('phig', pso.DEFAULTS['phig']), minstep=opt.get('minstep', pso.DEFAULTS['minstep']),
-                  minfunc=opt.get('minfunc', pso.DEFAULTS['minfunc']))
-        swarmsize = opt.get('swarmsize', pso.DEFAULTS['swarmsize'])
-        maxiter = opt.get('maxiter', pso.DEFAULTS['maxiter'])
+        plan = dict(kw=dict(omega=opt.get('omega', pso.DEFAULTS['omega']), phip=opt.get('phip', pso.DEFAULTS['phip']),
+                            phig=opt.get('phig', pso.DEFAULTS['phig']), minstep=opt.get('minstep', pso.DEFAULTS['minstep']),
+                            minfunc=opt.get('minfunc', pso.DEFAULTS['minfunc'])),
+                    swarmsize=opt.get('swarmsize', pso.DEFAULTS['swarmsize']),
+                    maxiter=opt.get('maxiter', pso.DEFAULTS['maxiter']), check_every=opt.get('check_every', 64))
         seed = opt.get('seed')
         if seed is None:     # pyswarm draws from numpy's unseeded global RNG: do the equivalent
             seed = int(np.random.SeedSequence().generate_state(1, dtype=np.uint64)[0])
         self.seed = seed     # (extra attribute: the seed this fit ran with -- rank 0's in a multi-rank fit)
+        plan['seed'] = seed
+        # kernel variant: by name or number, default by problem size (default_variant above)
+        n_peaks = (len(self.lower) - 4) // 3
+        plan['n_peaks'] = n_peaks
+        plan['variant'] = _cabi.variant_id(opt.get('variant', default_variant(len(self.data.w), n_peaks, self.fit_im)))
+        return plan
+
+    def _batch_key(self, plan):
+        """The key under which core.fit_many may put this fit into a device batch with others (csrc/batch.hip: equal
+        grid length, swarm size and kernel variant, real part only) -- or None when it must run on its own."""
+        opt = self.options
+        if equations.fit_im_mode(self.fit_im) != _cabi.FIT_IM_OFF or opt.get('exchange') is not None or opt.get('polish', False):
+            return None
+        if plan['variant'] not in (_cabi.VARIANT_DEFAULT, _cabi.VARIANT_FARFIELD) or len(self.lower) > 400:
+            return None
+        return (self._device(), len(self.data.w), int(plan['swarmsize']), plan['variant'], int(plan['maxiter']),
+                int(plan['check_every']))
+
+    def _finish(self, xopt, fopt):
+        self.params = xopt
+        self.error = fopt
+        if self.summary is True:
+            self._print_summary()
+
+    def fit(self):
+        """utils.py:164-189: weights, minimise, store params/error, optional summary."""
+        plan = self._plan()
+        opt = self.options
+        kw, swarmsize, maxiter, seed = plan['kw'], plan['swarmsize'], plan['maxiter'], plan['seed']
         # Multi-GPU fits (one process per GPU, every rank makes the same fit() call):
         # options['exchange'] = "rccl" builds the RCCL communicator from the launcher's
         # environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; nmrfit_amd.rendezvous), or pass a
         # ready pso.RcclExchange (used as it is, fit after fit: a communicator serves any context of its
-        # device) / SocketExchange / TorchExchange.
+        # device) / an exchange object with the same interface (tests).
         exchange = opt.get('exchange')
         own_exchange = False
         if isinstance(exchange, str) and exchange.lower() != "rccl":
@@ -189,21 +249,20 @@ class FitUtility:
                 if exchange.channel is None or not exchange.handle.value:
                     raise ValueError("options['exchange']: this RcclExchange has been closed")
             ev.set_fit_im(self.fit_im)     # True: the reference's imaginary term (equations.py:197-209)
-            # kernel variant: by name or number, default by problem size (default_variant above)
-            n_peaks = (len(self.lower) - 4) // 3
-            ev.set_variant(_cabi.variant_id(opt.get('variant', default_variant(len(self.data.w), n_peaks, self.fit_im))))
+            ev.set_variant(plan['variant'])
             if exchange is None or (exchange.world == 1 and not isinstance(exchange, pso.RcclExchange)):
                 xopt, fopt = pso.pso(ev, self.lower, self.upper, swarmsize=swarmsize, maxiter=maxiter, seed=seed,
-                                     check_every=opt.get('check_every', 64), verbose=True, **kw)
+                                     check_every=plan['check_every'], verbose=True, **kw)
             else:
                 # every rank must run the same swarm: rank 0's seed wins (an unseeded fit would
                 # otherwise draw a different seed on every rank)
                 seed = exchange.broadcast_seed(seed)
                 self.seed = seed
                 off, n = pso.shard(swarmsize, exchange.rank, exchange.world)
+                small_shard_warning(n, len(self.data.w), plan['n_peaks'], exchange.world, rank=exchange.rank)
                 sw = pso.DeviceSwarm(ev, self.lower, self.upper, swarmsize, offset=off, S_local=n, seed=seed, **kw)
                 try:
-                    xopt, fopt = pso.run_sharded(sw, exchange, maxiter, check_every=opt.get('check_every', 64),
+                    xopt, fopt = pso.run_sharded(sw, exchange, maxiter, check_every=plan['check_every'],
                                                  verbose=True)
                 finally:
                     sw.close()
@@ -216,11 +275,7 @@ class FitUtility:
             if own_exchange:
                 exchange.close()
             ev.close()
-
-        self.params = xopt
-        self.error = fopt
-        if self.summary is True:
-            self._print_summary()
+        self._finish(xopt, fopt)
 
     def generate_result(self, scale=1):
         """utils.py:226-295: per-peak real and imaginary contributions of the fitted parameters
@@ -278,15 +333,20 @@ class FitUtility:
         return sats / (peaks + sats)
 
     def _print_summary(self):
-        """utils.py:324-339."""
-        import pandas as pd
-        res = np.array(self.params)
-        res_globals = pd.DataFrame(res[:4].reshape((1, -1)), columns=['p0', 'p1', 'r', 'y-off'])
-        res = pd.DataFrame(res[4:].reshape((-1, 3)), columns=['width', 'location', 'area'])
-        print('\nFit Summary:')
-        print('------------')
-        print('Global parameters')
-        print(res_globals.to_string(index=False))
-        print('\nPeak parameters')
-        print(res.to_string(index=False))
+        """What FitUtility._print_summary reports (nmrfit/utils.py:324-339): the four global parameters, one row
+        per peak, the error.  Plain text tables; no pandas needed."""
+        values = np.asarray(self.params, dtype=float)
+
+        def table(header, rows):
+            cells = [["%.6g" % x for x in row] for row in rows]
+            widths = [max(len(h), *(len(c[k]) for c in cells)) for k, h in enumerate(header)]
+            lines = [" ".join(h.rjust(n) for h, n in zip(header, widths))]
+            lines += [" ".join(c.rjust(n) for c, n in zip(row, widths)) for row in cells]
+            return "\n".join(lines)
+        print("\nFit Summary:")
+        print("------------")
+        print("Global parameters")
+        print(table(["p0", "p1", "r", "y-off"], [values[:4]]))
+        print("\nPeak parameters")
+        print(table(["width", "location", "area"], values[4:].reshape(-1, 3)))
         print("Error:\t", self.error)

@@ -15,8 +15,8 @@ from nmrfit_amd import _cabi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "nmrfit_amd.h")).read()
+def _declared_symbols(header="nmrfit_amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(nmrfit_[a-z0-9_]+)\s*\(", text)))
 
@@ -25,16 +25,35 @@ def test_library_is_built_and_exports_every_declared_symbol():
     if not os.path.exists(_cabi.LIB_PATH):
         _cabi.build()
     L = ctypes.CDLL(_cabi.LIB_PATH)
-    names = _declared_symbols()
-    assert len(names) >= 30
+    names = _declared_symbols() + _declared_symbols("nmrfit_amd_diag.h")
+    assert len(names) >= 60
     for n in names:
         assert hasattr(L, n), "libnmrfit_amd.so does not export " + n
 
 
 def test_ctypes_table_covers_header():
+    """The product interface (include/nmrfit_amd.h: what a binding for the hot path binds) and the diagnostic one
+    (include/nmrfit_amd_diag.h) against the two ctypes tables; the product header stays a thin interface."""
     names = set(_declared_symbols())
     bound = set(_cabi.SIGNATURES) | {"nmrfit_last_error"}
     assert names == bound, (names - bound, bound - names)
+    assert len(names) <= 40, len(names)
+    diag = set(_declared_symbols("nmrfit_amd_diag.h"))
+    assert diag == set(_cabi.DIAG_SIGNATURES), (diag - set(_cabi.DIAG_SIGNATURES), set(_cabi.DIAG_SIGNATURES) - diag)
+    assert not (names & diag)
+
+
+def test_ab_variants_exist_in_the_ab_library_only():
+    """The A/B kernel forms are not part of the product: the product library refuses them by name (no GPU needed:
+    the check precedes any device work), the A/B library says what it is."""
+    L = _cabi.lib()
+    if os.environ.get("NMRFIT_LIB"):
+        pytest.skip("another library is loaded through NMRFIT_LIB")
+    assert L.nmrfit_diag_ab_build() == 0
+    assert not _cabi.has_ab_variants() and _cabi.available_variants() == [0, 6, 7]
+    if os.path.exists(_cabi.AB_LIB_PATH):
+        A = ctypes.CDLL(_cabi.AB_LIB_PATH)
+        assert A.nmrfit_diag_ab_build() == 1
 
 
 def test_abi_version():

@@ -1,0 +1,197 @@
+"""
+GPU tier: device-batched fits (nmrfit_batch_*, csrc/batch.hip + objective_batch.hip).  K independent fits advance
+together, one launch per generation for all of them; the bar is that every fit's trajectory -- positions, velocities,
+personal bests, (g, fg), the stopping generation and the returned (params, error) -- is BIT-IDENTICAL to what the same
+fit does alone through nmrfit_pso_* / nmrfit_amd.fit (whose own trajectory is pinned against the restated pyswarm and
+the numpy mirror in tests/test_gpu_pso.py), in both launch geometries.  Reference: the per-spectrum loop over
+nmrfit.fit (nmrfit/core.py:64, README.md:64-66), 204 particles each (nmrfit/utils.py:177).
+"""
+import numpy as np
+import pytest
+
+from nmrfit_amd import _cabi, pso, synth
+from nmrfit_amd.batch import FitBatch
+from nmrfit_amd.equations import Evaluator
+
+pytestmark = pytest.mark.gpu
+
+
+def _problems(K, N=4096, peaks=(6, 4, 9, 1, 7, 6, 12, 3), seed0=40):
+    out = []
+    for k in range(K):
+        sp = synth.make_spectrum(N, peaks[k % len(peaks)], seed=seed0 + k)
+        out.append(sp)
+    return out
+
+
+def _lone_swarms(problems, S, seeds, variant, **kw):
+    evs, sws = [], []
+    for sp, seed in zip(problems, seeds):
+        ev = Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"])
+        ev.set_variant(_cabi.variant_id(variant))
+        sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, **kw)
+        evs.append(ev)
+        sws.append(sw)
+    return evs, sws
+
+
+def _close(evs, sws):
+    for sw in sws:
+        sw.close()
+    for ev in evs:
+        ev.close()
+
+
+def _batch(problems, S, seeds, variant="default", **kw):
+    return FitBatch([(sp["w"], sp["u"], sp["v"], sp["weights"]) for sp in problems], [sp["lower"] for sp in problems],
+                    [sp["upper"] for sp in problems], swarmsize=S, seeds=seeds, variant=variant, **kw)
+
+
+@pytest.mark.parametrize("geometry", ["workgroup", "wave"])
+@pytest.mark.parametrize("K,S,N", [(1, 204, 4096), (3, 204, 4096), (16, 204, 4096), (5, 50, 4096), (4, 203, 5000),
+                                   (3, 64, 16384)])
+def test_batch_trajectories_equal_lone_swarms_bit_for_bit(K, S, N, geometry):
+    """State after generation 0, after 1, 2, 3 and after 40 generations (read at different phases of the buffer
+    ping-pong), mixed peak counts, swarm sizes that are not multiples of the workgroup, a ragged grid: x, v, p, fp, fx,
+    the iteration counters, fg and the best row of every fit equal the lone swarm's."""
+    problems = _problems(K, N)
+    seeds = [1000 + 7 * k for k in range(K)]
+    kw = dict(minstep=-1.0, minfunc=-1.0)        # stopping rule off: every generation runs
+    evs, sws = _lone_swarms(problems, S, seeds, "default", **kw)
+    try:
+        with _batch(problems, S, seeds, **kw) as fb:
+            fb.set_geometry(geometry)
+            assert fb.geometry()["mode"] == geometry
+            fb.step()                                # generation 0
+            for sw in sws:
+                sw.init()
+                sw.step()                            # (folds generation 0)
+            done = 0
+            for upto in (0, 1, 2, 3, 40):
+                while done < upto:
+                    fb.step()
+                    for sw in sws:
+                        sw.step()
+                    done += 1
+                for k, sw in enumerate(sws):
+                    a, b = fb.state(k), sw.state()
+                    for name in ("x", "v", "p", "fp", "fx"):
+                        np.testing.assert_array_equal(a[name], b[name], err_msg="fit %d %s after %d" % (k, name, upto))
+                st = fb.status()
+                best = fb.best()
+                for k, sw in enumerate(sws):
+                    ls = sw.status()
+                    assert (st[k]["iteration"], st[k]["stop"], st[k]["fg"]) == (ls["iteration"], ls["stop"], ls["fg"]), (k, upto)
+                    xb, fbest = sw.best()
+                    np.testing.assert_array_equal(best[k][0], xb)
+                    assert best[k][1] == fbest
+    finally:
+        _close(evs, sws)
+
+
+@pytest.mark.parametrize("geometry", ["workgroup", "wave"])
+def test_batch_run_stops_every_fit_by_its_own_rule(geometry):
+    """pyswarm's rule on (defaults 1e-8): the fits of a batch stop at different generations, a stopped fit is left alone
+    while the others go on, and (params, error, stopping generation, reason) equal the lone nmrfit_pso_run's."""
+    K, S = 6, 204
+    problems = _problems(K)
+    seeds = [5 + k for k in range(K)]
+    evs, sws = _lone_swarms(problems, S, seeds, "default")
+    try:
+        lone = []
+        for sw in sws:
+            sw.run(600, 7)
+            lone.append((sw.status(), sw.best()))
+        with _batch(problems, S, seeds) as fb:
+            fb.set_geometry(geometry)
+            fb.run(600, 7)
+            st, best = fb.status(), fb.best()
+        stops = set()
+        for k in range(K):
+            ls, (xb, fbest) = lone[k]
+            assert (st[k]["iteration"], st[k]["stop"], st[k]["fg"]) == (ls["iteration"], ls["stop"], ls["fg"]), k
+            np.testing.assert_array_equal(best[k][0], xb)
+            assert best[k][1] == fbest
+            stops.add(ls["iteration"])
+        assert len(stops) > 1, "the fits should not all stop in the same generation: %r" % stops
+    finally:
+        _close(evs, sws)
+
+
+def test_batch_farfield_variant_and_per_fit_constants():
+    """The far-field kernel (what fit() selects from grid x peaks = 1e5 on) and per-fit swarm constants / stopping
+    thresholds."""
+    K, S, N = 3, 96, 16384
+    problems = _problems(K, N, peaks=(12, 9, 14))
+    seeds = [77, 78, 79]
+    omega, phip, phig = [-0.2134, 0.5, -0.1], [-0.3344, 0.5, 1.0], [2.3259, 0.5, 1.5]
+    evs, sws = [], []
+    try:
+        for k, sp in enumerate(problems):
+            ev = Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"])
+            ev.set_variant(_cabi.VARIANT_FARFIELD)
+            sws.append(pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seeds[k], omega=omega[k], phip=phip[k],
+                                       phig=phig[k], minstep=1e-8, minfunc=[1e-8, 1e-5, -1.0][k]))
+            evs.append(ev)
+        for sw in sws:
+            sw.run(120, 16)
+        for geometry in ("workgroup", "wave"):
+            with _batch(problems, S, seeds, variant="farfield", omega=omega, phip=phip, phig=phig,
+                        minfunc=[1e-8, 1e-5, -1.0]) as fb:
+                fb.set_geometry(geometry)
+                fb.run(120, 16)
+                st, best = fb.status(), fb.best()
+            for k, sw in enumerate(sws):
+                ls = sw.status()
+                assert (st[k]["iteration"], st[k]["stop"]) == (ls["iteration"], ls["stop"]), (geometry, k)
+                xb, fbest = sw.best()
+                np.testing.assert_array_equal(best[k][0], xb)
+                assert best[k][1] == fbest
+    finally:
+        _close(evs, sws)
+
+
+def test_fit_many_batches_what_it_can_and_equals_the_plain_loop(capsys):
+    """nmrfit_amd.fit_many: jobs of equal shape go through one device batch, the others (another grid length, fit_im)
+    through fit(); every result equals the plain loop's bit for bit, in job order."""
+    import nmrfit_amd
+    jobs, opts = [], []
+    for k, (N, P) in enumerate([(4096, 6), (4096, 4), (8192, 5), (4096, 7), (4096, 6), (8192, 3)]):
+        sp = synth.make_spectrum(N, P, seed=60 + k)
+        jobs.append((synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"]), list(sp["lower"]), list(sp["upper"])))
+        opts.append({"seed": 300 + k, "maxiter": 80, "swarmsize": 120})
+    loop = [nmrfit_amd.fit(*job, summary=False, options=o) for job, o in zip(jobs, opts)]
+    dict_jobs = [dict(data=j[0], lower=j[1], upper=j[2], options=o) for j, o in zip(jobs, opts)]
+    dict_jobs[3]["fit_im"] = True                     # cannot be batched: runs through fit()
+    loop[3] = nmrfit_amd.fit(*jobs[3], fit_im=True, summary=False, options=opts[3])
+    capsys.readouterr()
+    many = nmrfit_amd.fit_many(dict_jobs, threads=2)
+    out = capsys.readouterr().out
+    assert out.count("Stopping search:") == len(jobs)
+    for a, b in zip(many, loop):
+        np.testing.assert_array_equal(a.params, b.params)
+        assert a.error == b.error
+        np.testing.assert_array_equal(a.weights, b.weights)
+    # batch=False: the threaded path gives the same answers
+    again = nmrfit_amd.fit_many(dict_jobs, threads=3, batch=False)
+    for a, b in zip(again, loop):
+        np.testing.assert_array_equal(a.params, b.params)
+
+
+def test_batch_argument_validation():
+    sp = synth.make_spectrum(4096, 3, seed=1)
+    spec = (sp["w"], sp["u"], sp["v"], sp["weights"])
+    with pytest.raises(AssertionError):
+        FitBatch([spec], [sp["upper"]], [sp["lower"]])
+    with pytest.raises(ValueError):
+        FitBatch([spec, (sp["w"][:100], sp["u"][:100], sp["v"][:100], sp["weights"][:100])], [sp["lower"]] * 2, [sp["upper"]] * 2)
+    with pytest.raises(_cabi.NmrfitError) as ei:
+        FitBatch([spec], [sp["lower"]], [sp["upper"]], variant="norec")
+    assert ei.value.code == _cabi.E_UNSUPPORTED
+    with pytest.raises(_cabi.NmrfitError):
+        FitBatch([spec], [sp["lower"]], [sp["upper"]], device=1 << 20)
+    with FitBatch([spec], [sp["lower"]], [sp["upper"]], swarmsize=16, seeds=[3]) as fb:
+        with pytest.raises(_cabi.NmrfitError):
+            fb.status()                                # before the first generation
+        fb.run(0, 1)
+        assert fb.status()[0]["iteration"] == 0

@@ -511,6 +511,12 @@ def test_communicator_guards(problem):
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev2:
         other = pso.DeviceSwarm(ev2, sp["lower"], sp["upper"], 16, seed=1)
         other.set_comm(ex)                     # another context, the same device
+        # ONE swarm at a time: a second swarm is refused while `other` holds the communicator -- two
+        # swarms' all-gathers, issued from two host threads, would pair up differently on different ranks
+        with pytest.raises(_cabi.NmrfitError) as e:
+            sw.set_comm(ex)
+        assert e.value.code == _cabi.E_STATE and "one swarm at a time" in str(e.value)
+        other.set_comm(ex)                     # (re-attaching the holder is a no-op)
         other.run(3)
         got = other.state()
         for k in want:
@@ -815,22 +821,30 @@ def test_deferred_fold_is_invisible_from_outside(S, N, P):
 
 def test_deferred_fold_survives_a_change_of_kernel_between_generations():
     """A generation is waiting to be folded and the next objective launch cannot do it: the caller switched to a
-    kernel variant without the eight-wave workgroup form (204 x 4096 x 6 is then no longer one workgroup per
-    particle).  launch_objective reports it before launching anything, the swarm folds in a launch of its own and
-    goes on in the two-launch form; switching back resumes the one-launch form.  Against the numpy mirror."""
+    kernel without the eight-wave workgroup form -- an A/B variant (A/B library) or the imaginary channel (every
+    library) -- so that 204 x 4096 x 6 is no longer one workgroup per particle.  launch_objective reports it before
+    launching anything, the swarm folds in a launch of its own and goes on in the two-launch form; switching back
+    resumes the one-launch form.  Against the numpy mirror."""
     from nmrfit_amd import equations
     S, N, P = 204, 4096, 6
     sp = synth.make_spectrum(N, P, seed=13)
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
         kw = dict(minfunc=-1.0, minstep=-1.0)
-        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=5, **kw)
+        mode = [False]
+        host = pso.HostSwarm(lambda X: ev.objective_batch(X, fit_im=mode[0]), sp["lower"], sp["upper"], S, seed=5, **kw)
         dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=5, **kw)
         host.init()
         host.apply_global(host.candidate()[None, :])
         dev.init()
         dev.step()
-        for variant, launches in (("default", 1), ("quad", 2), ("default", 1), ("single", 2), ("farfield", 1)):
+        if _cabi.has_ab_variants():
+            walk = (("default", False, 1), ("quad", False, 2), ("default", False, 1), ("single", False, 2), ("farfield", False, 1))
+        else:
+            walk = (("default", False, 1), ("default", True, 2), ("default", False, 1), ("norec", "sum", 2), ("farfield", False, 1))
+        for variant, fit_im, launches in walk:
             ev.set_variant(_cabi.variant_id(variant))
+            ev.set_fit_im(fit_im)
+            mode[0] = fit_im
             for _ in range(7):
                 host.step_local()
                 host.apply_global(host.candidate()[None, :])
@@ -911,7 +925,8 @@ def test_random_walk_over_the_swarm_interface_matches_the_mirror(seed):
             elif op == 12:
                 dev.set_handover(str(rng.choice(["fast", "fenced", "two_launch"])))
             elif op == 13:                    # another kernel for the generations that follow (the mirror evaluates through the same context)
-                ev.set_variant(_cabi.variant_id(str(rng.choice(["default", "farfield", "norec", "quad", "staged"]))))
+                ev.set_variant(_cabi.variant_id(str(rng.choice(["default", "farfield", "norec", "quad", "staged"] if _cabi.has_ab_variants()
+                                                                  else ["default", "farfield", "norec", "norec", "default"]))))
         check_all("the end (%s)" % log[-12:])
         if seed == 2:
             assert host.stop in (1, 2)        # this one stops on the way: the no-op generations after it are part of the walk

@@ -16,7 +16,7 @@ from nmrfit_amd.equations import Evaluator
 
 def load(path):
     L = ctypes.CDLL(os.path.abspath(path))
-    for name, argtypes in _cabi.SIGNATURES.items():
+    for name, argtypes in _cabi.ALL_SIGNATURES.items():
         if not hasattr(L, name): continue      # (an older build of the library: entry points added since)
         fn = getattr(L, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
     L.nmrfit_last_error.argtypes = []; L.nmrfit_last_error.restype = ctypes.c_char_p

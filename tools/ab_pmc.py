@@ -45,9 +45,9 @@ def main():
     X = synth.make_swarm(sp["lower"], sp["upper"], cfg.S, seed=2, x_true=sp["x_true"])
     for path in a.libs:
         L = ctypes.CDLL(os.path.abspath(path))
-        for name, argtypes in _cabi.SIGNATURES.items():
+        for name, argtypes in _cabi.ALL_SIGNATURES.items():
             if not hasattr(L, name): continue      # (an older build of the library: entry points added since)
-        fn = getattr(L, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
+            fn = getattr(L, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
         L.nmrfit_last_error.argtypes = []; L.nmrfit_last_error.restype = ctypes.c_char_p
         _cabi._LIB = L
         with Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:

@@ -10,7 +10,7 @@ from nmrfit_amd import _cabi, synth, pso
 from nmrfit_amd.equations import Evaluator
 
 L = ctypes.CDLL(os.path.abspath(sys.argv[1]))
-for name, argtypes in _cabi.SIGNATURES.items():
+for name, argtypes in _cabi.ALL_SIGNATURES.items():
     fn = getattr(L, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
 L.nmrfit_last_error.argtypes = []; L.nmrfit_last_error.restype = ctypes.c_char_p
 L.nmrfit_diag_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]

@@ -27,7 +27,9 @@ def demangle(names):
 def resources(extra):
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
-        for src in ("objective.hip", "pso.hip"):
+        for src in ("objective_default.hip", "objective_farfield.hip", "objective_norec.hip", "objective_batch.hip", "objective.hip", "pso.hip", "batch.hip"):
+            if not os.path.exists(os.path.join(CSRC, src)):
+                continue
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
                    "-fno-fast-math", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", os.path.join(CSRC, src),
                    "-o", os.path.join(tmp, "x.o"), "-Rpass-analysis=kernel-resource-usage"] + extra
@@ -65,6 +67,10 @@ def main():
             label = "objective_kernel<%s,%s,fit_im=%d%s>" % (VARIANTS.get(v, v), "residual" if wr else "objective", fi,
                                                             ",8 waves" if m.group(4) == "8" else "")
             selectable = v in (0, 6, 7)
+        mb = re.match(r"objective_batch_kernel<(\d+), (\d+), (true|false)>", name)
+        if mb:
+            label = "objective_batch_kernel<%s,%s>" % (VARIANTS.get(int(mb.group(1)), mb.group(1)),
+                                                       "wave=particle" if mb.group(3) == "true" else "%s waves" % mb.group(2))
         scratch = int(r.get("ScratchSize [bytes/lane]", "0"))
         # (s-spill: scalar registers parked in VGPR lanes -- v_writelane / v_readlane, which are VALU instructions: in a
         # loop they cost issue slots like arithmetic does)

@@ -14,7 +14,7 @@ seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
 if len(sys.argv) > 3:
     import ctypes
     L = ctypes.CDLL(os.path.abspath(sys.argv[3]))
-    for name, argtypes in _cabi.SIGNATURES.items():
+    for name, argtypes in _cabi.ALL_SIGNATURES.items():
         if not hasattr(L, name): continue
         fn = getattr(L, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
     L.nmrfit_last_error.argtypes = []; L.nmrfit_last_error.restype = ctypes.c_char_p

@@ -11,7 +11,7 @@ if len(sys.argv) > 1:      # another build of the library (A/B): tools/small_swa
     import ctypes
     from nmrfit_amd import _cabi
     L = ctypes.CDLL(os.path.abspath(sys.argv[1]))
-    for name, argtypes in _cabi.SIGNATURES.items():
+    for name, argtypes in _cabi.ALL_SIGNATURES.items():
         if not hasattr(L, name): continue
         fn = getattr(L, name); fn.argtypes = argtypes; fn.restype = ctypes.c_int
     L.nmrfit_last_error.argtypes = []; L.nmrfit_last_error.restype = ctypes.c_char_p

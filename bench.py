@@ -37,9 +37,10 @@ EXACTLY K timed generations, each objective kernel bracketed by HIP events on it
 and each step by a mark (nmrfit_prof_*) -> barrier -> max over ranks.
 
 metric  = particle*gridpoint*peak evaluations per second, whole job.
-roofline: SURVEY.md 8(d)(i) streaming-operand byte model (32/P bytes per unit) against 8 TB/s,
-          from the objective kernel's own durations INSIDE the timed loop (kernel <= step is
-          asserted).  `roofline_valu` is the binding resource (fp64 vector-ALU issue).
+roofline: from the objective kernel's own durations INSIDE the timed loop (kernel <= step is
+          asserted).  `roofline` is the binding resource (fp64 vector-ALU issue: issued wave64 VALU instructions
+          per second against 1024 SIMDs x 2.4 GHz / 4 cycles), `roofline_streaming` the metric's "HBM GB/s vs peak"
+          under the streaming-operand model (an effective, L2-served rate).
           Fields that come from committed rocprofv3 --pmc passes rather than from this run are
           marked "from_committed_profile".
 cpu_baseline: the oracle (numpy restatement of the reference, 1 core = the reference's
@@ -96,6 +97,12 @@ def parse():
                          "same script under `rocprofv3 --kernel-trace --pmc ...`, started BEFORE this process touches "
                          "the GPU, give the line its physical HBM traffic and VALU counters live; without them -- or if "
                          "rocprofv3 is missing -- those fields come from the committed passes under profiles/ and say so)")
+    ap.add_argument("--kernel-only", choices=["sparse", "dense"], default=None,
+                    help="child mode (used by this script itself for the `variants` entry and the PMC passes of the "
+                         "every-unit and dense-spectrum cases): no swarm, no CPU legs -- time the objective kernel alone "
+                         "on the workload's synthetic swarm (sparse: SURVEY 8(d) positions; dense: broad overlapping "
+                         "lines) for every variant of --variants and print one small JSON line")
+    ap.add_argument("--variants", default="0", help="--kernel-only: comma-separated NMRFIT_VARIANT_* numbers")
     ap.add_argument("--launch-timeout", type=float, default=300.0, metavar="SECONDS",
                     help="N > 1: deadline of the self-launcher for the whole run, and of every rank for reaching the "
                          "timed region (rendezvous, RCCL communicator, first collective); 0 disables")
@@ -298,15 +305,29 @@ def cpu_baseline(spec, P, budget_s, pool_procs):
 
 
 # ---- live PMC passes (before any GPU call of this process) ----------------------------------------
+GEN_LOOP = ["--steps", "5", "--warmup", "2", "--cpu-seconds", "0", "--no-extras", "--no-other-configs", "--no-pmc",
+            "--preheat-seconds", "0.2"]
+SQ = ["SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"]
 PMC_PASSES = (
-    # (name, extra bench args, counters) -- one rocprofv3 run each: counters of different blocks are collected in
-    # their own passes, with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots)
-    ("sq", [], ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY",
-                "SQ_ACTIVE_INST_ANY", "SQ_WAVES"]),
-    ("fetch", [], ["FETCH_SIZE", "GRBM_GUI_ACTIVE"]),
-    ("write", [], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]),
-    ("sq_farfield", ["--variant", "6"], ["SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"]),
+    # (name, bench args of the child, counters, needs the A/B library) -- one rocprofv3 run each: counters of different
+    # blocks are collected in their own passes, with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+    ("sq", GEN_LOOP, ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY",
+                      "SQ_ACTIVE_INST_ANY", "SQ_WAVES"], False),
+    ("fetch", GEN_LOOP, ["FETCH_SIZE", "GRBM_GUI_ACTIVE"], False),
+    ("write", GEN_LOOP, ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"], False),
+    ("sq_farfield", GEN_LOOP + ["--variant", "6"], SQ, False),
+    # round 5: the cases where every unit is evaluated -- NOSKIP (an A/B kernel: libnmrfit_amd_ab.so) on the sparse
+    # spectrum, the headline and far-field kernels on the dense one -- objective launches only
+    ("sq_noskip", ["--kernel-only", "sparse", "--variants", "2"], SQ, True),
+    ("sq_dense", ["--kernel-only", "dense", "--variants", "0"], SQ, False),
+    ("sq_dense_farfield", ["--kernel-only", "dense", "--variants", "6"], SQ, False),
 )
+
+
+def ab_library():
+    """Path of the A/B library (the product + BASELINE / NOSKIP / SINGLE / QUAD / STAGED kernels), or None."""
+    p = os.path.join(ROOT, "nmrfit_amd", "lib", "libnmrfit_amd_ab.so")
+    return p if os.path.exists(p) else None
 
 
 def live_pmc_passes(timeout_s=90.0):
@@ -324,19 +345,24 @@ def live_pmc_passes(timeout_s=90.0):
     if not os.path.exists(exe):
         out["errors"].append("rocprofv3 not found")
         return out
-    for name, extra, counters in PMC_PASSES:
+    for name, child_args, counters, needs_ab in PMC_PASSES:
+        env = dict(os.environ, TMPDIR="/tmp")
+        if needs_ab:
+            if ab_library() is None:
+                out["errors"].append("%s: libnmrfit_amd_ab.so not built" % name)
+                continue
+            env["NMRFIT_LIB"] = ab_library()
         try:
             tmp = tempfile.mkdtemp(prefix="nmrfit_pmc_", dir="/tmp")
         except OSError as e:
             out["errors"].append("%s: %r" % (name, e))
             break
         cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", tmp, "--",
-               sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--cpu-seconds", "0",
-               "--no-extras", "--no-other-configs", "--no-pmc", "--preheat-seconds", "0.2"] + extra
+               sys.executable, os.path.abspath(__file__)] + child_args
         try:
             # its own process group: on a time-out the profiler AND the program under it are ended (by the
             # exact group id started here), not just the profiler's front end
-            pr = subprocess.Popen(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+            pr = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE,
                                   stderr=subprocess.PIPE, text=True, start_new_session=True)
             try:
                 so, se = pr.communicate(timeout=timeout_s)
@@ -364,10 +390,13 @@ def live_pmc_passes(timeout_s=90.0):
                 for row in csv.DictReader(fh):
                     if "objective_kernel" in row["Kernel_Name"]:
                         agg.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            ko = child.get("kernel_only")
+            kms = (list(ko["variants"].values())[0]["kernel_ms"] if ko else
+                   child["kernel_ms"]["mean"] if child.get("kernel_ms") else None)
             out[name] = {"counters": {k: sum(v) / len(v) for k, v in agg.items()},
                          "launches": max((len(v) for v in agg.values()), default=0),
-                         "kernel_ms_in_child": child["kernel_ms"]["mean"] if child.get("kernel_ms") else None,
-                         "clock_mhz_in_child": child.get("roofline_valu", {}).get("clock_mhz_in_run")}
+                         "kernel_ms_in_child": kms,
+                         "clock_mhz_in_child": child.get("roofline", {}).get("clock_mhz_in_run")}
         except Exception as e:     # a profiler hiccup must not cost the run its headline
             out["errors"].append("%s: %r" % (name, e))
         finally:
@@ -400,8 +429,63 @@ def time_objective(ev, S, P, d_x, d_f, reps, heat_s=0.25):
     return float(np.mean(k))
 
 
+VARIANT_NAMES = {0: "default", 1: "baseline", 2: "noskip", 3: "single", 4: "quad", 5: "staged", 6: "farfield", 7: "norec"}
+
+
+def kernel_only(args):
+    """Child mode: the objective kernel alone on the workload's synthetic swarm, for each variant asked for."""
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    from nmrfit_amd import _cabi, synth
+    from nmrfit_amd.equations import Evaluator
+    cfg = synth.CONFIGS[args.workload]
+    S, N, P = (args.swarm_per_gpu or cfg.S), cfg.N, cfg.P
+    spec = synth.make_spectrum(N, P, seed=1)
+    if args.kernel_only == "dense":
+        X = synth.make_dense_swarm(S, P, seed=5, w_lo=float(spec["w"].min()), w_hi=float(spec["w"].max()))
+    else:
+        X = synth.make_swarm(spec["lower"], spec["upper"], S, seed=2, x_true=spec["x_true"])
+    out = {"spectrum": args.kernel_only, "library": os.path.basename(_cabi.lib_path()), "variants": {}}
+    with Evaluator(spec["w"], spec["u"], spec["v"], spec["weights"], device=0) as ev:
+        d_x, d_f = ev.dev_alloc(X.nbytes), ev.dev_alloc(S * 8)
+        ev.upload(d_x, X)
+        f0 = None
+        for v in [int(x) for x in args.variants.split(",")]:
+            ev.set_variant(v)
+            ms = time_objective(ev, S, P, d_x, d_f, max(5, min(args.steps, 20)))
+            f = ev.download(d_f, (S,))
+            f0 = f if f0 is None else f0
+            out["variants"][VARIANT_NAMES[v]] = {
+                "kernel_ms": ms, "units_per_s": float(S) * N * P / (ms * 1e-3),
+                "max_rel_diff_vs_first": float(np.max(np.abs(f - f0) / np.maximum(np.abs(f0), 1e-6)))}
+        ev.dev_free(d_x)
+        ev.dev_free(d_f)
+    os.write(json_fd, (json.dumps({"kernel_only": out}) + "\n").encode())
+
+
+def kernel_only_child(spectrum, variants, use_ab, timeout_s=120.0, extra=()):
+    """Run `bench.py --kernel-only` in a child process (with the A/B library when asked) and return its JSON."""
+    env = dict(os.environ)
+    if use_ab:
+        if ab_library() is None:
+            return {"error": "libnmrfit_amd_ab.so not built (nmrfit_amd/csrc/build.sh --ab)"}
+        env["NMRFIT_LIB"] = ab_library()
+    cmd = [sys.executable, os.path.abspath(__file__), "--kernel-only", spectrum, "--variants",
+           ",".join(str(v) for v in variants)] + list(extra)
+    try:
+        pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %.0f s" % timeout_s}
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    if pr.returncode != 0 or not lines:
+        return {"error": "rc %d %s" % (pr.returncode, pr.stderr[-300:])}
+    return json.loads(lines[-1])["kernel_only"]
+
+
 def main():
     args = parse()
+    if args.kernel_only:
+        return kernel_only(args)
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus, args.launch_timeout))
@@ -645,8 +729,7 @@ def main():
             f_def = None
             variants = {}
             reps = max(5, min(args.steps, 20))
-            for name, vid in (("default", _cabi.VARIANT_DEFAULT), ("noskip", _cabi.VARIANT_NOSKIP),
-                              ("baseline", _cabi.VARIANT_BASELINE), ("farfield", _cabi.VARIANT_FARFIELD)):
+            for name, vid in (("default", _cabi.VARIANT_DEFAULT), ("farfield", _cabi.VARIANT_FARFIELD)):
                 ev.set_variant(vid)
                 ms = time_objective(ev, S_local, P, d_x, d_f, reps)
                 f = ev.download(d_f, (S_local,))
@@ -655,10 +738,23 @@ def main():
                 variants[name + "_ms"] = ms
                 variants[name + "_max_rel_diff_vs_default"] = float(np.max(np.abs(f - f_def) / np.maximum(np.abs(f_def), 1e-6)))
             ev.set_variant(args.variant)
-            variants["note"] = ("objective kernel alone on the final swarm positions (mean of %d HIP-event pairs after "
-                                "0.25 s of the same launches).  noskip / baseline evaluate every (particle, point, peak) "
-                                "unit -- DEFAULT skips out-of-window Gaussians (exact to fp64 rounding); baseline is "
-                                "IEEE divide + libdevice exp2 per unit; farfield is what fit() picks at this size (see "
+            # the every-unit forms are A/B kernels: not in the product library.  A child process loads the A/B library
+            # (libnmrfit_amd_ab.so) and times them, with DEFAULT beside them, on the workload's synthetic swarm
+            # (SURVEY 8(d) positions: the swarm before it has converged)
+            eu = kernel_only_child("sparse", (0, 2, 1), use_ab=True, extra=["--workload", args.workload])
+            if "error" not in eu:
+                for name in ("noskip", "baseline"):
+                    variants[name + "_ms"] = eu["variants"][name]["kernel_ms"]
+                    variants[name + "_max_rel_diff_vs_default"] = eu["variants"][name]["max_rel_diff_vs_first"]
+                variants["default_ms_in_ab_child"] = eu["variants"]["default"]["kernel_ms"]
+            else:
+                variants["every_unit_error"] = eu["error"]
+            variants["note"] = ("objective kernel alone (mean of %d HIP-event pairs after 0.25 s of the same launches): "
+                                "default / farfield on the final swarm positions, this process; noskip / baseline -- which "
+                                "evaluate every (particle, point, peak) unit: DEFAULT skips out-of-window Gaussians (exact to "
+                                "fp64 rounding), baseline is IEEE divide + libdevice exp2 per unit -- are A/B kernels, timed by "
+                                "a child process with libnmrfit_amd_ab.so on the workload's initial synthetic swarm "
+                                "(default_ms_in_ab_child: DEFAULT there).  farfield is what fit() picks at this size (see "
                                 "fit_default) and never the configuration `value` is measured on" % reps)
             farfield = {"kernel_ms": variants["farfield_ms"],
                         "units_per_s": float(S_local) * N * P / (variants["farfield_ms"] * 1e-3),
@@ -765,6 +861,39 @@ def main():
                                    "by the critical path of one wave per generation, not by throughput (DESIGN.md 4.2)"}
         except Exception as e:      # reported, never fatal for the headline
             default_fit = {"error": repr(e)}
+    # ... and the same default fits DEVICE-BATCHED (round 5; nmrfit_batch_*, csrc/batch.hip): K spectra, one launch per
+    # generation for all K swarms, every fit bit-identical to the lone one above
+    batched_fit = None
+    if rank == 0 and world == 1 and args.workload == "C3" and args.variant == 0 and args.other_configs:
+        try:
+            from nmrfit_amd.batch import FitBatch
+            Kb = 40
+            specs = [synth.make_spectrum(4096, 6, seed=100 + k % 8) for k in range(Kb)]
+            spectra = [(q["w"], q["u"], q["v"], q["weights"]) for q in specs]
+            batched_fit = {"shape": {"fits": Kb, "swarm": 204, "grid": 4096, "peaks": 6, "generations": 2000}}
+            for key, rule in (("stopping_rule_off", dict(minstep=-1.0, minfunc=-1.0)), ("stopping_rule_on", {})):
+                tb = time.perf_counter()
+                with FitBatch(spectra, [q["lower"] for q in specs], [q["upper"] for q in specs], swarmsize=204,
+                              seeds=list(range(7, 7 + Kb)), device=device, **rule) as fb:
+                    fb.run(2000, 64)
+                    stb = fb.status()
+                    bestb = fb.best()
+                    gm = fb.geometry()
+                dtb = time.perf_counter() - tb
+                gens = [q["iteration"] for q in stb]
+                batched_fit[key] = {"wall_ms": dtb * 1e3, "fits_per_s": Kb / dtb,
+                                    "generations": {"min": min(gens), "max": max(gens), "mean": float(np.mean(gens))},
+                                    "us_per_fit_generation": dtb * 1e6 / max(1.0, float(np.sum(gens))),
+                                    "geometry": gm, "error_fit0": bestb[0][1]}
+            batched_fit["note"] = ("nmrfit_amd.batch.FitBatch: context creation + generation 0 + generations + read-back of "
+                                   "%d fits of the reference's default shape in ONE batch (what nmrfit_amd.fit_many builds); "
+                                   "stopping_rule_off runs all 2000 generations of every fit (the work of "
+                                   "reference_default_fit x %d), stopping_rule_on is pyswarm's rule with its defaults "
+                                   "(1e-8): every fit stops on its own.  Ceiling of the rule-off case by instruction count: "
+                                   "~4800 fp64 VALU instructions per particle and generation (profiles/r05) -> ~285 fits/s "
+                                   "at full issue rate" % (Kb, Kb))
+        except Exception as e:      # reported, never fatal for the headline
+            batched_fit = {"error": repr(e)}
     # the host-pointer entry point (X uploaded, f downloaded every call): the PCIe-inclusive
     # rate, reported beside the resident one -- never as `value`
     try:
@@ -808,8 +937,8 @@ def main():
                 traffic = json.load(open(pmcf)).get(args.workload, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        valu = {"bound": "fp64_valu_issue", "unit": "fraction of fp64 VALU issue slots (1024 SIMDs x 2.4 GHz / 4 cycles "
-                                                     "per wave64 instruction)"}
+        valu = {"bound": "fp64_valu_issue", "unit": "wave64 fp64 VALU instructions/s (peak: 1024 SIMDs x 2.4 GHz / 4 cycles "
+                                                     "per instruction; frac = achieved / peak)"}
         summ = next((p for p in PMC_SUMMARIES if os.path.exists(os.path.join(ROOT, p))), None)
         sq = (pmc_live or {}).get("sq", {})
         sqc = sq.get("counters", {})
@@ -865,33 +994,32 @@ def main():
                        "exchange": exchange_desc, "variant": args.variant, "generations_done": st["iteration"],
                        "swarm_best_f": st["fg"], "preheat_launches": heat_launches},
             "step_ms": sst, "kernel_ms": kst,
-            "roofline": {"bound": "hbm",      # the roofline the METRIC names (BASELINE.json: "HBM GB/s vs peak"), under
-                         # the streaming-operand model below; what actually binds this kernel is `binding_resource`
-                         "binding_resource": "fp64_valu_issue (see roofline_valu)" + (
-                             ": physical HBM traffic is `traffic`, %.2f %% of peak"
-                             % (100.0 * traffic / (t_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else ""),
-                         "rate_kind": "effective",     # cache-reuse rate of the streaming model, not physical HBM bytes
-                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS,
-                         # also against the 6.29 TB/s a float4 copy measures on this part; > 1 here
-                         # IS the evidence that the streaming figure is served from L2, not from HBM
-                         "peak_measured_copy": HBM_COPY_GBS, "frac_vs_measured_copy_peak": ach / HBM_COPY_GBS,
-                         "traffic": traffic,
-                         "traffic_from_committed_profile": traffic is not None and not traffic_live,
-                         "traffic_source": ("live: child passes of this run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                            "(2 x FETCH_SIZE KiB + WRITE_SIZE KiB per launch, the gfx950 correction)"
-                                            if traffic_live else "profiles/pmc_traffic.json"),
-                         "l2_hit_rate": l2_hit,
-                         "model": "streaming-operand bytes S*(4*N*8)+S*D*8+S*8 per launch (SURVEY 8(d)(i)); "
-                                  "w/u/v/weights are shared by all particles and L2-resident, so this is an "
-                                  "effective rate, not physical HBM traffic (`traffic`); the binding resource "
-                                  "is fp64 VALU issue, see roofline_valu",
-                         "kernel": "objective_kernel", "kernel_ms": t_kernel_ms,
-                         "kernel_ms_note": "mean of the HIP-event durations of the objective kernel alone, one pair "
-                                           "per timed step, on the stream it is launched on",
-                         "bytes_per_launch": bytes_launch, "units_per_launch": units_launch,
-                         "launch": geom},
-            "roofline_valu": valu,
+            # the resource that BINDS this kernel: fp64 vector-ALU issue.  achieved = wave64 VALU
+            # instructions per second (this run's SQ_INSTS_VALU per launch / this run's kernel time), peak = 1024 SIMDs x
+            # 2.4 GHz / 4 cycles per fp64 instruction; `traffic` = physical HBM bytes per launch (PMC)
+            "roofline": dict(valu, kernel="objective_kernel", kernel_ms=t_kernel_ms,
+                             kernel_ms_note="mean of the HIP-event durations of the objective kernel alone, one pair "
+                                            "per timed step, on the stream it is launched on",
+                             units_per_launch=units_launch, launch=geom, traffic=traffic,
+                             traffic_from_committed_profile=traffic is not None and not traffic_live,
+                             traffic_source=("live: child passes of this run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                             "(2 x FETCH_SIZE KiB + WRITE_SIZE KiB per launch, the gfx950 correction)"
+                                             if traffic_live else "profiles/pmc_traffic.json"),
+                             l2_hit_rate=l2_hit),
+            # the roofline the METRIC names (BASELINE.json: "HBM GB/s vs peak"), under SURVEY 8(d)(i)'s streaming-operand
+            # model: an EFFECTIVE rate -- the operands are L2-resident, physical HBM traffic is `roofline.traffic`
+            "roofline_streaming": {"bound": "hbm", "rate_kind": "effective",
+                                   "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                   # also against the 6.29 TB/s a float4 copy measures on this part; > 1 here IS the
+                                   # evidence that the streaming figure is served from L2, not from HBM
+                                   "peak_measured_copy": HBM_COPY_GBS, "frac_vs_measured_copy_peak": ach / HBM_COPY_GBS,
+                                   "physical_hbm_frac_of_peak": (traffic / (t_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                                 if traffic else None),
+                                   "model": "streaming-operand bytes S*(4*N*8)+S*D*8+S*8 per launch (SURVEY 8(d)(i)); "
+                                            "w/u/v/weights are shared by all particles and L2-resident, so this is an "
+                                            "effective rate, not physical HBM traffic (`roofline.traffic`); the binding "
+                                            "resource is fp64 VALU issue: `roofline`",
+                                   "bytes_per_launch": bytes_launch, "kernel_ms": t_kernel_ms},
         }
         if kst and not (t_kernel_ms <= ms_per_step * 1.0005):
             line["error"] = "objective kernel (%.4f ms) longer than the step that contains it (%.4f ms)" % (
@@ -907,6 +1035,32 @@ def main():
         elif world > 1 and rccl_info is not None and rccl_info["ranks_counted_by_all_reduce"] != world:
             line["error"] = "RCCL counted %d ranks, expected %d" % (rccl_info["ranks_counted_by_all_reduce"], world)
             rc = 5
+        # What this line should read on N GPUs if the sharding costs what its parts cost (so that the first measured
+        # scaling curve can be judged against a prediction made BEFORE it): every rank runs the same 4096-particle
+        # shard, so a generation is the slowest rank's objective kernel + what a single-rank generation adds to its
+        # kernel (candidate / fold launches: measured here at N = 1) + one all-gather of (D + 1) doubles per rank +
+        # the fold launch that follows it.  The all-gather is latency-bound (616 B per rank at D = 76): 15-40 us on
+        # xGMI is assumed until measured.
+        overhead_ms = (ms_per_step - t_kernel_ms) if world == 1 else None
+        ag_lo, ag_hi, fold_ms = 0.015, 0.040, 0.006
+        kern = float(ranks["kernel_ms_mean"]["max"]) if ranks else t_kernel_ms
+        base_over = overhead_ms if overhead_ms is not None else 0.015     # (N = 1 of this build: ~0.015 ms)
+        line["scaling_model"] = {
+            "model": "ms_per_step(N) = max_rank(kernel_ms) + single_rank_overhead_ms + all_gather_ms + fold_launch_ms, "
+                     "N > 1; weak scaling: value(N) = N * units_per_launch / ms_per_step(N)",
+            "single_rank_overhead_ms": base_over, "all_gather_ms_assumed": [ag_lo, ag_hi], "fold_launch_ms": fold_ms,
+            "max_rank_kernel_ms": kern,
+            "expected_ms_per_step": ([kern + base_over + ag_lo + fold_ms, kern + base_over + ag_hi + fold_ms]
+                                     if world > 1 else [ms_per_step, ms_per_step]),
+            "expected_weak_scaling_efficiency": [kern_eff for kern_eff in (
+                (t_kernel_ms + base_over) / (kern + base_over + ag_hi + fold_ms),
+                (t_kernel_ms + base_over) / (kern + base_over + ag_lo + fold_ms))] if world > 1 else [1.0, 1.0],
+            "measured_over_expected": ([ms_per_step / (kern + base_over + ag_hi + fold_ms),
+                                        ms_per_step / (kern + base_over + ag_lo + fold_ms)] if world > 1 else None),
+            "note": "at C3 / C4 size the exchange is 2-4 % of a generation: near-linear weak scaling is expected, and a "
+                    "rank that holds a lower clock at its power cap (kernel_ms spread in `ranks`) costs more than the "
+                    "collective.  Small swarms are the opposite: see nmrfit_amd.utils.small_shard_warning and "
+                    "fit_many(shard=True)"}
         line["power"] = power.summary()      # (null where the hwmon files are not readable)
         if ranks is not None:
             line["ranks"] = ranks
@@ -941,12 +1095,33 @@ def main():
                 except Exception as e:
                     fd["pmc_error"] = repr(e)
             line["fit_default"] = fd
+        def counters_of(name, units, kernel_ms):
+            """instructions per unit, busy and issue fraction of an extra PMC pass (objective launches only)"""
+            c = (pmc_live or {}).get(name, {})
+            cc = c.get("counters", {})
+            if not all(k in cc for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES")):
+                return None
+            kms = kernel_ms or c.get("kernel_ms_in_child")
+            return {"valu_instructions_per_unit": cc["SQ_INSTS_VALU"] * 64.0 / units,
+                    "valu_busy_frac": 4.0 * cc["SQ_ACTIVE_INST_VALU"] / SIMDS / (cc["SQ_BUSY_CYCLES"] / 32.0),
+                    "frac": (cc["SQ_INSTS_VALU"] / (kms * 1e-3)) / (SIMDS * PEAK_CLOCK_MHZ * 1e6 / FP64_ISSUE_CYCLES) if kms else None,
+                    "kernel_ms_in_pmc_child": c.get("kernel_ms_in_child"), "launches": c.get("launches"),
+                    "pmc_source": "live: child pass of this run under rocprofv3 --kernel-trace --pmc (bench.py --kernel-only)"}
+        if variants is not None and "noskip_ms" in variants:
+            line["every_unit"] = {"kernel": "objective_kernel<NOSKIP> (A/B library)", "kernel_ms": variants["noskip_ms"],
+                                  "units_per_s": units_launch / (variants["noskip_ms"] * 1e-3),
+                                  "roofline": counters_of("sq_noskip", units_launch, None),
+                                  "note": "every (particle, point, peak) unit evaluated: no Gaussian window skip"}
         if dense is not None:
+            dense["roofline"] = counters_of("sq_dense", units_launch, None)
+            dense["farfield"]["roofline"] = counters_of("sq_dense_farfield", units_launch, None)
             line["dense_spectrum"] = dense
         if others:
             line["other_configs"] = others
         if default_fit is not None:
             line["reference_default_fit"] = default_fit
+        if batched_fit is not None:
+            line["reference_default_fit_batched"] = batched_fit
         if host_ms is not None:
             line["host_pointer_call"] = {"ms": host_ms, "units_per_s": units_launch / (host_ms * 1e-3),
                                          "note": "nmrfit_objective_batch with host X/f (H2D + kernel + D2H per call)"}

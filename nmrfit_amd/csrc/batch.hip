@@ -225,6 +225,7 @@ void plan_geometry(nmrfit_batch *b)
         g.S = b->S;
         g.N = N;
         g.blk_chunks = blk_chunks;
+        g.n_blocks = (int)n_blocks;
         g.variant = b->variant;
         b->geom_ok[m] = false;
         int slices, rows;
@@ -247,6 +248,7 @@ void plan_geometry(nmrfit_batch *b)
             g.wpb = wpb;
             g.nseg = wpb;
             g.seg_len = seg_len;
+            g.seg_blocks = (int)(seg_len / blk_len);
             g.wave_swarm = false;
             g.blocks_per_fit = b->S;
             slices = 1;
@@ -258,6 +260,7 @@ void plan_geometry(nmrfit_batch *b)
             g.wpb = kWavesPerBlock;
             g.nseg = 1;
             g.seg_len = n_blocks * blk_len;
+            g.seg_blocks = (int)n_blocks;
             g.wave_swarm = true;
             g.blocks_per_fit = (b->S + kWavesPerBlock - 1) / kWavesPerBlock;
             slices = kWavesPerBlock;

@@ -27,6 +27,7 @@ struct BatchLaunch {
     int nseg;
     int64_t seg_len;
     int blk_chunks;
+    int seg_blocks, n_blocks;   // blocks per segment, per grid
     int wpb;                // 4 or 8 (workgroup = particle), or 4 with one particle per WAVE (wave_swarm)
     bool wave_swarm;
     int64_t blocks_per_fit;

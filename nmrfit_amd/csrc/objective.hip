@@ -297,6 +297,8 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     la.nseg = (int)nseg;
     la.seg_len = seg_len;
     la.blk_chunks = blk_chunks;
+    la.seg_blocks = (int)(seg_len / blk_len);
+    la.n_blocks = (int)n_blocks;
     la.blocks = blocks;
     la.lds = lds;
     la.fit_im = fit_im;

@@ -17,10 +17,19 @@
 namespace nmrfit {
 namespace {
 
+// Launch bound: FOUR waves per SIMD for the four-wave forms.  The direct kernel then parks one accumulator and one
+// prologue value in scratch (20 bytes per lane: one 8-byte reload + store per chunk, the other once per wave) -- the
+// descriptor indirection costs it the four registers the lone kernel has to spare at 127 -- and is 4 % FASTER that
+// way than at three waves without scratch (K = 40 ... 100 default fits: 2.36 / 2.27 against 2.45 / 2.38 us per fit
+// and generation; profiles/r05/batch_fits_waves_ab.txt): a generation is a few lock-step rounds of short waves, and
+// a round of four hides its memory round trips better than a round of three.
+#ifndef NMRFIT_BATCH_MIN_WAVES
+#define NMRFIT_BATCH_MIN_WAVES 4   // (A/B knob: tools/batch_fits.py with NMRFIT_LIB)
+#endif
 template <int VARIANT, int WPB, bool WAVE_SWARM>
-__global__ __launch_bounds__(kWave *WPB, (WPB == kWavesPerBlock) ? objective_min_waves(VARIANT, 0) : 2) void objective_batch_kernel(
+__global__ __launch_bounds__(kWave *WPB, (WPB == kWavesPerBlock) ? NMRFIT_BATCH_MIN_WAVES : 2) void objective_batch_kernel(
     const BatchFit *__restrict__ fits, int64_t S, int blocks_per_fit, int64_t N, int nseg, int64_t seg_len, int blk_chunks,
-    const unsigned aux_off)
+    int seg_blocks, int n_blocks, const unsigned aux_off)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     __shared__ double wsums[kWsumsCount];
@@ -42,7 +51,7 @@ __global__ __launch_bounds__(kWave *WPB, (WPB == kWavesPerBlock) ? objective_min
     }
     const int64_t g = lblock * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     objective_body<VARIANT, false, 0, WPB, WAVE_SWARM>(lds_raw, g, lblock, d.wc, d.u, d.v, d.wt, d.chunk, d.X, S, P, N, d.w0,
-                                                      d.wspan, nseg, seg_len, blk_chunks, d.lane_step, d.rec_devk, d.fx,
+                                                      d.wspan, nseg, seg_len, blk_chunks, seg_blocks, n_blocks, d.lane_step, d.rec_devk, d.fx,
                                                       nullptr, nullptr, d.upd, aux_off, wsums);
 }
 
@@ -52,7 +61,7 @@ int launch_batch_variant(const BatchLaunch &a)
     const dim3 grid((unsigned)(a.blocks_per_fit * a.K));
 #define NMRFIT_BATCH_LAUNCH(W, WS)                                                                                      \
     hipLaunchKernelGGL((objective_batch_kernel<VARIANT, W, WS>), grid, dim3(kWave *(W)), a.lds, a.stream, a.fits, a.S,    \
-                       (int)a.blocks_per_fit, a.N, a.nseg, a.seg_len, a.blk_chunks, a.aux_off)
+                       (int)a.blocks_per_fit, a.N, a.nseg, a.seg_len, a.blk_chunks, a.seg_blocks, a.n_blocks, a.aux_off)
     if (a.wave_swarm)
         NMRFIT_BATCH_LAUNCH(kWavesPerBlock, true);
     else if (a.wpb == kWideWaves)

@@ -199,15 +199,40 @@ __device__ __forceinline__ void lorentz_tail(int n, const PeakLor *r, const doub
 }
 
 // Gaussian of one peak: acc += AG2 * 2^-(1 + t^2)   (t recomputed: cheaper than keeping s live)
+// ROWS (round 5): a chunk that touches the peak's window is evaluated ROW by row -- a row is the 64 consecutive grid
+// points the lanes hold at one q -- and a row none of whose points lies inside the window (|t| <= sqrt(63): beyond,
+// the term is below 2^-64 of its amplitude, the same criterion as the chunk-level skip) costs one FMA and one
+// wave-uniform compare instead of the 21 operations of an exp2.  On a coarse grid -- the reference's own 4096-point
+// spectra: a chunk spans 1/8 of the spectrum, a line's window a third of that -- two rows in three are skipped, and
+// the recurrence (whose premise is a fine grid) never applies there.  NaN counts as inside: it propagates as before.
+constexpr double kGaussWindowT = 7.9372539331937721;   // sqrt(63), in half-widths (kGaussWindow is the same in widths)
+template <bool ROWS>
 __device__ __forceinline__ void gauss_add(const PeakLor *r, const double (&wv)[kPointsPerLane],
                                           double (&acc)[kPointsPerLane])
 {
     const double ihw = r->ihw, c = r->c, ag2 = r->ag2;
+    // which rows have a point inside the window: one scalar bit per row (each t dies at its compare; it is recomputed
+    // below for the rows that are evaluated -- one FMA, against eight values held across the rows' branches)
+    unsigned rows = 0xffu;
+    if (ROWS) {
+        rows = 0u;
+#pragma unroll
+        for (int q = 0; q < kPointsPerLane; ++q) {
+            const double t = __builtin_fma(wv[q], ihw, c);
+            rows |= (__ballot(!(fabs(t) > kGaussWindowT)) != 0ull) ? (1u << q) : 0u;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < kPointsPerLane; ++q) {
-        const double t = __builtin_fma(wv[q], ihw, c);
-        const double s = __builtin_fma(t, t, 1.0);
-        acc[q] = __builtin_fma(ag2, exp2_neg(-s), acc[q]);
+        // (the accumulator is updated unconditionally, with a zero for a skipped row: a conditional update makes the
+        // compiler carry two copies of all eight accumulators through the peak loop -- +20 VGPRs, a wave per SIMD)
+        double e = 0.0;
+        if (!ROWS || (rows & (1u << q)) != 0u) {
+            const double t = __builtin_fma(wv[q], ihw, c);
+            const double s = __builtin_fma(t, t, 1.0);
+            e = ROWS ? exp2_neg_sc(-s) : exp2_neg(-s);   // (the same operations: bit-identical values)
+        }
+        acc[q] = __builtin_fma(ag2, e, acc[q]);
     }
 }
 

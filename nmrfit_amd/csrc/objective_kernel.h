@@ -91,7 +91,8 @@ __device__ __forceinline__ void objective_body(
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax,
     const double *__restrict__ X, int64_t S, int P, int64_t N, double w0, double wspan, int nseg,
-    int64_t seg_len, int blk_chunks, double lane_step, double rec_devk,
+    int64_t seg_len, int blk_chunks, int seg_blocks /* blocks per segment */, int n_blocks_i /* blocks per grid */,
+    double lane_step, double rec_devk,
     double *__restrict__ out,       // nseg == 1: f[S];  else per-block sums [S * n_blocks] (x2 with FIT_IM)
     double *__restrict__ R_out,     // WRITE_R: residual rows [S*N]
     unsigned long long *__restrict__ clk,   // profiling only (else null): shader / reference clock of workgroup 0
@@ -167,9 +168,23 @@ __device__ __forceinline__ void objective_body(
         clk[0] = __builtin_amdgcn_s_memtime();
         clk[1] = __builtin_amdgcn_s_memrealtime();
     }
+    // (no 64-bit division on the way: the GPU has none, a software one is ~80 instructions on the critical path of a
+    // wave that may have a single chunk to work on -- the two geometries swarm generations use need none, and the
+    // block arithmetic below works from host-computed counts, seg_blocks and n_blocks)
     const bool active = g < S * nseg;
-    const int64_t particle = active ? g / nseg : 0;
-    const int seg = active ? (int)(g % nseg) : 0;
+    int64_t particle = 0;
+    int seg = 0;
+    if (active) {
+        if (nseg == 1) {
+            particle = g;
+        } else if (nseg == WPB) {   // the workgroup is the particle, its waves the segments
+            particle = pblock;
+            seg = wave;
+        } else {
+            particle = g / nseg;
+            seg = (int)(g - particle * nseg);
+        }
+    }
     const int64_t D = 4 + 3 * (int64_t)P;
     double wnext[kPointsPerLane];
     if (kPrefW && active) {   // the first chunk's w: on its way while the prologue runs
@@ -327,8 +342,9 @@ __device__ __forceinline__ void objective_body(
         lseed[kWave + lane] = li;
     }
     {
-        const int64_t b0 = j0 / blk_len;
-        const int64_t nb = (j1 - j0 + blk_len - 1) / blk_len;
+        const int64_t n_blocks = n_blocks_i;
+        const int64_t b0 = (int64_t)seg * seg_blocks;
+        const int64_t nb = (seg_blocks < n_blocks - b0) ? seg_blocks : n_blocks - b0;   // blocks of [j0, j1)
         if (lane < nb) {
             double er, ei;
             sincos_fast((p1 * (double)((b0 + lane) * blk_len)) * invN, &ei, &er);
@@ -336,9 +352,9 @@ __device__ __forceinline__ void objective_body(
         }
         wave_lds_fence();   // same-wave LDS write -> read
     }
-    const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
+    const int64_t n_blocks = n_blocks_i;
     double bs = 0.0, bs_im = 0.0;             // per-lane sums of squares of the current block
-    const int64_t blk0 = j0 / blk_len;         // global index of this segment's first block
+    const int64_t blk0 = (int64_t)seg * seg_blocks;   // global index of this segment's first block
     int cib = 0, bidx = 0;                     // chunk within block, block within segment
     const double base = wave_uniform((double)P * yoff);   // yoff is added once per peak (equations.py:147,195)
     double ss = 0.0, ss_im = 0.0;
@@ -541,7 +557,7 @@ __device__ __forceinline__ void objective_body(
                     if (kRec && full && rec_all) {
                         for (unsigned m = hits_c; m; m &= m - 1) gauss_add_rec(lor + __builtin_ctz(m), grec + __builtin_ctz(m), wv, acc);
                     } else {
-                        for (unsigned m = hits_c; m; m &= m - 1) gauss_add(lor + __builtin_ctz(m), wv, acc);
+                        for (unsigned m = hits_c; m; m &= m - 1) gauss_add<true>(lor + __builtin_ctz(m), wv, acc);
                     }
                 } else {
                 double csum = 0.0;    // lane l: coefficient of order l >> 2 (all 4 lanes of a quad)
@@ -603,7 +619,7 @@ __device__ __forceinline__ void objective_body(
                         if (kRec && full && rec_all)
                             gauss_add_rec(lor + k1, grec + k1, wv, acc);
                         else
-                            gauss_add(lor + k1, wv, acc);
+                            gauss_add<true>(lor + k1, wv, acc);
                     }
                 }
                 // broadcast the kFarTerms sums through LDS and evaluate them at the lane's points
@@ -655,7 +671,7 @@ __device__ __forceinline__ void objective_body(
                         gauss_add_rec(lor + k1, grec + k1, wv, acc);
                     }
                 } else
-                for (unsigned long long m = hits; m; m &= m - 1) gauss_add(lor + kb + __builtin_ctzll(m), wv, acc);
+                for (unsigned long long m = hits; m; m &= m - 1) gauss_add<kSkip>(lor + kb + __builtin_ctzll(m), wv, acc);
             }
         }
 
@@ -974,9 +990,9 @@ template <int VARIANT, bool WRITE_R, int FIT_IM, int WPB = kWavesPerBlock>
 __global__ __launch_bounds__(kWave *WPB, (WPB == kWavesPerBlock) ? objective_min_waves(VARIANT, FIT_IM) : 2) void objective_kernel(
     const double *__restrict__ wc, const double *__restrict__ u, const double *__restrict__ v,
     const double *__restrict__ wt, const double2 *__restrict__ chunk_minmax, const double *__restrict__ X, int64_t S,
-    int P, int64_t N, double w0, double wspan, int nseg, int64_t seg_len, int blk_chunks, double lane_step,
-    double rec_devk, double *__restrict__ out, double *__restrict__ R_out, unsigned long long *__restrict__ clk,
-    const PsoFused upd, const unsigned aux_off)
+    int P, int64_t N, double w0, double wspan, int nseg, int64_t seg_len, int blk_chunks, int seg_blocks, int n_blocks,
+    double lane_step, double rec_devk, double *__restrict__ out, double *__restrict__ R_out,
+    unsigned long long *__restrict__ clk, const PsoFused upd, const unsigned aux_off)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     // block sums (x2 with the imaginary channel); then f; then what the fused personal-best step needs at the very
@@ -996,7 +1012,7 @@ __global__ __launch_bounds__(kWave *WPB, (WPB == kWavesPerBlock) ? objective_min
     }
     const int64_t g = (int64_t)blockIdx.x * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     objective_body<VARIANT, WRITE_R, FIT_IM, WPB>(lds_raw, g, (int64_t)blockIdx.x, wc, u, v, wt, chunk_minmax, X, S, P, N, w0, wspan, nseg, seg_len,
-                                             blk_chunks, lane_step, rec_devk, out, R_out, clk, upd, aux_off, wsums);
+                                             blk_chunks, seg_blocks, n_blocks, lane_step, rec_devk, out, R_out, clk, upd, aux_off, wsums);
 }
 
 template <int VARIANT>
@@ -1014,8 +1030,8 @@ int launch_variant(const ObjectiveLaunch &a)
 #define NMRFIT_LAUNCH_W(WR, FI, W)                                                                              \
     hipLaunchKernelGGL((objective_kernel<VARIANT, WR, FI, W>), dim3((unsigned)blocks), dim3(kWave *(W)), lds,  \
                        ctx->stream, ctx->d_wc, ctx->d_u, ctx->d_v, ctx->d_wt, ctx->d_chunk, dX, S, (int)P,     \
-                       ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, blk_chunks, ctx->lane_step,                 \
-                       ctx->grid_dev * 11.0e10, out, dR, clk, upd, aux_off)
+                       ctx->N, ctx->w0, ctx->wspan, nseg, seg_len, blk_chunks, a.seg_blocks, a.n_blocks,      \
+                       ctx->lane_step, ctx->grid_dev * 11.0e10, out, dR, clk, upd, aux_off)
 #define NMRFIT_LAUNCH(WR, FI) NMRFIT_LAUNCH_W(WR, FI, kWavesPerBlock)
     // nmrfit_prof_enable: HIP events on the launch stream around this kernel alone
     const bool prof = ctx->prof_cap > 0 && ctx->prof_nk < ctx->prof_cap;

@@ -16,6 +16,8 @@ struct ObjectiveLaunch {
     int nseg;
     int64_t seg_len;
     int blk_chunks;
+    int seg_blocks;        // blocks per segment (seg_len / block length)
+    int n_blocks;          // blocks per grid
     int64_t blocks;        // workgroups
     size_t lds;            // dynamic LDS per workgroup
     int fit_im;

@@ -72,6 +72,36 @@ __device__ __forceinline__ double exp2_neg(double x)
     return __builtin_amdgcn_ldexp(p, (int)n);
 }
 
+// The same, with every coefficient pinned to SCALAR registers at the point of use (s_mov pairs, issued by the scalar
+// unit beside the vector work).  For code that sits inside a conditional block of a loop: left to itself the compiler
+// hoists the eleven coefficients out of the loop into VECTOR registers -- 22 VGPRs held across the chunk loop (a wave
+// per SIMD for the kernels at the 128-register line) and a v_mov + v_fmac pair per Horner step instead of one v_fma
+// with a scalar operand.
+__device__ __forceinline__ double scalar_const(double x)
+{
+    asm volatile("" : "+s"(x));
+    return x;
+}
+__device__ __forceinline__ double exp2_neg_sc(double x)
+{
+    x = fmax(x, -1100.0);
+    const double n = __builtin_rint(x);
+    const double f = x - n;
+    double p = scalar_const(4.455817908336064493e-10);
+    p = __builtin_fma(p, f, scalar_const(7.0741942972885210056e-9));
+    p = __builtin_fma(p, f, scalar_const(1.0178057087733941105e-7));
+    p = __builtin_fma(p, f, scalar_const(1.3215432535912376166e-6));
+    p = __builtin_fma(p, f, scalar_const(1.5252733841556772589e-5));
+    p = __builtin_fma(p, f, scalar_const(1.5403530463724354209e-4));
+    p = __builtin_fma(p, f, scalar_const(1.3333558146406470697e-3));
+    p = __builtin_fma(p, f, scalar_const(9.6181291075872566681e-3));
+    p = __builtin_fma(p, f, scalar_const(5.5504108664821627039e-2));
+    p = __builtin_fma(p, f, scalar_const(2.4022650695910159567e-1));
+    p = __builtin_fma(p, f, scalar_const(6.9314718055994530925e-1));
+    p = __builtin_fma(p, f, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
 // sin and cos of phi by a 3-term Cody-Waite reduction by pi/2 (FMA form: each step is exact
 // before its single rounding, so the reduced angle stays accurate to ~|k| * 1e-26 + 1e-16)
 // + polynomials on [-pi/4, pi/4] (<= 3e-16).  Branch-free; good to ~1e-14 up to |phi| ~ 1e12.

@@ -50,16 +50,22 @@ def test_bench_paths_agree():
     common = ["--steps", "5", "--warmup", "2", "--cpu-seconds", "0", "--workload", "C2", "--preheat-seconds", "0.1"]
     plain = _run([sys.executable, "bench.py", "--swarm-per-gpu", "512"] + common, {})
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "roofline_valu", "step_ms", "kernel_ms"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "roofline_streaming", "step_ms", "kernel_ms",
+                "scaling_model"):
         assert key in plain, key
     assert plain["dtype"] == "f64" and plain["vs_baseline"] is None and plain["n_gpus"] == 1
-    r = plain["roofline"]
+    # `roofline` names the resource that binds (fp64 VALU issue); the metric's "HBM GB/s vs peak" under the
+    # streaming-operand model is `roofline_streaming`, an effective rate
+    assert plain["roofline"]["bound"] == "fp64_valu_issue"
+    r = plain["roofline_streaming"]
     assert r["bound"] == "hbm" and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
     # the kernel is timed inside the steps that contain it
     assert plain["kernel_ms"]["n"] == 5 and plain["step_ms"]["n"] == 5
     assert plain["kernel_ms"]["mean"] <= plain["ms_per_step"]
     assert plain["kernel_ms"]["max"] <= plain["step_ms"]["max"] * 1.001
-    assert 500.0 < plain["roofline_valu"]["clock_mhz_in_run"] < 3000.0
+    assert 500.0 < plain["roofline"]["clock_mhz_in_run"] < 3000.0
+    sm = plain["scaling_model"]
+    assert sm["expected_ms_per_step"] == [plain["ms_per_step"]] * 2 and sm["measured_over_expected"] is None
     assert "error" not in plain
     # both peaks of SURVEY 8(d)(i), the kind of rate, the spectrum the headline is measured on
     # and the dense-spectrum figure beside it
@@ -148,6 +154,15 @@ def test_c4_rehearsal_four_ranks_on_one_gpu():
     rf = one["reference_default_fit"]
     assert rf["shape"] == {"swarm": 204, "grid": 4096, "peaks": 6, "generations": 2000}
     assert 5.0 < rf["wall_ms"] < 500.0 and 0.0 < rf["error"] < 0.05
+    # ... and the same default fits device-batched (round 5): 40 of them in one batch, one launch per generation
+    bf = one["reference_default_fit_batched"]
+    assert bf["shape"]["fits"] == 40 and bf["stopping_rule_off"]["generations"] == {"min": 2000, "max": 2000, "mean": 2000.0}
+    assert bf["stopping_rule_off"]["fits_per_s"] > 2.0 * 1e3 / rf["wall_ms"]      # at least twice a loop of lone fits
+    assert bf["stopping_rule_on"]["generations"]["max"] <= 2000 and bf["stopping_rule_on"]["fits_per_s"] > bf["stopping_rule_off"]["fits_per_s"]
+    assert bf["stopping_rule_off"]["geometry"]["mode"] == "wave"
+    # the sharded run carries the model its step time is to be judged against
+    sm = four["scaling_model"]
+    assert len(sm["expected_ms_per_step"]) == 2 and sm["max_rank_kernel_ms"] > 0 and sm["measured_over_expected"] is not None
 
 
 def test_bench_line_carries_live_pmc_counters():
@@ -157,7 +172,8 @@ def test_bench_line_carries_live_pmc_counters():
     not echoed from a committed file; so is the far-field kernel's entry in `fit_default`."""
     d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--cpu-seconds", "0", "--no-other-configs",
               "--preheat-seconds", "0.2"], {})
-    r, v, fd = d["roofline"], d["roofline_valu"], d["fit_default"]
+    r, fd = d["roofline"], d["fit_default"]
+    v = r
     if "pmc_live_errors" in d:
         # a profiler hiccup on this box must not cost the run its line: the fields then fall back to the
         # committed passes and SAY so -- check that, and report the reason instead of failing the suite
@@ -170,6 +186,15 @@ def test_bench_line_carries_live_pmc_counters():
     assert v["from_committed_profile"] is False and v["pmc_source"].startswith("live")
     assert 5.0 < v["valu_instructions_per_unit"] < 7.0 and 0.8 < v["valu_busy_frac"] <= 1.0
     assert 3.9 < v["valu_cycles_per_instruction"] < 4.6
+    # the line's roofline is the issued-VALU fraction, reproducible from the counters it carries
+    assert r["bound"] == "fp64_valu_issue" and r["peak"] == pytest.approx(1024 * 2.4e9 / 4)
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.6 < r["frac"] < 1.0
+    assert r["achieved"] == pytest.approx(v["valu_instructions_per_unit"] * r["units_per_launch"] / 64.0 / (r["kernel_ms"] * 1e-3))
+    assert d["roofline_streaming"]["rate_kind"] == "effective" and d["roofline_streaming"]["physical_hbm_frac_of_peak"] < 0.05
+    # round 5: every unit evaluated (NOSKIP: an A/B kernel, timed and counted by children that load libnmrfit_amd_ab.so)
+    eu = d["every_unit"]
+    assert eu["kernel_ms"] > 2.0 * d["kernel_ms"]["mean"] and 15.0 < eu["roofline"]["valu_instructions_per_unit"] < 35.0
+    assert 0.5 < eu["roofline"]["valu_busy_frac"] <= 1.0
     assert fd["variant"] == "farfield" and fd["from_committed_profile"] is False
     assert 1.5 < fd["valu_instructions_per_unit"] < 4.0 and fd["kernel_ms"] < d["kernel_ms"]["mean"]
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise a tools/profile.sh output directory: per-kernel stats + mean PMC counters of the
-objective kernel.  Usage: tools/pmc_summary.py gpurun_out/prof/<tag> [--json out.json]"""
+"""Summarise a tools/profile.sh (or tools/pmc_cmd.sh) output directory: per-kernel stats + mean PMC counters of one
+kernel (default: the objective kernel).
+Usage: tools/pmc_summary.py gpurun_out/prof/<tag> [--kernel <substring of its name>] [--json out.json]"""
 import collections
 import csv
 import glob
@@ -11,7 +12,8 @@ import sys
 
 def main():
     d = sys.argv[1]
-    out = {}
+    kname = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "objective_kernel"
+    out = {"kernel": kname}
     st = sorted(glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if st:
         rows = list(csv.DictReader(open(st[-1])))     # newest run of this tag
@@ -25,7 +27,7 @@ def main():
             continue
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(fs[-1])):
-            if "objective_kernel" in r["Kernel_Name"]:
+            if kname in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             pmc[k] = {"mean": sum(v) / len(v), "n": len(v)}
@@ -38,7 +40,7 @@ def main():
         out["hbm_bytes_per_launch"] = fetch + write
         out["hbm_bytes_note"] = "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction per MI355X_MICROARCH.md)"
     if "GRBM_GUI_ACTIVE" in pmc and st:
-        ks = [k for k in out["kernel_stats"] if "objective_kernel" in k["name"]]
+        ks = [k for k in out["kernel_stats"] if kname in k["name"]]
         if ks:
             out["clock_ghz_est"] = pmc["GRBM_GUI_ACTIVE"]["mean"] / 8 / ks[0]["avg_ns"]
     if "SQ_INSTS_VALU" in pmc and "SQ_ACTIVE_INST_VALU" in pmc:
@@ -48,6 +50,10 @@ def main():
         kernel_cycles = pmc["SQ_BUSY_CYCLES"]["mean"] / 32
         out["kernel_cycles"] = kernel_cycles
         out["valu_busy_frac"] = 4 * pmc["SQ_ACTIVE_INST_VALU"]["mean"] / 1024 / kernel_cycles
+    if "SQ_INSTS_VALU" in pmc and st:
+        ks = [k for k in out["kernel_stats"] if kname in k["name"]]
+        if ks:   # wave-instructions issued per SIMD and second, against 2.4 GHz / 4 cycles per fp64 instruction
+            out["valu_issue_frac_of_2p4GHz"] = pmc["SQ_INSTS_VALU"]["mean"] * 4 / 1024 / (ks[0]["avg_ns"] * 2.4)
     print(json.dumps(out, indent=1))
     if "--json" in sys.argv:
         json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

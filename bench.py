@@ -642,7 +642,8 @@ def main():
         def step():
             sw.step()
     elif use_dist:
-        ex = pso.SocketExchange(channel=channel)
+        from tests.swarm_support import SocketExchange   # (rehearsal / RCCL-failed path: test infrastructure)
+        ex = SocketExchange(channel=channel)
         exchange_desc = "host-staged all-gather of %d doubles per generation (sockets%s)" % (
             D + 1, "; RCCL FAILED: " + rccl_failure if rccl_failure else "; rehearsal")
 

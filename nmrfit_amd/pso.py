@@ -4,20 +4,14 @@ Batched particle-swarm driver: the replacement for ``pyswarm.pso`` as the refere
 vendored in the reference) evaluates one particle per Python call; here a generation is one
 batched objective launch and the swarm state never leaves the GPU.
 
-Two implementations of the same generation, bit-compatible in the swarm arithmetic:
-
-``DeviceSwarm``   the product path: nmrfit_pso_* entry points of libnmrfit_amd.so
-                  (csrc/pso.hip).  State in HBM, Philox4x32-10 counter RNG on the device.
-``HostSwarm``     a numpy mirror of those kernels with an injectable ``evaluate(X) -> f``.
-                  Used to drive third-party evaluators and by the CPU tests of the sharding
-                  / exchange logic; it is NOT a fallback for DeviceSwarm (nothing selects it
-                  automatically).
+``DeviceSwarm`` is the product path: the nmrfit_pso_* entry points of libnmrfit_amd.so (csrc/pso.hip), state in HBM,
+Philox4x32-10 counter RNG on the device.  (Its numpy mirror and the host-staged exchanges that the CPU tests and
+one-GPU rehearsals drive it with live in tests/swarm_support.py: test infrastructure, not part of this package.)
 
 Sharding: rank q of G owns particles [offset, offset+S_local); the
 only cross-rank traffic is one all-gather of a (D+1)-double candidate record per generation
 (``RcclExchange``: ncclAllGather inside libnmrfit_amd.so, on the kernels' stream, no Python in
-the generation loop; ``SocketExchange`` / ``TorchExchange``: the record staged through the
-host, for CPU tests and one-GPU rehearsals).  Random numbers are
+the generation loop).  Random numbers are
 a function of (seed, generation, dimension, GLOBAL particle index), so the trajectory does
 not depend on the number of ranks.
 
@@ -229,155 +223,6 @@ class RcclExchange:
             pass
 
 
-class SocketExchange:
-    """Host-staged exchange over a ``rendezvous.Channel`` (standard-library sockets): the
-    (D+1)-double record goes device -> host -> rank 0 -> every rank -> device.  For CPU tests of
-    the sharding logic and for rehearsing several ranks on ONE GPU (RCCL refuses two ranks on
-    the same device); multi-GPU fits use RcclExchange."""
-
-    def __init__(self, channel=None):
-        from . import rendezvous
-        self._own_channel = channel is None
-        self.channel = rendezvous.Channel() if channel is None else channel
-        self.rank, self.world = self.channel.rank, self.channel.world
-
-    def gather_host(self, cand):
-        cand = np.ascontiguousarray(cand, dtype=np.float64)
-        parts = self.channel.all_gather(cand.tobytes())
-        return np.stack([np.frombuffer(p, dtype=np.float64) for p in parts])
-
-    def broadcast_seed(self, seed):
-        import struct
-        return struct.unpack("<Q", self.channel.broadcast(struct.pack("<Q", int(seed) & 0xFFFFFFFFFFFFFFFF)))[0]
-
-    def barrier(self):
-        self.channel.barrier()
-
-    def all_reduce(self, values, op="max"):
-        a = np.array(values, dtype=np.float64).reshape(-1)
-        parts = np.stack([np.frombuffer(p, dtype=np.float64) for p in self.channel.all_gather(a.tobytes())])
-        return {"sum": parts.sum, "max": parts.max, "min": parts.min}[op](axis=0)
-
-    def close(self):
-        if self._own_channel and self.channel is not None:
-            self.channel.close()
-            self.channel = None
-
-
-class TorchExchange:
-    """The same host-staged exchange over a torch.distributed group (gloo): kept for the CPU
-    tests that rehearse the N>1 logic under ``torch.distributed.run``.  Not used by the product
-    path -- multi-GPU fits exchange through RcclExchange without importing torch."""
-
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        self._dist = dist
-        self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
-        self.backend = dist.get_backend(group)
-
-    def gather_host(self, cand):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(cand))
-        out = torch.empty(self.world * t.numel(), dtype=t.dtype)   # flat: gloo needs 1-D
-        self._dist.all_gather_into_tensor(out, t, group=self.group)
-        return out.view(self.world, t.numel()).numpy()
-
-    def broadcast_seed(self, seed):
-        import torch
-        t = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64)
-        self._dist.broadcast(t, src=0, group=self.group)
-        return int(t.item())
-
-
-# ---- numpy mirror -----------------------------------------------------------------------------
-class HostSwarm:
-    def __init__(self, evaluate, lower, upper, swarmsize, offset=0, S_local=None, seed=0,
-                 omega=DEFAULTS["omega"], phip=DEFAULTS["phip"], phig=DEFAULTS["phig"],
-                 minstep=DEFAULTS["minstep"], minfunc=DEFAULTS["minfunc"]):
-        self.lb = np.array(lower, dtype=np.float64)
-        self.ub = np.array(upper, dtype=np.float64)
-        assert len(self.lb) == len(self.ub), 'Lower- and upper-bounds must be the same length'
-        assert np.all(self.ub > self.lb), 'All upper-bound values must be greater than lower-bound values'
-        self.evaluate = evaluate
-        self.S_global = int(swarmsize)
-        self.offset = int(offset)
-        self.S = self.S_global if S_local is None else int(S_local)
-        self.D = self.lb.size
-        self.seed = int(seed)
-        self.omega, self.phip, self.phig = omega, phip, phig
-        self.minstep, self.minfunc = minstep, minfunc
-        self.iteration, self.stop = 0, 0
-        self.fg = np.inf
-        self.g = np.zeros(self.D)
-        self.best_x, self.best_f = np.zeros(self.D), np.inf
-
-    def _select(self):
-        if self.S:
-            self.fx = np.asarray(self.evaluate(self.x), dtype=np.float64)
-            upd = self.fx < self.fp
-            self.p[upd, :] = self.x[upd, :]
-            self.fp[upd] = self.fx[upd]
-            i = int(np.argmin(self.fp))
-            # pyswarm seeds g with p[argmin fp] -- or, while no particle has a finite objective yet (every
-            # fp still +inf, argmin 0), with x[0]: the record then carries this shard's first position, and
-            # the fold's lowest-rank tie-break makes it GLOBAL particle 0's
-            row = self.p[i, :] if self.fp[i] < np.inf else self.x[i, :]
-            self.cand = np.concatenate(([self.fp[i]], row))
-        else:
-            self.fx = np.zeros(0)
-            self.cand = np.concatenate(([np.inf], np.zeros(self.D)))
-
-    def init(self):
-        r0, r1 = uniform2(self.seed, 0, self.S, self.D, self.offset)
-        vhigh = np.abs(self.ub - self.lb)
-        vlow = -vhigh
-        self.x = self.lb + r0 * (self.ub - self.lb)
-        self.v = vlow + r1 * (vhigh - vlow)
-        self.p = np.zeros_like(self.x)
-        self.fp = np.full(self.S, np.inf)
-        self.iteration, self.stop, self._seeded = 0, 0, False
-        self._select()
-
-    def step_local(self):
-        if self.stop:
-            return
-        rp, rg = uniform2(self.seed, self.iteration + 1, self.S, self.D, self.offset)
-        self.v = (self.omega * self.v + (self.phip * rp) * (self.p - self.x)) + (self.phig * rg) * (self.g - self.x)
-        x = self.x + self.v
-        x = np.where(x < self.lb, self.lb, x)
-        x = np.where(x > self.ub, self.ub, x)
-        self.x = x
-        self._select()
-
-    def candidate(self):
-        return self.cand
-
-    def apply_global(self, cands):
-        if self.stop:
-            return
-        cands = np.asarray(cands, dtype=np.float64).reshape(-1, self.D + 1)
-        win = int(np.argmin(cands[:, 0]))          # first minimum: lowest rank wins ties
-        fc, pc = cands[win, 0], cands[win, 1:]
-        if not self._seeded:
-            self.g, self.fg = pc.copy(), fc
-            self.best_x, self.best_f = pc.copy(), fc
-            self._seeded = True
-            self.iteration = 0
-            return
-        if fc < self.fg:
-            stepsize = np.sqrt(np.sum((self.g - pc) ** 2))
-            if np.abs(self.fg - fc) <= self.minfunc:
-                self.stop, self.best_x, self.best_f = 1, pc.copy(), fc
-            elif stepsize <= self.minstep:
-                self.stop, self.best_x, self.best_f = 2, pc.copy(), fc
-            else:
-                self.g, self.fg = pc.copy(), fc
-                self.best_x, self.best_f = pc.copy(), fc
-        self.iteration += 1
-
-
 # ---- the product path ---------------------------------------------------------------------------
 class DeviceSwarm:
     """Device-resident swarm over an ``equations.Evaluator`` (csrc/pso.hip)."""
@@ -537,8 +382,8 @@ def run_sharded(swarm, exchange, maxiter, check_every=1, verbose=False):
     """Generation loop for a (possibly sharded) swarm; every rank must call it.  Returns
     (x_best, f_best).  A DeviceSwarm with an RcclExchange runs entirely inside the library
     (``nmrfit_pso_run`` with the communicator attached: one ncclAllGather per generation on
-    the kernels' stream); otherwise (HostSwarm, SocketExchange, gloo) the (D+1)-double record
-    is staged through the host."""
+    the kernels' stream); with any other exchange object (``gather_host(cand) -> rows``, ``rank``: the host-staged
+    exchanges of tests/swarm_support.py) the (D+1)-double record is staged through the host."""
     if isinstance(swarm, DeviceSwarm) and isinstance(exchange, RcclExchange):
         swarm.set_comm(exchange)
         try:
@@ -557,10 +402,10 @@ def run_sharded(swarm, exchange, maxiter, check_every=1, verbose=False):
             swarm.step_local()
             swarm.apply_global(exchange.gather_host(swarm.candidate()))
             if it % check_every == 0 or it == maxiter:
-                stopped = swarm.stop if isinstance(swarm, HostSwarm) else swarm.status()["stop"]
+                stopped = swarm.status()["stop"]
                 if stopped:
                     break
-        best = (swarm.best_x.copy(), float(swarm.best_f)) if isinstance(swarm, HostSwarm) else swarm.best()
+        best = swarm.best()
     if verbose and exchange.rank == 0:
         if stopped:
             print(STOP_MESSAGES[stopped].format(minfunc=getattr(swarm, "minfunc", 1e-8),

@@ -27,6 +27,7 @@ def _worker(rank, world, port, S, maxiter, seed, out_dir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from nmrfit_amd import pso, synth
+    from tests import swarm_support
     from oracle import c_oracle
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
@@ -34,9 +35,9 @@ def _worker(rank, world, port, S, maxiter, seed, out_dir):
 
         def evaluate(X):
             return c_oracle.objective_batch(X, sp["w"], sp["u"], sp["v"], sp["weights"], threads=1)
-        ex = pso.TorchExchange()
+        ex = swarm_support.TorchExchange()
         off, n = pso.shard(S, ex.rank, ex.world)
-        sw = pso.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=S, offset=off, S_local=n, seed=seed,
+        sw = swarm_support.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=S, offset=off, S_local=n, seed=seed,
                            minfunc=-1.0, minstep=-1.0)
         x, f = pso.run_sharded(sw, ex, maxiter=maxiter)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x, f=f, g=sw.g, fg=sw.fg, it=sw.iteration,
@@ -49,12 +50,13 @@ def _worker(rank, world, port, S, maxiter, seed, out_dir):
 def _single(S, maxiter, seed):
     sys.path.insert(0, ROOT)
     from nmrfit_amd import pso, synth
+    from tests import swarm_support
     from oracle import c_oracle
     sp = synth.make_spectrum(512, 2, seed=5)
 
     def evaluate(X):
         return c_oracle.objective_batch(X, sp["w"], sp["u"], sp["v"], sp["weights"], threads=1)
-    sw = pso.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=S, seed=seed, minfunc=-1.0, minstep=-1.0)
+    sw = swarm_support.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=S, seed=seed, minfunc=-1.0, minstep=-1.0)
     x, f = pso.run_sharded(sw, pso.LocalExchange(), maxiter=maxiter)
     return x, f, sw
 

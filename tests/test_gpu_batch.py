@@ -195,3 +195,51 @@ def test_batch_argument_validation():
             fb.status()                                # before the first generation
         fb.run(0, 1)
         assert fb.status()[0]["iteration"] == 0
+
+
+_SHARD_RANK = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import nmrfit_amd
+from nmrfit_amd import synth
+
+jobs = []
+for k, (N, P) in enumerate([(4096, 6), (4096, 4), (4096, 7), (2048, 3), (4096, 5), (4096, 6), (4096, 2)]):
+    sp = synth.make_spectrum(N, P, seed=80 + k)
+    jobs.append(dict(data=synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"]), lower=list(sp["lower"]),
+                     upper=list(sp["upper"]), options={"seed": 500 + k, "maxiter": 60, "swarmsize": 96}))
+res = nmrfit_amd.fit_many(jobs, shard=%(shard)s)
+print(json.dumps(dict(rank=int(os.environ.get("RANK", "0")), params=[list(map(float, r.params)) for r in res],
+                      errors=[float(r.error) for r in res])))
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fit_many_shards_jobs_over_ranks_on_one_gpu(world, tmp_path):
+    """The spectra-parallel multi-GPU mode rehearsed on one card: `world` rank processes (each shown device 0 only, the
+    way a launcher isolates ranks), fit_many(jobs, shard=True): rank r fits jobs r, r + world, ... as device batches
+    of its own, the records are gathered over the rendezvous channel, and every rank returns all seven results -- equal
+    bit for bit to the unsharded call's.  No collective touches the fits (replicas)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text(_SHARD_RANK % dict(root=root, shard="True"))
+    alone = tmp_path / "alone.py"
+    alone.write_text(_SHARD_RANK % dict(root=root, shard="False"))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="0")
+    ref = subprocess.run([sys.executable, str(alone)], env=env, capture_output=True, text=True, timeout=300)
+    assert ref.returncode == 0, ref.stderr[-2000:]
+    want = json.loads([l for l in ref.stdout.splitlines() if l.startswith("{")][-1])
+    renv = dict(env, WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                NMRFIT_RDZV_TOKEN="shard%d" % os.getpid())
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(renv, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-2000:]
+        got = json.loads([l for l in o.splitlines() if l.startswith("{")][-1])
+        assert got["params"] == want["params"] and got["errors"] == want["errors"], got["rank"]

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from nmrfit_amd import _cabi, pso, synth
+from tests import swarm_support
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +29,7 @@ def test_device_swarm_matches_numpy_mirror_bitwise(problem, S):
     sp, ev = problem
     seed = 77
     dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
-    host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+    host = swarm_support.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
     dev.init()
     host.init()
     st = dev.state()
@@ -107,7 +108,7 @@ def test_stop_flag_on_device_and_run_polling(problem):
         np.testing.assert_array_equal(r[2][0], res[0][2][0])
         assert r[2][1] == res[0][2][1]
     # and the mirror stops at the same generation with the same answer
-    host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], 64, seed=3)
+    host = swarm_support.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], 64, seed=3)
     xh, fh = pso.run_sharded(host, pso.LocalExchange(), 400)
     assert host.stop == res[0][0] and host.iteration == res[0][1]
     np.testing.assert_array_equal(xh, res[0][2][0])
@@ -115,7 +116,7 @@ def test_stop_flag_on_device_and_run_polling(problem):
     sw = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 600, seed=4)
     sw.run(300, check_every=5)
     st = sw.status()
-    host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], 600, seed=4)
+    host = swarm_support.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], 600, seed=4)
     xh, fh = pso.run_sharded(host, pso.LocalExchange(), 300)
     assert (st["stop"], st["iteration"]) == (host.stop, host.iteration)
     xb, fb = sw.best()
@@ -326,7 +327,7 @@ def test_device_swarm_wide_parameter_vectors(S, P):
     sp = synth.make_spectrum(1024, P, seed=9)
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
         dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=31, minfunc=-1.0, minstep=-1.0)
-        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=31, minfunc=-1.0, minstep=-1.0)
+        host = swarm_support.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=31, minfunc=-1.0, minstep=-1.0)
         dev.init(); host.init()
         for _ in range(4):
             np.testing.assert_array_equal(dev.candidate(), host.candidate())
@@ -351,7 +352,7 @@ def test_ticket_select_long_run(problem):
     sp, ev = problem
     S, seed, gens = 512, 19, 600
     dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
-    host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
+    host = swarm_support.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=seed, minfunc=-1.0, minstep=-1.0)
     dev.run(gens, check_every=200)
     host.init()
     host.apply_global(host.candidate()[None, :])
@@ -396,7 +397,7 @@ def test_handover_modes_match_numpy_mirror(S, N, P, variant, fit_im, mode):
         ev.set_variant(_cabi.variant_id(variant))
         ev.set_fit_im(fit_im)
         gens = 40
-        host = pso.HostSwarm(lambda X: ev.objective_batch(X, fit_im=fit_im), sp["lower"], sp["upper"], S, seed=23,
+        host = swarm_support.HostSwarm(lambda X: ev.objective_batch(X, fit_im=fit_im), sp["lower"], sp["upper"], S, seed=23,
                              minfunc=-1.0, minstep=-1.0)
         host.init()
         host.apply_global(host.candidate()[None, :])
@@ -432,7 +433,7 @@ def test_handover_modes_stop_rule(mode):
     from nmrfit_amd import equations
     sp = synth.make_spectrum(4096, 6, seed=1)
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
-        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], 204, seed=8)
+        host = swarm_support.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], 204, seed=8)
         xh, fh = pso.run_sharded(host, pso.LocalExchange(), 2000)
         assert host.stop in (1, 2) and host.iteration < 2000
         for ce in (64, 5):
@@ -535,9 +536,10 @@ sys.path.insert(0, %(root)r)
 import numpy as np
 import nmrfit_amd
 from nmrfit_amd import pso, synth
+from tests import swarm_support
 sp = synth.make_spectrum(4096, 6, seed=21)
 data = synth.SynthData(sp['w'], sp['u'], sp['v'], sp['peaks'])
-opts = {"swarmsize": 203, "maxiter": 80, "exchange": pso.SocketExchange()}       # UNSEEDED: rank 0's seed must win
+opts = {"swarmsize": 203, "maxiter": 80, "exchange": swarm_support.SocketExchange()}       # UNSEEDED: rank 0's seed must win
 opts.update(%(extra)r)
 res = nmrfit_amd.fit(data, list(sp['lower']), list(sp['upper']), summary=False, options=opts)
 res.generate_result()
@@ -671,7 +673,7 @@ def test_no_finite_objective_yet_seeds_g_with_particle_zero(S):
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], nan_w) as ev:
         kw = dict(minfunc=-1.0, minstep=-1.0)
         dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=31, **kw)
-        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=31, **kw)
+        host = swarm_support.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=31, **kw)
         dev.init()
         host.init()
         x0 = host.x[0].copy()
@@ -722,7 +724,7 @@ def test_lds_budget_on_both_sides_of_every_threshold(P, fit_im):
             ev.set_variant(_cabi.variant_id(variant))
             ev.set_fit_im(fit_im)
             dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], 6, seed=5, minfunc=-1.0, minstep=-1.0)
-            host = pso.HostSwarm(lambda X: ev.objective_batch(X, fit_im=fit_im), sp["lower"], sp["upper"], 6, seed=5,
+            host = swarm_support.HostSwarm(lambda X: ev.objective_batch(X, fit_im=fit_im), sp["lower"], sp["upper"], 6, seed=5,
                                  minfunc=-1.0, minstep=-1.0)
             dev.run(2, check_every=2)
             host.init()
@@ -752,7 +754,7 @@ def test_one_launch_generation(S, N, P, variant):
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
         ev.set_variant(_cabi.variant_id(variant))
         for kw, gens in ((dict(minfunc=-1.0, minstep=-1.0), 60), ({}, 400)):
-            host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=41, **kw)
+            host = swarm_support.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=41, **kw)
             xh, fh = pso.run_sharded(host, pso.LocalExchange(), gens)
             res = {}
             for fused in (True, False):
@@ -784,7 +786,7 @@ def test_deferred_fold_is_invisible_from_outside(S, N, P):
     sp = synth.make_spectrum(N, P, seed=12)
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
         kw = dict(minfunc=1e-3, minstep=1e-8)                # stops after some tens of generations: the stop is deferred too
-        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=77, **kw)
+        host = swarm_support.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=77, **kw)
         dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=77, **kw)
         host.init()
         host.apply_global(host.candidate()[None, :])
@@ -831,7 +833,7 @@ def test_deferred_fold_survives_a_change_of_kernel_between_generations():
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
         kw = dict(minfunc=-1.0, minstep=-1.0)
         mode = [False]
-        host = pso.HostSwarm(lambda X: ev.objective_batch(X, fit_im=mode[0]), sp["lower"], sp["upper"], S, seed=5, **kw)
+        host = swarm_support.HostSwarm(lambda X: ev.objective_batch(X, fit_im=mode[0]), sp["lower"], sp["upper"], S, seed=5, **kw)
         dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=5, **kw)
         host.init()
         host.apply_global(host.candidate()[None, :])
@@ -870,7 +872,7 @@ def test_random_walk_over_the_swarm_interface_matches_the_mirror(seed):
     sp = synth.make_spectrum(N, P, seed=20 + seed)
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
         kw = dict(minfunc=-1.0, minstep=-1.0) if seed != 2 else dict(minfunc=3e-4, minstep=1e-8)
-        host = pso.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=900 + seed, **kw)
+        host = swarm_support.HostSwarm(ev.objective_batch, sp["lower"], sp["upper"], S, seed=900 + seed, **kw)
         dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=900 + seed, **kw)
         host.init()
         host.apply_global(host.candidate()[None, :])
@@ -965,7 +967,7 @@ def test_one_launch_generation_with_the_imaginary_channel(fit_im):
     with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
         ev.set_fit_im(fit_im)
         kw = dict(minfunc=-1.0, minstep=-1.0)
-        host = pso.HostSwarm(lambda X: ev.objective_batch(X, fit_im=fit_im), sp["lower"], sp["upper"], S, seed=17, **kw)
+        host = swarm_support.HostSwarm(lambda X: ev.objective_batch(X, fit_im=fit_im), sp["lower"], sp["upper"], S, seed=17, **kw)
         xh, fh = pso.run_sharded(host, pso.LocalExchange(), 40)
         dev = pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=17, **kw)
         dev.run(40, check_every=7)

@@ -1,12 +1,13 @@
 """
 CPU tier (iii): host logic of the swarm driver -- the numpy mirror of the device kernels
-(nmrfit_amd.pso.HostSwarm) with the oracle injected as the evaluator (test infrastructure;
+(nmrfit_amd.swarm_support.HostSwarm) with the oracle injected as the evaluator (test infrastructure;
 the product never does this), the counter RNG, the pyswarm stopping rule and the sharding.
 """
 import numpy as np
 import pytest
 
 from nmrfit_amd import pso, synth
+from tests import swarm_support
 from oracle import c_oracle
 from oracle import nmrfit_oracle as onp
 
@@ -58,7 +59,7 @@ def test_shard_covers_swarm():
 def test_host_swarm_converges():
     sp, evaluate = _problem()
     f_true = evaluate(sp["x_true"][None, :])[0]
-    sw = pso.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=64, seed=11)
+    sw = swarm_support.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=64, seed=11)
     x, f = pso.run_sharded(sw, pso.LocalExchange(), maxiter=150)
     # pyswarm's minfunc rule stops at the first improvement smaller than 1e-8, typically after
     # 50-150 generations here, at 1.0-1.5x the objective of the generating parameters
@@ -142,7 +143,7 @@ def test_swarm_rule_equals_the_restated_pyswarm_bit_for_bit(case):
     seed = 1000 + case
     func_o, func_h = make(), make()
     xo, fo, st = onp.pso(func_o, lb, ub, swarmsize=S, maxiter=maxiter, rng=PhiloxFeed(seed, S, D), full_output=True, **kw)
-    sw = pso.HostSwarm(lambda X: np.array([func_h(x) for x in X]), lb, ub, swarmsize=S, seed=seed, **kw)
+    sw = swarm_support.HostSwarm(lambda X: np.array([func_h(x) for x in X]), lb, ub, swarmsize=S, seed=seed, **kw)
     xh, fh = pso.run_sharded(sw, pso.LocalExchange(), maxiter=maxiter)
     if reason is not None:
         assert st["reason"] == reason, name
@@ -177,7 +178,7 @@ def test_swarm_rule_pin_survives_sharding():
     shards = []
     for r in range(3):
         off, n = pso.shard(S, r, 3)
-        shards.append(pso.HostSwarm(lambda X: np.array([f_sh(x) for x in X]), lb, ub, swarmsize=S, offset=off,
+        shards.append(swarm_support.HostSwarm(lambda X: np.array([f_sh(x) for x in X]), lb, ub, swarmsize=S, offset=off,
                                     S_local=n, seed=77, **kw))
     for s in shards:
         s.init()
@@ -208,7 +209,7 @@ def test_stop_rules_follow_pyswarm():
         calls["n"] += 1
         return np.full(X.shape[0], 1.0 - 1e-9 * calls["n"]) + 1e-12 * np.arange(X.shape[0])
 
-    sw = pso.HostSwarm(flat, lb, ub, swarmsize=10, seed=1)
+    sw = swarm_support.HostSwarm(flat, lb, ub, swarmsize=10, seed=1)
     x, f = pso.run_sharded(sw, pso.LocalExchange(), maxiter=50)
     assert sw.stop == 1 and sw.iteration == 1       # stopped by the first generation after init
     assert f < sw.fg                                 # it returns (p_min, fp[i_min]), not (g, fg)
@@ -217,26 +218,26 @@ def test_stop_rules_follow_pyswarm():
     def bowl(X):
         return np.sum(X * X, axis=1)
 
-    sw = pso.HostSwarm(bowl, lb, ub, swarmsize=30, seed=2, minfunc=0.0, minstep=1e-3)
+    sw = swarm_support.HostSwarm(bowl, lb, ub, swarmsize=30, seed=2, minfunc=0.0, minstep=1e-3)
     pso.run_sharded(sw, pso.LocalExchange(), maxiter=500)
     assert sw.stop == 2                              # position change below minstep
-    sw = pso.HostSwarm(bowl, lb, ub, swarmsize=30, seed=2, minfunc=-1.0, minstep=-1.0)
+    sw = swarm_support.HostSwarm(bowl, lb, ub, swarmsize=30, seed=2, minfunc=-1.0, minstep=-1.0)
     pso.run_sharded(sw, pso.LocalExchange(), maxiter=25)
     assert sw.stop == 0 and sw.iteration == 25       # never stops: maximum iterations reached
     with pytest.raises(AssertionError):
-        pso.HostSwarm(bowl, ub, lb, swarmsize=4)     # pyswarm: assert np.all(ub > lb)
+        swarm_support.HostSwarm(bowl, ub, lb, swarmsize=4)     # pyswarm: assert np.all(ub > lb)
 
 
 def test_two_shards_in_process_equal_one_swarm_bitwise():
     """SURVEY 8(e) determinism: sharding must not change the trajectory."""
     sp, evaluate = _problem(N=256, P=1, seed=8)
-    one = pso.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=21, seed=99)
+    one = swarm_support.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=21, seed=99)
     one.init()
     one.apply_global(one.candidate()[None, :])
     shards = []
     for r in range(3):
         off, n = pso.shard(21, r, 3)
-        s = pso.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=21, offset=off, S_local=n, seed=99)
+        s = swarm_support.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=21, offset=off, S_local=n, seed=99)
         s.init()
         shards.append(s)
     cands = np.stack([s.candidate() for s in shards])
@@ -259,6 +260,6 @@ def test_two_shards_in_process_equal_one_swarm_bitwise():
 
 def test_empty_shard_is_harmless():
     sp, evaluate = _problem(N=128, P=1, seed=8)
-    s = pso.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=4, offset=4, S_local=0, seed=1)
+    s = swarm_support.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=4, offset=4, S_local=0, seed=1)
     s.init()
     assert s.candidate()[0] == np.inf

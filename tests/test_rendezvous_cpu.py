@@ -1,7 +1,7 @@
 """
 CPU tier (iv) without torch: the standard-library rendezvous (nmrfit_amd/rendezvous.py) that
 hands RCCL's unique id to the ranks, and the sharded generation loop over it
-(pso.SocketExchange) with real processes -- world sizes 2, 3 and 8 (the C4 rank count) on
+(swarm_support.SocketExchange) with real processes -- world sizes 2, 3 and 8 (the C4 rank count) on
 127.0.0.1.  Every rank must end with the single-rank answer bit for bit.  Also: the
 self-launching `bench.py --gpus N` must fail fast and loudly when its ranks fail (here: no GPU),
 never hang; its --launch-timeout ends ranks that never arrive and names them; every rank's own
@@ -119,17 +119,18 @@ def _swarm_worker(rank, world, port, token, S, maxiter, seed, out_dir):
     sys.path.insert(0, ROOT)
     _env(rank, world, port, token, {})
     from nmrfit_amd import pso, synth
+    from tests import swarm_support
     from oracle import c_oracle
     sp = synth.make_spectrum(512, 2, seed=5)
 
     def evaluate(X):
         return c_oracle.objective_batch(X, sp["w"], sp["u"], sp["v"], sp["weights"], threads=1)
-    ex = pso.SocketExchange()
+    ex = swarm_support.SocketExchange()
     assert (ex.rank, ex.world) == (rank, world)
     seed = ex.broadcast_seed(seed if rank == 0 else 999)        # rank 0's seed wins
     assert float(ex.all_reduce([float(rank)], "max")[0]) == world - 1
     off, n = pso.shard(S, ex.rank, ex.world)
-    sw = pso.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=S, offset=off, S_local=n, seed=seed,
+    sw = swarm_support.HostSwarm(evaluate, sp["lower"], sp["upper"], swarmsize=S, offset=off, S_local=n, seed=seed,
                        minfunc=-1.0, minstep=-1.0)
     x, f = pso.run_sharded(sw, ex, maxiter=maxiter)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x, f=f, g=sw.g, fg=sw.fg, it=sw.iteration, xs=sw.x)
@@ -141,6 +142,7 @@ def _swarm_worker(rank, world, port, token, S, maxiter, seed, out_dir):
 def test_sharded_swarm_over_sockets_equals_single_rank(tmp_path, world, S):
     sys.path.insert(0, ROOT)
     from nmrfit_amd import pso, synth
+    from tests import swarm_support
     from oracle import c_oracle
     maxiter, seed = 12, 4242
     ctx = mp.get_context("spawn")
@@ -154,7 +156,7 @@ def test_sharded_swarm_over_sockets_equals_single_rank(tmp_path, world, S):
         p.join(180)
         assert p.exitcode == 0
     sp = synth.make_spectrum(512, 2, seed=5)
-    sw1 = pso.HostSwarm(lambda X: c_oracle.objective_batch(X, sp["w"], sp["u"], sp["v"], sp["weights"], threads=1),
+    sw1 = swarm_support.HostSwarm(lambda X: c_oracle.objective_batch(X, sp["w"], sp["u"], sp["v"], sp["weights"], threads=1),
                         sp["lower"], sp["upper"], swarmsize=S, seed=seed, minfunc=-1.0, minstep=-1.0)
     x1, f1 = pso.run_sharded(sw1, pso.LocalExchange(), maxiter=maxiter)
     xs = []

@@ -730,7 +730,8 @@ def main():
             f_def = None
             variants = {}
             reps = max(5, min(args.steps, 20))
-            for name, vid in (("default", _cabi.VARIANT_DEFAULT), ("farfield", _cabi.VARIANT_FARFIELD)):
+            for name, vid in (("default", _cabi.VARIANT_DEFAULT), ("farfield", _cabi.VARIANT_FARFIELD),
+                              ("farfield32", _cabi.VARIANT_FARFIELD32)):
                 ev.set_variant(vid)
                 ms = time_objective(ev, S_local, P, d_x, d_f, reps)
                 f = ev.download(d_f, (S_local,))
@@ -1096,6 +1097,15 @@ def main():
                 except Exception as e:
                     fd["pmc_error"] = repr(e)
             line["fit_default"] = fd
+            # the opt-in mixed-precision form of that kernel: never `value`, never selected automatically
+            line["mixed_precision"] = {
+                "variant": "farfield32", "kernel_ms": variants["farfield32_ms"],
+                "units_per_s": units_launch / (variants["farfield32_ms"] * 1e-3),
+                "kernel_ms_fp64_farfield": variants["farfield_ms"],
+                "speedup_vs_fp64_farfield": variants["farfield_ms"] / variants["farfield32_ms"],
+                "max_rel_diff_vs_default": variants["farfield32_max_rel_diff_vs_default"],
+                "note": "orders 1..15 of the far-field kernel's shared polynomial in packed fp32 (v_pk_fma_f32), everything "
+                        "else fp64; options={'variant': 'farfield32'}"}
         def counters_of(name, units, kernel_ms):
             """instructions per unit, busy and issue fraction of an extra PMC pass (objective launches only)"""
             c = (pmc_live or {}).get(name, {})

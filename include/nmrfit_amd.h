@@ -61,6 +61,13 @@ enum {
     NMRFIT_VARIANT_FARFIELD = 6,  /* opt-in: Lorentzian tails of distant peaks through one shared
                                      Taylor expansion per 512-point chunk (truncation <= 1e-16 of each
                                      term); not the default because it changes the per-unit work      */
+    NMRFIT_VARIANT_FARFIELD32 = 8, /* opt-in MIXED PRECISION (ABI 5): FARFIELD with orders 1..15 of its shared polynomial in
+                                     packed fp32 (v_pk_fma_f32); everything else -- near peaks, Gaussians, data, the constant
+                                     term, every sum -- stays fp64.  f within 5e-12 relative of FARFIELD on the
+                                     reference-generated goldens and on dense spectra, -5.5 % kernel time at
+                                     4096 x 65536 x 24.  Never selected automatically (narrower than the reference's
+                                     float64); objective launches without the imaginary channel only -- residual rows
+                                     and fit_im run FARFIELD                                                        */
     NMRFIT_VARIANT_NOREC = 7      /* the general form throughout: 8 Lorentzians per reciprocal, one
                                      reciprocal per point, one exp2 for every in-window Gaussian.
                                      (DEFAULT and FARFIELD objective launches on a uniformly spaced

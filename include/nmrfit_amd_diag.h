@@ -66,17 +66,19 @@ int nmrfit_pso_set_candidate_dev(nmrfit_pso *pso, double *dptr);
  * the minfunc / minstep stopping tests.  Single-rank callers pass their own candidate. */
 int nmrfit_pso_apply_global_dev(nmrfit_pso *pso, const double *d_candidates, int32_t nranks);
 
-/* How the workgroups of the personal-best / argmin kernel hand their results to the workgroup that
- * finishes the reduction (swarms of up to 1024 particles do it inside ONE launch; the swarm loop
- * replacing nmrfit/utils.py:176-182).  Results are bit-identical in every mode.
- *   FAST (default)  agent-scope write-through atomic stores ordered by s_waitcnt vmcnt(0): no L2
- *                   write-back per workgroup (6.7 us instead of 8.8 us per select at 51 workgroups)
- *   FENCED          release / acquire fences at agent scope: the textbook form, kept as the A/B
- *                   reference for FAST (tools/handover_stress.py); NMRFIT_SAFE_HANDOVER=1 in the
- *                   environment makes it the default of every swarm created afterwards
- *   TWO_LAUNCH      no hand-over inside a launch: the reduction is its own launch (what larger
- *                   swarms use anyway)
- * Never switched automatically. */
+/* How the workgroups of the personal-best / argmin kernel hand their results to the workgroup that finishes the
+ * reduction (the swarm loop replacing nmrfit/utils.py:176-182), where a generation is NOT finished inside the objective
+ * launch (swarms whose launch geometry does not make a workgroup the particle: the imaginary channel on a small swarm,
+ * A/B settings).  Results are bit-identical in every mode.
+ *   TWO_LAUNCH (default, round 5)  no hand-over inside a launch: the reduction is its own launch, the kernel boundary
+ *                   orders everything -- nothing in the default configuration rests on memory-ordering behaviour
+ *                   outside the AMDGPU memory model.  +1.8-2.1 us per generation at 204 particles against FAST, none
+ *                   at 1024 (profiles/r05/handover_cost.txt)
+ *   FAST            one launch: agent-scope write-through atomic stores ordered by s_waitcnt vmcnt(0), no L2 write-back
+ *                   per workgroup; rests on measured gfx950 behaviour (tools/handover_stress.py)
+ *   FENCED          one launch: release / acquire fences at agent scope, the textbook form (a fence is an L2
+ *                   write-back on this 8-XCD part: 9 us more per generation at 1024 particles)
+ * NMRFIT_HANDOVER=fast|fenced in the environment changes the default of swarms created afterwards. */
 enum { NMRFIT_HANDOVER_FAST = 0, NMRFIT_HANDOVER_FENCED = 1, NMRFIT_HANDOVER_TWO_LAUNCH = 2 };
 int nmrfit_pso_set_handover(nmrfit_pso *pso, int mode);
 /* When the launch geometry puts a whole particle into one workgroup (four grid segments per particle: e.g.

@@ -23,10 +23,11 @@ UNIQUE_ID_BYTES = 128
 FIT_IM_OFF, FIT_IM_REFERENCE, FIT_IM_SUM = 0, 1, 2
 VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED, VARIANT_FARFIELD = 0, 1, 2, 3, 4, 5, 6
 VARIANT_NOREC = 7
+VARIANT_FARFIELD32 = 8     # opt-in mixed precision: the far-field kernel's shared polynomial in packed fp32
 HANDOVER_FAST, HANDOVER_FENCED, HANDOVER_TWO_LAUNCH = 0, 1, 2
 ABI_VERSION = 5
 _VARIANT_NAMES = {"default": 0, "baseline": 1, "noskip": 2, "single": 3, "quad": 4, "staged": 5, "farfield": 6,
-                  "norec": 7}
+                  "norec": 7, "farfield32": 8}
 
 
 def variant_id(v):
@@ -164,14 +165,14 @@ def has_ab_variants():
     return bool(lib().nmrfit_diag_ab_build())
 
 
-PRODUCT_VARIANTS = (VARIANT_DEFAULT, VARIANT_FARFIELD, VARIANT_NOREC)
+PRODUCT_VARIANTS = (VARIANT_DEFAULT, VARIANT_FARFIELD, VARIANT_NOREC, VARIANT_FARFIELD32)
 
 
 def available_variants():
     """Kernel variants of the loaded library: the three product kernels, plus the A/B forms in an A/B build."""
     if has_ab_variants():
         return [VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD, VARIANT_STAGED,
-                VARIANT_FARFIELD, VARIANT_NOREC]
+                VARIANT_FARFIELD, VARIANT_NOREC, VARIANT_FARFIELD32]
     return list(PRODUCT_VARIANTS)
 
 

@@ -285,9 +285,11 @@ int nmrfit_ctx_create(int device, int64_t N, const double *w, const double *u, c
     if (const char *dv = getenv("NMRFIT_DEFAULT_VARIANT")) {
         const int vnum = atoi(dv);
 #ifdef NMRFIT_AB_BUILD
-        if (vnum >= 0 && vnum <= NMRFIT_VARIANT_NOREC) ctx->variant = vnum;
+        if (vnum >= 0 && vnum <= NMRFIT_VARIANT_FARFIELD32) ctx->variant = vnum;
 #else
-        if (vnum == NMRFIT_VARIANT_DEFAULT || vnum == NMRFIT_VARIANT_FARFIELD || vnum == NMRFIT_VARIANT_NOREC) ctx->variant = vnum;
+        if (vnum == NMRFIT_VARIANT_DEFAULT || vnum == NMRFIT_VARIANT_FARFIELD || vnum == NMRFIT_VARIANT_NOREC ||
+            vnum == NMRFIT_VARIANT_FARFIELD32)
+            ctx->variant = vnum;
 #endif
     }
     analyse_grid(w, N, &ctx->w0, &ctx->wspan, &ctx->lane_step, &ctx->grid_dev);
@@ -395,12 +397,13 @@ int nmrfit_ctx_set_stream(nmrfit_ctx *ctx, void *hip_stream)
 
 int nmrfit_ctx_set_variant(nmrfit_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant > NMRFIT_VARIANT_NOREC) {
+    if (!ctx || variant < 0 || variant > NMRFIT_VARIANT_FARFIELD32) {
         set_error("bad context or variant");
         return NMRFIT_E_INVALID;
     }
 #ifndef NMRFIT_AB_BUILD
-    if (variant != NMRFIT_VARIANT_DEFAULT && variant != NMRFIT_VARIANT_FARFIELD && variant != NMRFIT_VARIANT_NOREC) {
+    if (variant != NMRFIT_VARIANT_DEFAULT && variant != NMRFIT_VARIANT_FARFIELD && variant != NMRFIT_VARIANT_NOREC &&
+        variant != NMRFIT_VARIANT_FARFIELD32) {
         set_error("this kernel variant is an A/B form: it exists in libnmrfit_amd_ab.so (nmrfit_amd/csrc/build.sh --ab) only");
         return NMRFIT_E_UNSUPPORTED;
     }

@@ -119,6 +119,10 @@ static_assert(kObjectiveStaticLds == (size_t)kWsumsCount * sizeof(double) + 64, 
 size_t objective_lds(int variant, int32_t P, bool residual, int fit_im, int *variant_out, unsigned *aux_off, int wpb,
                      int slices, int rows)
 {
+    // the mixed-precision far-field kernel exists for objective launches without the imaginary channel; everything else
+    // of a context set to it runs the fp64 far-field kernel (same records, same LDS)
+    const bool want32 = variant == NMRFIT_VARIANT_FARFIELD32;
+    if (want32) variant = NMRFIT_VARIANT_FARFIELD;
     const size_t np = (size_t)std::max(P, 1);
     // what a workgroup may take of a CU's 160 KiB for the records sized here: everything but the kernel's static
     // LDS and (swarm generations) the per-wave copies of the updated rows that launch_objective appends
@@ -156,6 +160,7 @@ size_t objective_lds(int variant, int32_t P, bool residual, int fit_im, int *var
         *aux_off = (unsigned)lds;
         lds += lds_tab;
     }
+    if (want32 && variant == NMRFIT_VARIANT_FARFIELD && !residual && fit_im == 0) variant = NMRFIT_VARIANT_FARFIELD32;
     *variant_out = variant;
     return lds;
 }
@@ -309,6 +314,7 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     switch (variant) {   // one translation unit per selectable variant (they compile in parallel)
         case NMRFIT_VARIANT_DEFAULT: rc = launch_objective_default(la); break;
         case NMRFIT_VARIANT_FARFIELD: rc = launch_objective_farfield(la); break;
+        case NMRFIT_VARIANT_FARFIELD32: rc = launch_objective_farfield32(la); break;
         case NMRFIT_VARIANT_NOREC: rc = launch_objective_norec(la); break;
         default:
 #ifdef NMRFIT_AB_BUILD

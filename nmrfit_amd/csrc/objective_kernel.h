@@ -79,8 +79,8 @@ namespace {
 constexpr int objective_min_waves(int variant, int fit_im)
 {
     const bool tuned = variant == NMRFIT_VARIANT_DEFAULT || variant == NMRFIT_VARIANT_NOSKIP || variant == NMRFIT_VARIANT_STAGED ||
-                       variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_NOREC;
-    return (fit_im != 0 && variant == NMRFIT_VARIANT_FARFIELD) ? 2 : (fit_im == 2) ? 2 : tuned ? kMinWaves : 4;
+                       is_farfield(variant) || variant == NMRFIT_VARIANT_NOREC;
+    return (fit_im != 0 && is_farfield(variant)) ? 2 : (fit_im == 2) ? 2 : tuned ? kMinWaves : 4;
 }
 // WAVE_SWARM (device-batched fits, objective_batch.hip): every WAVE holds a whole particle (one segment) and does
 // the particle's whole swarm step by itself -- deferred fold, update, evaluation, personal best (swarm_prologue.h).
@@ -146,10 +146,10 @@ __device__ __forceinline__ void objective_body(
 
     // objective launches of DEFAULT / FARFIELD: per-peak (d, C) of the Gaussian recurrence, after
     // everything else (residual rows are evaluated point by point: they feed finite differences)
-    constexpr bool kRec = !WRITE_R && (VARIANT == NMRFIT_VARIANT_DEFAULT || VARIANT == NMRFIT_VARIANT_FARFIELD);
+    constexpr bool kRec = !WRITE_R && (VARIANT == NMRFIT_VARIANT_DEFAULT || is_farfield(VARIANT));
     unsigned char *grec_base = lds_tail2 +
                         (kStage ? (size_t)WPB * 3 * kChunk * sizeof(double)
-                                : (VARIANT == NMRFIT_VARIANT_FARFIELD || FIT_IM == 2) ? (size_t)WPB * kFarTerms * kFarPad * sizeof(double) : 0);
+                                : (is_farfield(VARIANT) || FIT_IM == 2) ? (size_t)WPB * kFarTerms * kFarPad * sizeof(double) : 0);
     double2 *grec = reinterpret_cast<double2 *>(grec_base) + (size_t)slice * P;
 
     // DEFAULT: scaled Lorentzian constants for the two-operation pair form, after grec
@@ -359,7 +359,7 @@ __device__ __forceinline__ void objective_body(
     const double base = wave_uniform((double)P * yoff);   // yoff is added once per peak (equations.py:147,195)
     double ss = 0.0, ss_im = 0.0;
     constexpr bool kSkip = (VARIANT != NMRFIT_VARIANT_NOSKIP && VARIANT != NMRFIT_VARIANT_BASELINE);
-    constexpr bool kFar = (VARIANT == NMRFIT_VARIANT_FARFIELD);
+    constexpr bool kFar = is_farfield(VARIANT);
     constexpr int kGroup = (VARIANT == NMRFIT_VARIANT_SINGLE) ? 1 : (VARIANT == NMRFIT_VARIANT_QUAD) ? 4 : kGroupSize;
 
     unsigned even_near = 0, even_hits = 0;     // FARFIELD, P <= 32: near-peak and Gaussian-window masks of the even ...
@@ -543,6 +543,31 @@ __device__ __forceinline__ void objective_body(
                         // and the accumulators need neither initialising nor a separate add per point.
                         const double ihw1 = (hw > 0.0) ? rcp64(hw) : 0.0;
                         const double c0 = cf[0] + base;
+                        if constexpr (VARIANT == NMRFIT_VARIANT_FARFIELD32) {
+                            // Mixed precision, opt-in: orders 1..15 of the shared polynomial in PACKED
+                            // fp32 -- v_pk_fma_f32, two points per instruction -- the constant term and the last step in
+                            // fp64.  What is rounded to fp32 is the VARIATION of the far peaks' tails across the chunk
+                            // (rho <= 0.1: first order <= a tenth of their sum), never a near peak, a Gaussian or the
+                            // data: f moves by <= 5e-12 relative on the reference-generated goldens and on dense spectra
+                            // (profiles/r05/farfield_f32_horner.txt), -5.5 % kernel time at C3.
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            float cff[kFarTerms];
+#pragma unroll
+                            for (int n = 1; n < kFarTerms; ++n) cff[n] = (float)cf[n];
+#pragma unroll
+                            for (int q = 0; q < kPointsPerLane; q += 2) {
+                                const double u0 = (wv[q] - wcen) * ihw1, u1 = (wv[q + 1] - wcen) * ihw1;
+                                const f32x2 uf = {(float)u0, (float)u1};
+                                f32x2 pz = {cff[kFarTerms - 1], cff[kFarTerms - 1]};
+#pragma unroll
+                                for (int n = kFarTerms - 2; n >= 1; --n) {
+                                    const f32x2 cn = {cff[n], cff[n]};
+                                    pz = __builtin_elementwise_fma(pz, uf, cn);
+                                }
+                                acc[q] = __builtin_fma((double)pz.x, u0, c0);         // the constant term and the last step: fp64
+                                acc[q + 1] = __builtin_fma((double)pz.y, u1, c0);
+                            }
+                        } else
 #pragma unroll
                         for (int q = 0; q < kPointsPerLane; ++q) {
                             const double uu = (wv[q] - wcen) * ihw1;
@@ -885,7 +910,7 @@ __device__ __forceinline__ void objective_body(
         }
     };
     int64_t jb = j0;
-    if constexpr (VARIANT == NMRFIT_VARIANT_FARFIELD) {   // chunks alternate even / odd from the segment start
+    if constexpr (is_farfield(VARIANT)) {   // chunks alternate even / odd from the segment start
         for (; jb + 2 * kChunk <= j1; jb += 2 * kChunk) {
             chunk(jb, std::true_type{}, std::false_type{});
             chunk(jb + kChunk, std::true_type{}, std::true_type{});
@@ -1037,7 +1062,16 @@ int launch_variant(const ObjectiveLaunch &a)
     const bool prof = ctx->prof_cap > 0 && ctx->prof_nk < ctx->prof_cap;
     unsigned long long *clk = prof ? ctx->d_clk : nullptr;
     if (prof) NMRFIT_HIP(hipEventRecord(ctx->prof_k0[(size_t)ctx->prof_nk], ctx->stream));
-    if (dR) {
+    if constexpr (VARIANT == NMRFIT_VARIANT_FARFIELD32) {   // (objective launches without the imaginary channel only:
+        if (dR || fit_im != 0) {                             // launch_objective sends everything else to FARFIELD)
+            set_error("internal: FARFIELD32 launch with residual rows or the imaginary channel");
+            return NMRFIT_E_STATE;
+        }
+        if (wpb == kWideWaves)
+            NMRFIT_LAUNCH_W(false, 0, kWideWaves);
+        else
+            NMRFIT_LAUNCH(false, 0);
+    } else if (dR) {
         NMRFIT_LAUNCH(true, 0);
     } else if (fit_im == 0) {
         if constexpr (has_eight_wave_form(VARIANT)) {

@@ -28,9 +28,10 @@ struct ObjectiveLaunch {
 
 // Which instantiations exist with eight-wave workgroups (one workgroup = one particle cut into eight segments):
 // the objective launches without the imaginary channel of the three kernels fit() can select.
+constexpr bool is_farfield(int variant) { return variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_FARFIELD32; }
 constexpr bool has_eight_wave_form(int variant)
 {
-    return variant == NMRFIT_VARIANT_DEFAULT || variant == NMRFIT_VARIANT_FARFIELD || variant == NMRFIT_VARIANT_NOREC;
+    return variant == NMRFIT_VARIANT_DEFAULT || is_farfield(variant) || variant == NMRFIT_VARIANT_NOREC;
 }
 constexpr int kWideWaves = 8;
 // objective_kernel's own __shared__ block (wsums: 2 x kMaxBlocks block sums + 8 parked values) + alignment slack
@@ -45,6 +46,7 @@ size_t objective_lds(int variant, int32_t P, bool residual, int fit_im, int *var
 int launch_objective_default(const ObjectiveLaunch &a);    // objective_default.hip
 int launch_objective_farfield(const ObjectiveLaunch &a);   // objective_farfield.hip
 int launch_objective_norec(const ObjectiveLaunch &a);      // objective_norec.hip
+int launch_objective_farfield32(const ObjectiveLaunch &a); // objective_farfield32.hip (objective launches, fit_im = 0)
 #ifdef NMRFIT_AB_BUILD
 int launch_objective_ab(int variant, const ObjectiveLaunch &a);   // objective_ab.hip: BASELINE, NOSKIP, SINGLE, QUAD, STAGED
 #endif

@@ -40,6 +40,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 
 struct nmrfit_pso {
@@ -61,7 +62,8 @@ struct nmrfit_pso {
     double *d_part_val = nullptr;      // pso_select_kernel: per-workgroup (min fp, index) posts
     long long *d_part_idx = nullptr;
     unsigned *d_ticket = nullptr;
-    int handover = NMRFIT_HANDOVER_FAST;   // nmrfit_pso_set_handover: how the select kernel's workgroups hand over
+    int handover = NMRFIT_HANDOVER_TWO_LAUNCH;   // nmrfit_pso_set_handover: how the select kernel's workgroups hand over
+                                                 // (round 5 default: not inside a launch at all -- see the comment below)
     bool fused_pbest = true;               // nmrfit_pso_set_fused_pbest: personal bests inside the objective launch
     bool fused_tail = true;                // ... and the rest of a single-rank generation, as a fold deferred into the next
                                            // objective launch's prologue (PsoFused::tail; NMRFIT_NO_FUSED_TAIL: A/B knob)
@@ -227,7 +229,13 @@ constexpr int kSelectMaxPosts = 65536;    // posts buffer; larger swarms: the wo
 //           ticket is an acq_rel read-modify-write, the finishing workgroup fences before it reads.
 //           A/B reference for FAST, never chosen automatically.
 //   TWO_LAUNCH  no hand-over inside a launch at all: posts, then pso_select_final_kernel as its own
-//           launch (the kernel boundary orders everything).  What swarms above 1024 particles use.
+//           launch (the kernel boundary orders everything).  What swarms above 1024 particles use -- and, from
+//           round 5, the DEFAULT everywhere: the shapes nmrfit_amd.fit() spends its time in finish a generation
+//           inside the objective launch (deferred fold) and never come here; what still does (the imaginary
+//           channel on a small swarm, personal bests switched off) pays 1.8-2.1 us per generation for an
+//           ordering that rests on the kernel boundary instead of on measured hardware behaviour
+//           (204 x 4096 x 6 with fit_im: 21.5 -> 23.3 us; 1024 particles: the same or faster;
+//           profiles/r05/handover_cost.txt).  FAST and FENCED remain as opt-in A/B forms.
 
 // Reduce the nb posted (min fp, index) pairs, write the candidate record and (kTailApply) fold
 // it.  Called by every thread of ONE workgroup; posts and rows written by other workgroups are
@@ -645,8 +653,10 @@ int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_
     pso->P = P;
     pso->D = D;
     pso->prm = *params;
-    if (const char *e = getenv("NMRFIT_SAFE_HANDOVER"))   // A/B knob: the fenced hand-over as every swarm's default
-        if (atoi(e) != 0) pso->handover = NMRFIT_HANDOVER_FENCED;
+    if (const char *e = getenv("NMRFIT_HANDOVER")) {   // A/B knob: every new swarm's hand-over form
+        if (!strcmp(e, "fast")) pso->handover = NMRFIT_HANDOVER_FAST;
+        if (!strcmp(e, "fenced")) pso->handover = NMRFIT_HANDOVER_FENCED;
+    }
     if (getenv("NMRFIT_NO_FUSED_PBEST")) pso->fused_pbest = false;   // A/B knob
     if (getenv("NMRFIT_NO_FUSED_TAIL")) pso->fused_tail = false;     // A/B knob
     const size_t sd = (size_t)std::max<int64_t>(S_local * D, 1) * sizeof(double);

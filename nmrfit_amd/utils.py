@@ -12,7 +12,8 @@ Kept verbatim from the reference interface:
            (utils.py:177-181).  Extra opt-in keys: minstep, minfunc (pyswarm's 1e-8 defaults,
            which the reference does not forward), seed, device, check_every, polish,
            variant (kernel variant by name or number; default: "farfield" when grid x peaks
-           >= 1e5, else "default" -- see default_variant), exchange ("rccl" for a
+           >= 1e5, else "default" -- see default_variant; "farfield32" is the opt-in mixed-precision
+           form of the far-field kernel, f within 5e-12 of it, 5 % faster at C3 size), exchange ("rccl" for a
            multi-GPU fit, one process per GPU: the swarm axis is sharded and the global best is
            exchanged by one RCCL all-gather per generation inside libnmrfit_amd.so).
 

@@ -50,7 +50,7 @@ def test_ab_variants_exist_in_the_ab_library_only():
     if os.environ.get("NMRFIT_LIB"):
         pytest.skip("another library is loaded through NMRFIT_LIB")
     assert L.nmrfit_diag_ab_build() == 0
-    assert not _cabi.has_ab_variants() and _cabi.available_variants() == [0, 6, 7]
+    assert not _cabi.has_ab_variants() and _cabi.available_variants() == [0, 6, 7, 8]
     if os.path.exists(_cabi.AB_LIB_PATH):
         A = ctypes.CDLL(_cabi.AB_LIB_PATH)
         assert A.nmrfit_diag_ab_build() == 1

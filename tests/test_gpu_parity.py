@@ -631,3 +631,37 @@ def test_farfield_as_context_default_runs_the_swarm(eq):
         d = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), fit_im=mode, summary=False,
                            options=dict(opts, maxiter=40))
         assert np.isfinite(c.error) and c.error == pytest.approx(d.error, rel=0.2)
+
+
+def test_mixed_precision_farfield_variant(eq):
+    """NMRFIT_VARIANT_FARFIELD32 (opt-in): orders 1..15 of the far-field kernel's shared polynomial in packed
+    fp32, everything else fp64.  Bar: 1e-8 relative on f against the fp64 kernels; measured <= 5e-12 --
+    asserted at 1e-10 on the C3 workload, on a dense spectrum where every peak is near every chunk, and on the
+    reference-generated C3-shape golden; residual rows of a context set to it are the fp64 far-field kernel's, bit for
+    bit; fit() takes it by name."""
+    import nmrfit_amd
+    sp, X = synth.make_workload("C3")
+    Xd = synth.make_dense_swarm(128, 24, seed=5, w_lo=float(sp["w"].min()), w_hi=float(sp["w"].max()))
+    with eq.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        out = {}
+        for v in (_cabi.VARIANT_DEFAULT, _cabi.VARIANT_FARFIELD, _cabi.VARIANT_FARFIELD32):
+            ev.set_variant(v)
+            out[v] = (ev.objective_batch(X[:1024]), ev.objective_batch(Xd), ev.objective_batch(X[:7]), ev.residual_batch(X[:2]))
+        for k in range(3):
+            ref = out[_cabi.VARIANT_DEFAULT][k]
+            got = out[_cabi.VARIANT_FARFIELD32][k]
+            assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)) < 1e-10
+        assert not np.array_equal(out[_cabi.VARIANT_FARFIELD32][0], out[_cabi.VARIANT_FARFIELD][0])   # (it IS another kernel)
+        np.testing.assert_array_equal(out[_cabi.VARIANT_FARFIELD32][0][:7], out[_cabi.VARIANT_FARFIELD32][2])   # geometry-independent
+        np.testing.assert_array_equal(out[_cabi.VARIANT_FARFIELD32][3], out[_cabi.VARIANT_FARFIELD][3])         # residual rows: fp64
+        # the imaginary channel of such a context runs the fp64 far-field kernel
+        ev.set_variant(_cabi.VARIANT_FARFIELD)
+        f_im = ev.objective_batch(X[:64], fit_im=True)
+        ev.set_variant(_cabi.VARIANT_FARFIELD32)
+        np.testing.assert_array_equal(ev.objective_batch(X[:64], fit_im=True), f_im)
+    spf = synth.make_spectrum(16384, 12, seed=3)
+    data = synth.SynthData(spf["w"], spf["u"], spf["v"], spf["peaks"])
+    opts = {"seed": 11, "maxiter": 60, "swarmsize": 128}
+    a = nmrfit_amd.fit(data, list(spf["lower"]), list(spf["upper"]), summary=False, options=dict(opts, variant="farfield"))
+    b = nmrfit_amd.fit(data, list(spf["lower"]), list(spf["upper"]), summary=False, options=dict(opts, variant="farfield32"))
+    assert b.error == pytest.approx(a.error, rel=1e-6)

@@ -16,7 +16,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nmrfit_amd", "csrc")
-VARIANTS = {0: "DEFAULT", 1: "BASELINE", 2: "NOSKIP", 3: "SINGLE", 4: "QUAD", 5: "STAGED", 6: "FARFIELD", 7: "NOREC"}
+VARIANTS = {0: "DEFAULT", 1: "BASELINE", 2: "NOSKIP", 3: "SINGLE", 4: "QUAD", 5: "STAGED", 6: "FARFIELD", 7: "NOREC", 8: "FARFIELD32"}
 
 
 def demangle(names):
@@ -27,7 +27,7 @@ def demangle(names):
 def resources(extra):
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
-        for src in ("objective_default.hip", "objective_farfield.hip", "objective_norec.hip", "objective_batch.hip", "objective.hip", "pso.hip", "batch.hip"):
+        for src in ("objective_default.hip", "objective_farfield.hip", "objective_farfield32.hip", "objective_norec.hip", "objective_batch.hip", "objective.hip", "pso.hip", "batch.hip"):
             if not os.path.exists(os.path.join(CSRC, src)):
                 continue
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
@@ -66,7 +66,7 @@ def main():
             v, wr, fi = int(m.group(1)), m.group(2) == "true", int(m.group(3))
             label = "objective_kernel<%s,%s,fit_im=%d%s>" % (VARIANTS.get(v, v), "residual" if wr else "objective", fi,
                                                             ",8 waves" if m.group(4) == "8" else "")
-            selectable = v in (0, 6, 7)
+            selectable = v in (0, 6, 7, 8)
         mb = re.match(r"objective_batch_kernel<(\d+), (\d+), (true|false)>", name)
         if mb:
             label = "objective_batch_kernel<%s,%s>" % (VARIANTS.get(int(mb.group(1)), mb.group(1)),

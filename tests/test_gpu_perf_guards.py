@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from nmrfit_amd import _cabi
-from test_gpu_parity import adversarial_case
+from tests.test_gpu_parity import adversarial_case
 
 pytestmark = pytest.mark.gpu
 

@@ -67,8 +67,8 @@ SIMDS = 1024                   # 256 CUs x 4 SIMDs
 PEAK_CLOCK_MHZ = 2400.0        # MI355X_MICROARCH.md
 LAUNCHER_GRACE_S = 15.0        # self-launcher: how much later than the ranks' own watchdogs its deadline falls
 FP64_ISSUE_CYCLES = 4.0        # one wave64 fp64 VALU instruction occupies a SIMD's issue port for 4 cycles
-PMC_SUMMARIES = [os.path.join("profiles", r, "bench_c3_pmc_summary.json") for r in ("r04", "r03", "r02", "r01")]
-FARFIELD_PMC_SUMMARIES = [os.path.join("profiles", r, "farfield_c3_pmc_summary.json") for r in ("r04", "r03")]
+PMC_SUMMARIES = [os.path.join("profiles", r, "bench_c3_pmc_summary.json") for r in ("r05", "r04", "r03", "r02", "r01")]
+FARFIELD_PMC_SUMMARIES = [os.path.join("profiles", r, "farfield_c3_pmc_summary.json") for r in ("r05", "r04", "r03")]
 
 
 def parse():

@@ -17,7 +17,10 @@ def main():
     st = sorted(glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if st:
         rows = list(csv.DictReader(open(st[-1])))     # newest run of this tag
-        out["kernel_stats"] = [{"name": r["Name"].split("(")[0][-60:], "calls": int(r["Calls"]),
+        def short(n):      # "void nmrfit::(anonymous namespace)::objective_kernel<0, false, 0, 4>(double const*, ...)"
+            n = n.replace("nmrfit::(anonymous namespace)::", "").replace("void ", "")
+            return n.split("(")[0][-60:]
+        out["kernel_stats"] = [{"name": short(r["Name"]), "calls": int(r["Calls"]),
                                 "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
                                 "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])} for r in rows[:8]]
     pmc = {}

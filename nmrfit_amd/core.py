@@ -69,7 +69,7 @@ def _result_record(f):
 def _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, channel=None, local=None):
     """Jobs r, r + world, ... on this rank's GPU; every rank returns every result (the other ranks' as FitUtility
     objects holding ``params`` / ``error`` / ``seed``; their ``weights`` are recomputed on demand only by ``fit``)."""
-    import pickle
+    import json
     from . import rendezvous
     mine = list(range(rank, len(jobs), world))
     if local is None:
@@ -87,7 +87,8 @@ def _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, channel=None, l
     if own:
         channel = rendezvous.Channel()
     try:
-        parts = channel.all_gather(pickle.dumps([(i, _result_record(f)) for i, f in zip(mine, done)]))
+        # (JSON, not pickle: what arrives from another rank is data, never code; repr round-trips a float64 exactly)
+        parts = channel.all_gather(json.dumps([[i, _result_record(f)] for i, f in zip(mine, done)]).encode())
     finally:
         if own:
             channel.close()
@@ -97,7 +98,7 @@ def _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, channel=None, l
     for r, blob in enumerate(parts):
         if r == rank:
             continue
-        for i, rec in pickle.loads(blob):
+        for i, rec in json.loads(blob.decode()):
             job = jobs[i]
             args = {k: v for k, v in dict(kwargs, **job).items() if k not in ("data", "lower", "upper")}
             f = utils.FitUtility(job["data"], job["lower"], job["upper"], **args)

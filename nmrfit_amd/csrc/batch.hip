@@ -514,9 +514,12 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
     // the geometry decides where the row copies sit in LDS: stamp the chosen one's offset into the fused tables
     b->mode = b->geom_ok[0] ? 0 : 1;
     {
-        // many particles: the wave form (one prologue per particle instead of one per workgroup of idle waves).
-        // Measured crossover on MI355X: see DESIGN.md 4.5; NMRFIT_BATCH_WAVE_MIN overrides (tuning knob)
-        int64_t wave_min = 1536;
+        // many particles: the wave form (one prologue per particle instead of one per workgroup of idle waves).  Measured
+        // on 204 x 4096 x 6 fits (profiles/r05/batch_fits_small_k.txt): the workgroup form costs ~9 us per fit and
+        // generation whatever K (two fits: 20.1 us), the wave form 25 us per generation up to a wave per SIMD and ~9 us
+        // per further wave per SIMD (three fits: 25.4, eight: 32.1) -- they cross between two and three fits.  Longer
+        // grids have longer waves: there the wave form waits until every SIMD has one.  NMRFIT_BATCH_WAVE_MIN overrides.
+        int64_t wave_min = (b->n_chunks <= 16) ? 512 : 1024;
         if (const char *e = getenv("NMRFIT_BATCH_WAVE_MIN")) wave_min = atoll(e);
         if (b->geom_ok[1] && (int64_t)K * S >= wave_min) b->mode = 1;
     }

@@ -25,7 +25,7 @@
 #include <new>
 #include <vector>
 
-struct nmrfit_batch {
+struct BatchPart {
     int device = -1;
     int compute_units = 0;
     hipStream_t stream = nullptr;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(1024) void batch_tail_kernel(const BatchFit *__rest
     for (int64_t d = threadIdx.x; d < D; d += blockDim.x) bestx[boff[blockIdx.x] + d] = best[2 + D + d];
 }
 
-int bind_batch(const nmrfit_batch *b)
+int bind_batch(const BatchPart *b)
 {
     if (!b) {
         set_error("null batch handle");
@@ -187,9 +187,9 @@ int bind_batch(const nmrfit_batch *b)
     return NMRFIT_OK;
 }
 
-const BatchFit *table(const nmrfit_batch *b, int t) { return b->d_tables + (size_t)t * (size_t)b->K; }
+const BatchFit *table(const BatchPart *b, int t) { return b->d_tables + (size_t)t * (size_t)b->K; }
 
-int launch_tail(nmrfit_batch *b, int phases, int is_init)
+int launch_tail(BatchPart *b, int phases, int is_init)
 {
     // the table of the CURRENT phases: x_in / p are the buffers the last launch wrote, best / flags the current block
     const BatchFit *t = table(b, b->xp + 2 * b->b);
@@ -200,7 +200,7 @@ int launch_tail(nmrfit_batch *b, int phases, int is_init)
 }
 
 // fold the generation whose personal bests are still waiting, in a launch of its own (pso.hip, flush_fold)
-int flush_fold(nmrfit_batch *b)
+int flush_fold(BatchPart *b)
 {
     if (!b->fold_pending) return NMRFIT_OK;
     const int rc = launch_tail(b, kBatchArgmin | kBatchApply, 0);
@@ -209,7 +209,7 @@ int flush_fold(nmrfit_batch *b)
 }
 
 // the two launch geometries of a batch (objective.hip's launch_objective picks among the same forms for a lone swarm)
-void plan_geometry(nmrfit_batch *b)
+void plan_geometry(BatchPart *b)
 {
     const int64_t N = b->N;
     const int64_t n_chunks = (N + kChunk - 1) / kChunk;
@@ -280,7 +280,7 @@ void plan_geometry(nmrfit_batch *b)
     }
 }
 
-unsigned xrow_offset(const nmrfit_batch *b, int m)
+unsigned xrow_offset(const BatchPart *b, int m)
 {
     const BatchLaunch &g = b->geom[m];
     const int64_t Dmax = 4 + 3 * (int64_t)b->Pmax;
@@ -315,11 +315,13 @@ struct Carver {
 
 }  // namespace
 
-extern "C" {
+// ---- one part of a batch: a set of fits advanced by one launch per generation on one stream ----------------
 
-int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
+static int part_destroy(BatchPart *b);
+
+static int part_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
                         const double *weights, const int32_t *P, const double *lower, const double *upper,
-                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, nmrfit_batch **out)
+                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, BatchPart **out)
 {
     if (!out) {
         set_error("null out pointer");
@@ -356,7 +358,7 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
         set_error(std::string("device is ") + prop.arch + ", this library is built for gfx950 only");
         return NMRFIT_E_NO_DEVICE;
     }
-    nmrfit_batch *b = new (std::nothrow) nmrfit_batch();
+    BatchPart *b = new (std::nothrow) BatchPart();
     if (!b) {
         set_error("out of host memory");
         return NMRFIT_E_INVALID;
@@ -393,7 +395,7 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
         hipError_t _e = (call);                                        \
         if (_e != hipSuccess) {                                        \
             int _rc = hip_fail(_e, #call, __FILE__, __LINE__);         \
-            nmrfit_batch_destroy(b);                                   \
+            part_destroy(b);                                   \
             return _rc;                                                \
         }                                                              \
     } while (0)
@@ -401,7 +403,7 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
     plan_geometry(b);
     if (!b->geom_ok[0] && !b->geom_ok[1]) {
         set_error("nmrfit_batch_create: too many peaks for the kernel's LDS records in a batched launch");
-        nmrfit_batch_destroy(b);
+        part_destroy(b);
         return NMRFIT_E_UNSUPPORTED;
     }
     // ---- one allocation: per fit the four padded grid arrays + chunk table + swarm state; then the summary, the best
@@ -558,7 +560,7 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
     return NMRFIT_OK;
 }
 
-int nmrfit_batch_destroy(nmrfit_batch *b)
+static int part_destroy(BatchPart *b)
 {
     if (!b) return NMRFIT_OK;
     (void)hipSetDevice(b->device);
@@ -570,7 +572,7 @@ int nmrfit_batch_destroy(nmrfit_batch *b)
 }
 
 // generation 0: positions, velocities, evaluation, personal bests, (g, fg) <- the best of them
-static int batch_init(nmrfit_batch *b)
+static int batch_init(BatchPart *b)
 {
     b->xp = b->b = 0;
     b->fold_pending = false;
@@ -588,7 +590,7 @@ static int batch_init(nmrfit_batch *b)
 }
 
 // one generation of every swarm that has not stopped: ONE launch
-static int batch_generation(nmrfit_batch *b)
+static int batch_generation(BatchPart *b)
 {
     BatchLaunch g = b->geom[b->mode];
     g.fits = table(b, b->xp + 2 * b->b + (b->fold_pending ? 4 : 0));
@@ -601,7 +603,7 @@ static int batch_generation(nmrfit_batch *b)
     return NMRFIT_OK;
 }
 
-int nmrfit_batch_step(nmrfit_batch *b)
+static int part_step(BatchPart *b)
 {
     int rc = bind_batch(b);
     if (rc != NMRFIT_OK) return rc;
@@ -609,7 +611,7 @@ int nmrfit_batch_step(nmrfit_batch *b)
     return batch_generation(b);
 }
 
-static int read_summary(nmrfit_batch *b, std::vector<double> &s)
+static int read_summary(BatchPart *b, std::vector<double> &s)
 {
     int rc = flush_fold(b);
     if (rc != NMRFIT_OK) return rc;
@@ -619,31 +621,7 @@ static int read_summary(nmrfit_batch *b, std::vector<double> &s)
     return NMRFIT_OK;
 }
 
-int nmrfit_batch_run(nmrfit_batch *b, int64_t maxiter, int32_t check_every)
-{
-    int rc = bind_batch(b);
-    if (rc != NMRFIT_OK) return rc;
-    if (maxiter < 0 || check_every < 1) {
-        set_error("nmrfit_batch_run: maxiter must be >= 0 and check_every >= 1");
-        return NMRFIT_E_INVALID;
-    }
-    if (!b->initialized && (rc = batch_init(b)) != NMRFIT_OK) return rc;
-    // every fit runs the generations a lone nmrfit_pso_run would: a stopped swarm's workgroups return at once, so the
-    // others' generations do not touch it; the loop ends when every swarm has stopped (polled every check_every)
-    std::vector<double> s;
-    for (int64_t it = 1; it <= maxiter; ++it) {
-        if ((rc = batch_generation(b)) != NMRFIT_OK) return rc;
-        if (it % check_every == 0 || it == maxiter) {
-            if ((rc = read_summary(b, s)) != NMRFIT_OK) return rc;
-            bool all = true;
-            for (int32_t k = 0; k < b->K; ++k) all = all && s[(size_t)k * 4 + 1] != 0.0;
-            if (all) break;
-        }
-    }
-    return NMRFIT_OK;
-}
-
-int nmrfit_batch_status(nmrfit_batch *b, int64_t *iteration, int32_t *stop_code, double *fg)
+static int part_status(BatchPart *b, int64_t *iteration, int32_t *stop_code, double *fg)
 {
     int rc = bind_batch(b);
     if (rc != NMRFIT_OK) return rc;
@@ -661,7 +639,7 @@ int nmrfit_batch_status(nmrfit_batch *b, int64_t *iteration, int32_t *stop_code,
     return NMRFIT_OK;
 }
 
-int nmrfit_batch_best(nmrfit_batch *b, double *x_best, double *f_best)
+static int part_best(BatchPart *b, double *x_best, double *f_best)
 {
     int rc = bind_batch(b);
     if (rc != NMRFIT_OK) return rc;
@@ -680,9 +658,8 @@ int nmrfit_batch_best(nmrfit_batch *b, double *x_best, double *f_best)
     return NMRFIT_OK;
 }
 
-/* ---- diagnostics (include/nmrfit_amd_diag.h) ---- */
 
-int nmrfit_batch_set_geometry(nmrfit_batch *b, int mode)
+static int part_set_geometry(BatchPart *b, int mode)
 {
     int rc = bind_batch(b);
     if (rc != NMRFIT_OK) return rc;
@@ -702,7 +679,7 @@ int nmrfit_batch_set_geometry(nmrfit_batch *b, int mode)
     return NMRFIT_OK;
 }
 
-int nmrfit_batch_geometry(const nmrfit_batch *b, int32_t *mode, int32_t *waves_per_workgroup, int32_t *segments, int64_t *workgroups)
+static int part_geometry(const BatchPart *b, int32_t *mode, int32_t *waves_per_workgroup, int32_t *segments, int64_t *workgroups)
 {
     if (!b) {
         set_error("null batch handle");
@@ -716,7 +693,7 @@ int nmrfit_batch_geometry(const nmrfit_batch *b, int32_t *mode, int32_t *waves_p
     return NMRFIT_OK;
 }
 
-int nmrfit_batch_synchronize(nmrfit_batch *b)
+static int part_synchronize(BatchPart *b)
 {
     int rc = bind_batch(b);
     if (rc != NMRFIT_OK) return rc;
@@ -725,7 +702,7 @@ int nmrfit_batch_synchronize(nmrfit_batch *b)
 }
 
 // swarm state of fit k (any pointer may be NULL): x, v, p are S x D_k; fx, fp are S
-int nmrfit_batch_get_state(nmrfit_batch *b, int32_t k, double *x, double *v, double *p, double *fx, double *fp)
+static int part_get_state(BatchPart *b, int32_t k, double *x, double *v, double *p, double *fx, double *fp)
 {
     int rc = bind_batch(b);
     if (rc != NMRFIT_OK) return rc;
@@ -747,4 +724,205 @@ int nmrfit_batch_get_state(nmrfit_batch *b, int32_t k, double *x, double *v, dou
     return NMRFIT_OK;
 }
 
+
+// ---- the batch: its fits divided over one or two parts, each with a stream of its own ---------------------------------
+// A generation of a part is a few lock-step rounds of short waves: its last round drains with the SIMDs
+// half empty, its first starts with every wave in the latency-bound prologue.  Two parts on two streams fill each
+// other's gaps -- the launches of one generation of part A and part B are independent -- for 5-11 % more fits per
+// second (K = 40: 216 -> 241, K = 200: 238 -> 251; profiles/r05/batch_two_streams.txt).  From 16 fits on (each part
+// then still takes the wave = particle geometry); NMRFIT_BATCH_STREAMS=1 turns it off (A/B knob).
+struct nmrfit_batch {
+    std::vector<BatchPart *> parts;
+    std::vector<int32_t> first;      // first fit of each part (+ K at the end)
+    std::vector<int64_t> boff;       // offset of each fit's row in the concatenated bounds / best arrays (+ total)
+    int32_t K = 0;
+    int device = -1;
+};
+
+namespace {
+
+int check_batch_handle(const nmrfit_batch *b)
+{
+    if (!b || b->parts.empty()) {
+        set_error("null batch handle");
+        return NMRFIT_E_INVALID;
+    }
+    NMRFIT_HIP(hipSetDevice(b->device));
+    return NMRFIT_OK;
+}
+
+static int part_of(const nmrfit_batch *b, int32_t k)
+{
+    int p = 0;
+    while (p + 1 < (int)b->parts.size() && k >= b->first[(size_t)p + 1]) ++p;
+    return p;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)   // the C-ABI: the only symbols the library exports (build.sh: -fvisibility=hidden)
+extern "C" {
+
+int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
+                        const double *weights, const int32_t *P, const double *lower, const double *upper,
+                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, nmrfit_batch **out)
+{
+    if (!out) {
+        set_error("null out pointer");
+        return NMRFIT_E_INVALID;
+    }
+    *out = nullptr;
+    if (K <= 0 || N <= 0 || swarmsize <= 0 || !w || !u || !v || !weights || !P || !lower || !upper || !params) {
+        set_error("nmrfit_batch_create: K, N, swarmsize must be > 0 and every array non-null");
+        return NMRFIT_E_INVALID;
+    }
+    nmrfit_batch *b = new (std::nothrow) nmrfit_batch();
+    if (!b) {
+        set_error("out of host memory");
+        return NMRFIT_E_INVALID;
+    }
+    b->K = K;
+    b->device = device;
+    b->boff.resize((size_t)K + 1);
+    b->boff[0] = 0;
+    for (int32_t k = 0; k < K; ++k) b->boff[(size_t)k + 1] = b->boff[(size_t)k] + 4 + 3 * (int64_t)std::max(P[k], 0);
+    int nparts = (K >= 16) ? 2 : 1;
+    if (const char *e = getenv("NMRFIT_BATCH_STREAMS")) nparts = std::max(1, std::min(atoi(e), (int)std::min<int32_t>(K, 8)));
+    for (int p = 0; p <= nparts; ++p) b->first.push_back((int32_t)((int64_t)K * p / nparts));
+    for (int p = 0; p < nparts; ++p) {
+        const int32_t f0 = b->first[(size_t)p], f1 = b->first[(size_t)p + 1];
+        BatchPart *part = nullptr;
+        const int rc = part_create(device, f1 - f0, N, w + (size_t)f0 * (size_t)N, u + (size_t)f0 * (size_t)N,
+                                   v + (size_t)f0 * (size_t)N, weights + (size_t)f0 * (size_t)N, P + f0,
+                                   lower + b->boff[(size_t)f0], upper + b->boff[(size_t)f0], swarmsize, params + f0, variant,
+                                   &part);
+        if (rc != NMRFIT_OK) {
+            nmrfit_batch_destroy(b);
+            return rc;
+        }
+        b->parts.push_back(part);
+    }
+    *out = b;
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_destroy(nmrfit_batch *b)
+{
+    if (!b) return NMRFIT_OK;
+    for (BatchPart *p : b->parts) (void)part_destroy(p);
+    delete b;
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_step(nmrfit_batch *b)
+{
+    int rc = check_batch_handle(b);
+    for (size_t p = 0; rc == NMRFIT_OK && p < b->parts.size(); ++p) rc = part_step(b->parts[p]);
+    return rc;
+}
+
+int nmrfit_batch_run(nmrfit_batch *b, int64_t maxiter, int32_t check_every)
+{
+    int rc = check_batch_handle(b);
+    if (rc != NMRFIT_OK) return rc;
+    if (maxiter < 0 || check_every < 1) {
+        set_error("nmrfit_batch_run: maxiter must be >= 0 and check_every >= 1");
+        return NMRFIT_E_INVALID;
+    }
+    for (BatchPart *p : b->parts)
+        if (!p->initialized && (rc = batch_init(p)) != NMRFIT_OK) return rc;
+    // every fit runs the generations a lone nmrfit_pso_run would: a stopped swarm's waves return at once, so the others'
+    // generations do not touch it; a part leaves the loop when every one of its swarms has stopped (polled every
+    // check_every).  The parts' launches are interleaved on their own streams.
+    std::vector<char> done(b->parts.size(), 0);
+    std::vector<double> s;
+    for (int64_t it = 1; it <= maxiter; ++it) {
+        bool any = false;
+        for (size_t p = 0; p < b->parts.size(); ++p) {
+            if (done[p]) continue;
+            any = true;
+            if ((rc = batch_generation(b->parts[p])) != NMRFIT_OK) return rc;
+        }
+        if (!any) break;
+        if (it % check_every == 0 || it == maxiter) {
+            for (size_t p = 0; p < b->parts.size(); ++p) {
+                if (done[p]) continue;
+                if ((rc = read_summary(b->parts[p], s)) != NMRFIT_OK) return rc;
+                bool all = true;
+                for (int32_t k = 0; k < b->parts[p]->K; ++k) all = all && s[(size_t)k * 4 + 1] != 0.0;
+                done[p] = all ? 1 : 0;
+            }
+        }
+    }
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_status(nmrfit_batch *b, int64_t *iteration, int32_t *stop_code, double *fg)
+{
+    int rc = check_batch_handle(b);
+    for (size_t p = 0; rc == NMRFIT_OK && p < b->parts.size(); ++p) {
+        const int32_t f0 = b->first[p];
+        rc = part_status(b->parts[p], iteration ? iteration + f0 : nullptr, stop_code ? stop_code + f0 : nullptr,
+                         fg ? fg + f0 : nullptr);
+    }
+    return rc;
+}
+
+int nmrfit_batch_best(nmrfit_batch *b, double *x_best, double *f_best)
+{
+    int rc = check_batch_handle(b);
+    for (size_t p = 0; rc == NMRFIT_OK && p < b->parts.size(); ++p) {
+        const int32_t f0 = b->first[p];
+        rc = part_best(b->parts[p], x_best ? x_best + b->boff[(size_t)f0] : nullptr, f_best ? f_best + f0 : nullptr);
+    }
+    return rc;
+}
+
+/* ---- diagnostics (include/nmrfit_amd_diag.h) ---- */
+
+int nmrfit_batch_set_geometry(nmrfit_batch *b, int mode)
+{
+    int rc = check_batch_handle(b);
+    for (size_t p = 0; rc == NMRFIT_OK && p < b->parts.size(); ++p) rc = part_set_geometry(b->parts[p], mode);
+    return rc;
+}
+
+int nmrfit_batch_geometry(const nmrfit_batch *b, int32_t *mode, int32_t *waves_per_workgroup, int32_t *segments, int64_t *workgroups)
+{
+    if (!b || b->parts.empty()) {
+        set_error("null batch handle");
+        return NMRFIT_E_INVALID;
+    }
+    int64_t total = 0;
+    for (size_t p = 0; p < b->parts.size(); ++p) {   // (mode, waves and segments of the first part; workgroups of all)
+        int64_t n = 0;
+        const int rc = part_geometry(b->parts[p], p == 0 ? mode : nullptr, p == 0 ? waves_per_workgroup : nullptr,
+                                     p == 0 ? segments : nullptr, &n);
+        if (rc != NMRFIT_OK) return rc;
+        total += n;
+    }
+    if (workgroups) *workgroups = total;
+    return NMRFIT_OK;
+}
+
+int nmrfit_batch_synchronize(nmrfit_batch *b)
+{
+    int rc = check_batch_handle(b);
+    for (size_t p = 0; rc == NMRFIT_OK && p < b->parts.size(); ++p) rc = part_synchronize(b->parts[p]);
+    return rc;
+}
+
+int nmrfit_batch_get_state(nmrfit_batch *b, int32_t k, double *x, double *v, double *p, double *fx, double *fp)
+{
+    int rc = check_batch_handle(b);
+    if (rc != NMRFIT_OK) return rc;
+    if (k < 0 || k >= b->K) {
+        set_error("nmrfit_batch_get_state: fit index out of range");
+        return NMRFIT_E_INVALID;
+    }
+    const int q = part_of(b, k);
+    return part_get_state(b->parts[(size_t)q], k - b->first[(size_t)q], x, v, p, fx, fp);
+}
+
 }  // extern "C"
+#pragma GCC visibility pop

@@ -27,7 +27,7 @@ for arg in "$@"; do
 done
 OBJ="$(mktemp -d "${TMPDIR:-/tmp}/nmrfit_build.XXXXXX")"
 trap 'rm -rf "$OBJ"' EXIT
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-fast-math -I"$ROOT/include" -I"$HERE")
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=on -fno-fast-math -I"$ROOT/include" -I"$HERE")
 pids=()
 for u in "${UNITS[@]}"; do
     [ -f "$HERE/$u.hip" ] || continue

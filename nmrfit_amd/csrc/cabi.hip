@@ -167,6 +167,7 @@ static int check_batch(const nmrfit_ctx *ctx, int64_t S, int32_t P, const void *
 
 using namespace nmrfit;
 
+#pragma GCC visibility push(default)   // the C-ABI: the only symbols the library exports (build.sh: -fvisibility=hidden)
 extern "C" {
 
 int nmrfit_abi_version(void) { return NMRFIT_ABI_VERSION; }
@@ -754,3 +755,4 @@ int nmrfit_diag_read_stamps(nmrfit_ctx *ctx, unsigned long long *out, int64_t wo
 #endif
 
 }  // extern "C"
+#pragma GCC visibility pop

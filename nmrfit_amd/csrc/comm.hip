@@ -166,6 +166,7 @@ int comm_all_gather(nmrfit_comm *c, hipStream_t stream, const double *d_send, in
 
 using namespace nmrfit;
 
+#pragma GCC visibility push(default)   // the C-ABI: the only symbols the library exports (build.sh: -fvisibility=hidden)
 extern "C" {
 
 int nmrfit_comm_available(void)
@@ -335,3 +336,4 @@ int nmrfit_comm_barrier(nmrfit_comm *c)
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

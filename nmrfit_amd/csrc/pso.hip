@@ -618,6 +618,7 @@ int evaluate_and_select(nmrfit_pso *pso, bool advance, int more = 0, int is_init
 
 using namespace nmrfit;
 
+#pragma GCC visibility push(default)   // the C-ABI: the only symbols the library exports (build.sh: -fvisibility=hidden)
 extern "C" {
 
 int nmrfit_pso_create(nmrfit_ctx *ctx, int64_t S_local, int64_t S_global, int64_t offset, int32_t P,
@@ -1002,3 +1003,4 @@ int nmrfit_pso_get_state(nmrfit_pso *pso, double *x, double *v, double *p, doubl
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

@@ -2,8 +2,9 @@
 """A/B timing of several builds of libnmrfit_amd in ONE process on ONE device, interleaved
 rounds, median and min reported (perf deltas from separate runs or boxes are not comparable:
 devices differ by several per cent).  Usage:
-    NMRFIT_LIBNAME=libab_i2.so nmrfit_amd/csrc/build.sh -DNMRFIT_INTERLEAVE=2
-    python tools/ab.py nmrfit_amd/lib/libnmrfit_amd.so nmrfit_amd/lib/libab_i2.so [--variant 0] [--workload C3]
+    NMRFIT_LIBNAME=libab_w3.so nmrfit_amd/csrc/build.sh -DNMRFIT_BATCH_MIN_WAVES=3      (any -D knob the sources still carry;
+                                                     the round 1-4 tuning knobs became constants in round 5: DESIGN.md 7a)
+    python tools/ab.py nmrfit_amd/lib/libnmrfit_amd.so nmrfit_amd/lib/libab_w3.so [--variant 0] [--workload C3]
 A spec may carry its own variant after a colon (same build, two kernel variants):
     python tools/ab.py nmrfit_amd/lib/libnmrfit_amd.so:0 nmrfit_amd/lib/libnmrfit_amd.so:7
 Also prints the largest relative difference of f from the first spec's values.

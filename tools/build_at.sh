@@ -7,9 +7,10 @@ C="$1"; shift
 T="$(mktemp -d)"
 mkdir -p "$T/csrc" "$T/include"
 for f in $(git -C "$ROOT" ls-tree --name-only "$C" nmrfit_amd/csrc/); do git -C "$ROOT" show "$C:$f" > "$T/csrc/$(basename "$f")"; done
-git -C "$ROOT" show "$C:include/nmrfit_amd.h" > "$T/include/nmrfit_amd.h"
+for h in $(git -C "$ROOT" ls-tree --name-only "$C" include/); do git -C "$ROOT" show "$C:$h" > "$T/include/$(basename "$h")"; done
+# (every translation unit the commit had: one objective.hip up to round 4, one per kernel variant since round 5)
+SRCS=$(ls "$T"/csrc/*.hip | grep -v objective_ab.hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=on -fno-fast-math \
-    -I"$T/include" -I"$T/csrc" "$T/csrc/objective.hip" "$T/csrc/pso.hip" "$T/csrc/cabi.hip" "$T/csrc/comm.hip" -ldl \
-    -o "$ROOT/nmrfit_amd/lib/libab_$C.so" "$@"
+    -I"$T/include" -I"$T/csrc" $SRCS -ldl -o "$ROOT/nmrfit_amd/lib/libab_$C.so" "$@"
 rm -rf "$T"
 echo "built nmrfit_amd/lib/libab_$C.so"

@@ -178,6 +178,37 @@ def test_fit_many_batches_what_it_can_and_equals_the_plain_loop(capsys):
         np.testing.assert_array_equal(a.params, b.params)
 
 
+def test_batch_edge_shapes_two_parts_tiny_grid_no_peaks():
+    """17 fits (two parts on two streams: 8 + 9), a 600-point grid (two chunks: no workgroup = particle form exists),
+    three particles per swarm, peak counts 0, 1, 2, ...: still the lone swarms' trajectories, bit for bit."""
+    K, S, N = 17, 3, 600
+    problems = [synth.make_spectrum(N, k % 4, seed=90 + k) for k in range(K)]
+    seeds = [2 ** 63 + 11 * k for k in range(K)]
+    kw = dict(minstep=-1.0, minfunc=-1.0)
+    evs, sws = _lone_swarms(problems, S, seeds, "default", **kw)
+    try:
+        with _batch(problems, S, seeds, **kw) as fb:
+            assert fb.geometry()["mode"] == "wave"
+            with pytest.raises(_cabi.NmrfitError) as ei:
+                fb.set_geometry("workgroup")
+            assert ei.value.code == _cabi.E_UNSUPPORTED
+            fb.run(12, 5)
+            for sw in sws:
+                sw.run(12, 5)
+            st, best = fb.status(), fb.best()
+            for k, sw in enumerate(sws):
+                a, b = fb.state(k), sw.state()
+                for name in ("x", "v", "p", "fp", "fx"):
+                    np.testing.assert_array_equal(a[name], b[name], err_msg="fit %d %s" % (k, name))
+                ls = sw.status()
+                assert (st[k]["iteration"], st[k]["stop"], st[k]["fg"]) == (ls["iteration"], ls["stop"], ls["fg"]), k
+                xb, fbest = sw.best()
+                np.testing.assert_array_equal(best[k][0], xb)
+                assert best[k][1] == fbest
+    finally:
+        _close(evs, sws)
+
+
 def test_batch_argument_validation():
     sp = synth.make_spectrum(4096, 3, seed=1)
     spec = (sp["w"], sp["u"], sp["v"], sp["weights"])

@@ -125,6 +125,26 @@ def test_comm_argument_validation_needs_no_gpu():
     assert L.nmrfit_prof_enable(None, 4) == _cabi.E_INVALID
 
 
+def test_batch_argument_validation_needs_no_gpu():
+    """nmrfit_batch_*: argument errors are reported before anything touches a device; without a GPU the creation itself
+    fails loudly (NMRFIT_E_NO_DEVICE) -- there is no CPU path behind nmrfit_amd.fit_many either."""
+    L = _cabi.lib()
+    out = ctypes.c_void_p()
+    assert L.nmrfit_batch_create(0, 0, 64, None, None, None, None, None, None, None, 8, None, 0, ctypes.byref(out)) == _cabi.E_INVALID
+    assert b"K, N, swarmsize" in L.nmrfit_last_error()
+    assert L.nmrfit_batch_destroy(None) == _cabi.OK
+    assert L.nmrfit_batch_run(None, 1, 1) == _cabi.E_INVALID
+    assert L.nmrfit_batch_status(None, None, None, None) == _cabi.E_INVALID
+    assert L.nmrfit_batch_step(None) == _cabi.E_INVALID
+    if _cabi.device_count() == 0:
+        from nmrfit_amd import synth
+        from nmrfit_amd.batch import FitBatch
+        sp = synth.make_spectrum(1024, 2, seed=1)
+        with pytest.raises(_cabi.NmrfitError) as ei:
+            FitBatch([(sp["w"], sp["u"], sp["v"], sp["weights"])] * 2, [sp["lower"]] * 2, [sp["upper"]] * 2, swarmsize=8, seeds=[1, 2])
+        assert ei.value.code == _cabi.E_NO_DEVICE
+
+
 def test_variant_names():
     import pytest
     assert _cabi.variant_id("farfield") == _cabi.VARIANT_FARFIELD == 6

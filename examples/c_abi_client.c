@@ -226,7 +226,7 @@ int main(int argc, char **argv)
             prmK[k].seed = prm.seed + (uint64_t)k;
         }
         nmrfit_batch *batch = NULL;
-        CHECK(nmrfit_batch_create(0, K, N, wK, uK, vK, wtK, PK, loK, hiK, 204, prmK, NMRFIT_VARIANT_DEFAULT, &batch));
+        CHECK(nmrfit_batch_create(0, K, N, wK, uK, vK, wtK, PK, loK, hiK, 204, prmK, NMRFIT_VARIANT_DEFAULT, NMRFIT_FIT_IM_OFF, &batch));
         CHECK(nmrfit_batch_run(batch, 1000, 100));
         CHECK(nmrfit_batch_status(batch, itK, stopK, NULL));
         CHECK(nmrfit_batch_best(batch, xK, fK));

@@ -231,14 +231,16 @@ int nmrfit_pso_step(nmrfit_pso *pso);
  *   w, u, v, weights   K x N, row-major (fit k's arrays at offset k*N)
  *   P                  K peak counts; lower / upper: the K boxes concatenated, sum_k (4 + 3 P[k]) doubles each
  *   params             K records (omega, phip, phig, minstep, minfunc, seed)
- *   variant            NMRFIT_VARIANT_DEFAULT or NMRFIT_VARIANT_FARFIELD for the whole batch (fit_im = 0)
+ *   variant, fit_im    NMRFIT_VARIANT_DEFAULT or NMRFIT_VARIANT_FARFIELD and NMRFIT_FIT_IM_* for the whole batch (the
+ *                      all-peak imaginary model, NMRFIT_FIT_IM_SUM, with DEFAULT: the kernels nmrfit_amd.fit selects)
  * nmrfit_batch_run: generation 0 (if needed) + up to maxiter generations, polling the K stop flags every
  * `check_every`; returns when every fit has stopped or maxiter is reached.  nmrfit_batch_status / _best: K values
  * each (any pointer may be NULL); x_best receives the K best positions concatenated like `lower`. */
 typedef struct nmrfit_batch nmrfit_batch;
 int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
                         const double *weights, const int32_t *P, const double *lower, const double *upper,
-                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, nmrfit_batch **out);
+                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im,
+                        nmrfit_batch **out);
 int nmrfit_batch_destroy(nmrfit_batch *batch);
 int nmrfit_batch_run(nmrfit_batch *batch, int64_t maxiter, int32_t check_every);
 int nmrfit_batch_status(nmrfit_batch *batch, int64_t *iteration, int32_t *stop_code, double *fg);

@@ -12,7 +12,7 @@ import ctypes
 
 import numpy as np
 
-from . import _cabi, pso
+from . import _cabi, equations, pso
 
 
 class FitBatch:
@@ -25,11 +25,13 @@ class FitBatch:
     seeds : K integers (the swarm's random stream, like options['seed'] of ``fit``)
     omega, phip, phig, minstep, minfunc : scalars or length-K sequences
     variant : "default" or "farfield" (what ``fit`` would select for these shapes)
+    fit_im : False, True (the reference's imaginary term) or "sum" (every peak; "default" kernel), for the whole batch
     """
 
     def __init__(self, spectra, lowers, uppers, swarmsize=pso.DEFAULTS["swarmsize"], seeds=None,
                  omega=pso.DEFAULTS["omega"], phip=pso.DEFAULTS["phip"], phig=pso.DEFAULTS["phig"],
-                 minstep=pso.DEFAULTS["minstep"], minfunc=pso.DEFAULTS["minfunc"], variant="default", device=0):
+                 minstep=pso.DEFAULTS["minstep"], minfunc=pso.DEFAULTS["minfunc"], variant="default", fit_im=False,
+                 device=0):
         self._lib = _cabi.lib()
         self._h = ctypes.c_void_p()
         K = len(spectra)
@@ -71,7 +73,8 @@ class FitBatch:
         _cabi.check(self._lib.nmrfit_batch_create(int(device), K, N, _cabi.ptr(planes[0]), _cabi.ptr(planes[1]),
                                                   _cabi.ptr(planes[2]), _cabi.ptr(planes[3]), _cabi.ptr(self.P),
                                                   _cabi.ptr(lower), _cabi.ptr(upper), self.S, prm,
-                                                  _cabi.variant_id(variant), ctypes.byref(self._h)))
+                                                  _cabi.variant_id(variant), equations.fit_im_mode(fit_im),
+                                                  ctypes.byref(self._h)))
 
     # -- life cycle ----------------------------------------------------------------------------
     def close(self):

@@ -40,11 +40,11 @@ def fit_many(jobs, threads=4, batch=True, shard=False, **kwargs):
 
     How the jobs run:
 
-    * ``batch=True`` (default): jobs of equal grid length, swarm size and kernel variant, real part only, are fitted as
+    * ``batch=True`` (default): jobs of equal grid length, swarm size, kernel variant and ``fit_im`` are fitted as
       ONE device batch -- one kernel launch per swarm generation for all of them (nmrfit_amd.batch.FitBatch,
       csrc/batch.hip).  A 204-particle swarm fills a fraction of an MI355X; a batch fills it.  Each fit's ``params`` and
       ``error`` are bit-identical to what ``fit`` returns for it alone with the same ``options['seed']``.
-    * whatever cannot be batched (``fit_im``, ``polish``, a lone shape) runs through ``fit`` on ``threads`` host
+    * whatever cannot be batched (``polish``, a lone shape, more than 132 peaks) runs through ``fit`` on ``threads`` host
       threads, each fit with its own context and HIP stream -- serially when ``options['exchange']`` is given: a
       communicator serves one swarm at a time.
     * ``shard=True`` in a multi-GPU launch (one process per GPU, RANK / WORLD_SIZE / LOCAL_RANK set by the launcher):
@@ -150,11 +150,11 @@ def _fit_batch(fits, plans, key):
     (what FitUtility.fit does for one, utils.py:164-189)."""
     from .batch import FitBatch
     from .pso import STOP_MESSAGES
-    device, _, swarmsize, variant, maxiter, check_every = key
+    device, _, swarmsize, variant, maxiter, check_every, fit_im = key
     spectra = [(f.data.w, f.data.u, f.data.v, f.weights) for f in fits]
     kw = {name: [p['kw'][name] for p in plans] for name in ("omega", "phip", "phig", "minstep", "minfunc")}
     with FitBatch(spectra, [f.lower for f in fits], [f.upper for f in fits], swarmsize=swarmsize,
-                  seeds=[p['seed'] for p in plans], variant=variant, device=device, **kw) as fb:
+                  seeds=[p['seed'] for p in plans], variant=variant, fit_im=fit_im, device=device, **kw) as fb:
         fb.run(maxiter, check_every)
         status = fb.status()
         best = fb.best()

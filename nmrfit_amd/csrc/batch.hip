@@ -32,6 +32,7 @@ struct BatchPart {
     int32_t K = 0;
     int64_t N = 0, S = 0, n_chunks = 0;
     int variant = NMRFIT_VARIANT_DEFAULT;
+    int fit_im = NMRFIT_FIT_IM_OFF;
     int32_t Pmax = 0;
     std::vector<int32_t> P;
     std::vector<int64_t> D, boff;        // per fit: 4 + 3P, offset of its bounds / best row in the concatenated arrays
@@ -187,6 +188,8 @@ int bind_batch(const BatchPart *b)
     return NMRFIT_OK;
 }
 
+int launch_generation(const BatchLaunch &g) { return g.fit_im ? launch_objective_batch_im(g) : launch_objective_batch(g); }
+
 const BatchFit *table(const BatchPart *b, int t) { return b->d_tables + (size_t)t * (size_t)b->K; }
 
 int launch_tail(BatchPart *b, int phases, int is_init)
@@ -227,6 +230,7 @@ void plan_geometry(BatchPart *b)
         g.blk_chunks = blk_chunks;
         g.n_blocks = (int)n_blocks;
         g.variant = b->variant;
+        g.fit_im = b->fit_im;
         b->geom_ok[m] = false;
         int slices, rows;
         size_t row_bytes;
@@ -236,6 +240,7 @@ void plan_geometry(BatchPart *b)
             int wpb = 0;
             int64_t seg_len = 0;
             for (int w : {kWideWaves, kWavesPerBlock}) {
+                if (w == kWideWaves && b->fit_im != NMRFIT_FIT_IM_OFF) continue;   // (the imaginary channel has four-wave forms only)
                 if (n_blocks < w) continue;
                 const int64_t sl = ((n_blocks + w - 1) / w) * blk_len;
                 if ((N + sl - 1) / sl != w) continue;
@@ -269,7 +274,7 @@ void plan_geometry(BatchPart *b)
         }
         int v = b->variant;
         unsigned aux = 0;
-        size_t lds = objective_lds(b->variant, b->Pmax, false, 0, &v, &aux, g.wpb, slices, rows);
+        size_t lds = objective_lds(b->variant, b->Pmax, false, b->fit_im, &v, &aux, g.wpb, slices, rows);
         if (v != b->variant) continue;   // (would run another kernel than a lone fit: not bit-identical)
         lds = (lds + 15) & ~(size_t)15;   // the row copies come last (their offset, xrow_offset below, travels in the
         lds += row_bytes;                 // descriptor tables: PsoFused::xrow_off, re-stamped when the geometry changes)
@@ -320,8 +325,8 @@ struct Carver {
 static int part_destroy(BatchPart *b);
 
 static int part_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
-                        const double *weights, const int32_t *P, const double *lower, const double *upper,
-                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, BatchPart **out)
+                       const double *weights, const int32_t *P, const double *lower, const double *upper,
+                       int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im, BatchPart **out)
 {
     if (!out) {
         set_error("null out pointer");
@@ -334,6 +339,14 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
     }
     if (variant != NMRFIT_VARIANT_DEFAULT && variant != NMRFIT_VARIANT_FARFIELD) {
         set_error("nmrfit_batch_create: device-batched fits run the DEFAULT and FARFIELD kernels");
+        return NMRFIT_E_UNSUPPORTED;
+    }
+    if (fit_im < 0 || fit_im > NMRFIT_FIT_IM_SUM) {
+        set_error("fit_im must be 0 (real part), 1 (reference fit_im=True) or 2 (all-peak imaginary model)");
+        return NMRFIT_E_INVALID;
+    }
+    if (fit_im == NMRFIT_FIT_IM_SUM && variant != NMRFIT_VARIANT_DEFAULT) {
+        set_error("nmrfit_batch_create: the all-peak imaginary model runs the DEFAULT kernel (what nmrfit_amd.fit selects)");
         return NMRFIT_E_UNSUPPORTED;
     }
     if (swarmsize > 0x7fffffffLL / 8) {
@@ -370,6 +383,7 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
     b->S = swarmsize;
     b->n_chunks = (N + kChunk - 1) / kChunk;
     b->variant = variant;
+    b->fit_im = fit_im;
     b->P.assign(P, P + K);
     b->D.resize((size_t)K);
     b->boff.resize((size_t)K);
@@ -582,7 +596,7 @@ static int batch_init(BatchPart *b)
     NMRFIT_HIP(hipGetLastError());
     BatchLaunch g = b->geom[b->mode];
     g.fits = table(b, 8);
-    int rc = launch_objective_batch(g);
+    int rc = launch_generation(g);
     if (rc != NMRFIT_OK) return rc;
     if ((rc = launch_tail(b, kBatchPbest | kBatchArgmin | kBatchApply, 1)) != NMRFIT_OK) return rc;
     b->initialized = true;
@@ -594,7 +608,7 @@ static int batch_generation(BatchPart *b)
 {
     BatchLaunch g = b->geom[b->mode];
     g.fits = table(b, b->xp + 2 * b->b + (b->fold_pending ? 4 : 0));
-    const int rc = launch_objective_batch(g);
+    const int rc = launch_generation(g);
     if (rc != NMRFIT_OK) return rc;
     b->xp ^= 1;                          // x / v and (p, fp): the buffers the launch has just written
     if (b->fold_pending) b->b ^= 1;      // it folded the generation before: particle 0 wrote the other state block
@@ -765,7 +779,7 @@ extern "C" {
 
 int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
                         const double *weights, const int32_t *P, const double *lower, const double *upper,
-                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, nmrfit_batch **out)
+                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im, nmrfit_batch **out)
 {
     if (!out) {
         set_error("null out pointer");
@@ -795,7 +809,7 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
         const int rc = part_create(device, f1 - f0, N, w + (size_t)f0 * (size_t)N, u + (size_t)f0 * (size_t)N,
                                    v + (size_t)f0 * (size_t)N, weights + (size_t)f0 * (size_t)N, P + f0,
                                    lower + b->boff[(size_t)f0], upper + b->boff[(size_t)f0], swarmsize, params + f0, variant,
-                                   &part);
+                                   fit_im, &part);
         if (rc != NMRFIT_OK) {
             nmrfit_batch_destroy(b);
             return rc;

@@ -34,8 +34,10 @@ struct BatchLaunch {
     size_t lds;
     unsigned aux_off;
     int variant;            // NMRFIT_VARIANT_DEFAULT or NMRFIT_VARIANT_FARFIELD
+    int fit_im;             // NMRFIT_FIT_IM_* (the imaginary channel: four-wave forms only)
 };
 
-int launch_objective_batch(const BatchLaunch &a);   // objective_batch.hip
+int launch_objective_batch(const BatchLaunch &a);      // objective_batch.hip (fit_im = 0)
+int launch_objective_batch_im(const BatchLaunch &a);   // objective_batch_im.hip (fit_im = 1, 2)
 
 }  // namespace nmrfit

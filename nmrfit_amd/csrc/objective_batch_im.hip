@@ -1,0 +1,43 @@
+// objective_batch_im.hip -- the batched objective kernel with the imaginary channel (fit_im = True: the reference's
+// last-peak-only term, nmrfit/equations.py:197-209; "sum": every peak), in the two geometries that exist for it: a
+// four-wave workgroup per particle, a wave per particle.  DEFAULT and FARFIELD for fit_im = 1, DEFAULT for fit_im = 2
+// (what nmrfit_amd.fit selects: utils.default_variant).  A translation unit of its own: these are the slowest kernels
+// to compile.
+#include "objective_batch_kernel.h"
+
+namespace nmrfit {
+namespace {
+
+template <int VARIANT, int FIT_IM>
+int launch_batch_im(const BatchLaunch &a)
+{
+    const dim3 grid((unsigned)(a.blocks_per_fit * a.K));
+    if (a.wave_swarm)
+        hipLaunchKernelGGL((objective_batch_kernel<VARIANT, kWavesPerBlock, true, FIT_IM>), grid, dim3(kWave * kWavesPerBlock), a.lds,
+                           a.stream, a.fits, a.S, (int)a.blocks_per_fit, a.N, a.nseg, a.seg_len, a.blk_chunks, a.seg_blocks,
+                           a.n_blocks, a.aux_off);
+    else
+        hipLaunchKernelGGL((objective_batch_kernel<VARIANT, kWavesPerBlock, false, FIT_IM>), grid, dim3(kWave * kWavesPerBlock), a.lds,
+                           a.stream, a.fits, a.S, (int)a.blocks_per_fit, a.N, a.nseg, a.seg_len, a.blk_chunks, a.seg_blocks,
+                           a.n_blocks, a.aux_off);
+    NMRFIT_HIP(hipGetLastError());
+    return NMRFIT_OK;
+}
+
+}  // namespace
+
+int launch_objective_batch_im(const BatchLaunch &a)
+{
+    if (a.K <= 0 || a.S <= 0) return NMRFIT_OK;
+    if (a.blocks_per_fit * (int64_t)a.K > 0x7fffffffLL || a.wpb != kWavesPerBlock) {
+        set_error("batch too large for one launch, or not a four-wave geometry");
+        return NMRFIT_E_INVALID;
+    }
+    if (a.variant == NMRFIT_VARIANT_DEFAULT && a.fit_im == NMRFIT_FIT_IM_REFERENCE) return launch_batch_im<NMRFIT_VARIANT_DEFAULT, 1>(a);
+    if (a.variant == NMRFIT_VARIANT_DEFAULT && a.fit_im == NMRFIT_FIT_IM_SUM) return launch_batch_im<NMRFIT_VARIANT_DEFAULT, 2>(a);
+    if (a.variant == NMRFIT_VARIANT_FARFIELD && a.fit_im == NMRFIT_FIT_IM_REFERENCE) return launch_batch_im<NMRFIT_VARIANT_FARFIELD, 1>(a);
+    set_error("device-batched fits with the imaginary channel: DEFAULT (fit_im 1, 2) and FARFIELD (fit_im 1) -- what nmrfit_amd.fit selects");
+    return NMRFIT_E_UNSUPPORTED;
+}
+
+}  // namespace nmrfit

@@ -206,14 +206,17 @@ class FitUtility:
 
     def _batch_key(self, plan):
         """The key under which core.fit_many may put this fit into a device batch with others (csrc/batch.hip: equal
-        grid length, swarm size and kernel variant, real part only) -- or None when it must run on its own."""
+        grid length, swarm size, kernel variant and imaginary-channel mode) -- or None when it must run on its own."""
         opt = self.options
-        if equations.fit_im_mode(self.fit_im) != _cabi.FIT_IM_OFF or opt.get('exchange') is not None or opt.get('polish', False):
+        mode = equations.fit_im_mode(self.fit_im)
+        if opt.get('exchange') is not None or opt.get('polish', False):
             return None
         if plan['variant'] not in (_cabi.VARIANT_DEFAULT, _cabi.VARIANT_FARFIELD) or len(self.lower) > 400:
             return None
+        if mode == _cabi.FIT_IM_SUM and plan['variant'] != _cabi.VARIANT_DEFAULT:
+            return None
         return (self._device(), len(self.data.w), int(plan['swarmsize']), plan['variant'], int(plan['maxiter']),
-                int(plan['check_every']))
+                int(plan['check_every']), mode)
 
     def _finish(self, xopt, fopt):
         self.params = xopt

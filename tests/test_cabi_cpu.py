@@ -130,7 +130,7 @@ def test_batch_argument_validation_needs_no_gpu():
     fails loudly (NMRFIT_E_NO_DEVICE) -- there is no CPU path behind nmrfit_amd.fit_many either."""
     L = _cabi.lib()
     out = ctypes.c_void_p()
-    assert L.nmrfit_batch_create(0, 0, 64, None, None, None, None, None, None, None, 8, None, 0, ctypes.byref(out)) == _cabi.E_INVALID
+    assert L.nmrfit_batch_create(0, 0, 64, None, None, None, None, None, None, None, 8, None, 0, 0, ctypes.byref(out)) == _cabi.E_INVALID
     assert b"K, N, swarmsize" in L.nmrfit_last_error()
     assert L.nmrfit_batch_destroy(None) == _cabi.OK
     assert L.nmrfit_batch_run(None, 1, 1) == _cabi.E_INVALID

@@ -34,14 +34,15 @@ def test_batch_key_groups_equal_shapes_only():
         f = utils.FitUtility(args.pop("data"), args.pop("lower"), args.pop("upper"), **args)
         return f._batch_key(f._plan())
     a, b, c = _job(4096, 6, 1), _job(4096, 4, 2), _job(8192, 6, 3)
+    big = _job(32768, 12, 4)
     ka, kb, kc = key(a), key(b), key(c)
     assert ka is not None and ka == kb and kc != ka                 # peak counts may differ, grid lengths may not
     assert key(a, options={"swarmsize": 100}) != ka
-    assert key(a, fit_im=True) is None and key(a, fit_im="sum") is None
+    assert key(a, fit_im=True) not in (None, ka) and key(a, fit_im="sum") not in (None, ka, key(a, fit_im=True))
+    assert key(big, fit_im="sum")[3] == _cabi.VARIANT_DEFAULT          # (every peak's imaginary line: the direct kernel)
     assert key(a, options={"polish": True}) is None
     assert key(a, options={"exchange": object()}) is None
     assert key(a, options={"variant": "norec"}) is None
-    big = _job(32768, 12, 4)
     assert key(big)[3] == _cabi.VARIANT_FARFIELD and key(a)[3] == _cabi.VARIANT_DEFAULT
 
 
@@ -62,7 +63,7 @@ def test_jobs_with_a_communicator_run_one_after_another(monkeypatch):
     assert len(out) == 5
     # without a communicator the same call may use the pool (order of completion is free, results keep job order)
     calls.clear()
-    jobs = [_job(1024, 2, 10 + k, fit_im=True, options={"tag": k}) for k in range(5)]
+    jobs = [_job(1024, 2, 10 + k, options={"tag": k, "polish": True}) for k in range(5)]      # (polish: not batchable)
     out = core.fit_many(jobs, threads=4)
     assert sorted(t for _, t in calls) == [0, 1, 2, 3, 4] and [f.options["tag"] for f in out] == [0, 1, 2, 3, 4]
 

@@ -151,6 +151,47 @@ def test_batch_farfield_variant_and_per_fit_constants():
         _close(evs, sws)
 
 
+@pytest.mark.parametrize("geometry", ["workgroup", "wave"])
+@pytest.mark.parametrize("fit_im,variant,N,P", [(True, "default", 4096, (6, 3, 5)), ("sum", "default", 4096, (4, 6, 2)),
+                                                  (True, "farfield", 16384, (12, 9, 10))])
+def test_batch_with_the_imaginary_channel(fit_im, variant, N, P, geometry):
+    """fit_im=True (the reference's last-peak-only imaginary term, nmrfit/equations.py:197-209) and "sum" in a device
+    batch: still the lone swarms' trajectories, bit for bit, with pyswarm's rule on."""
+    K, S = 3, 72
+    problems = [synth.make_spectrum(N, P[k], seed=70 + k) for k in range(K)]
+    seeds = [31, 32, 33]
+    evs, sws = [], []
+    try:
+        for sp, seed in zip(problems, seeds):
+            ev = Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"])
+            ev.set_variant(_cabi.variant_id(variant))
+            ev.set_fit_im(fit_im)
+            evs.append(ev)
+            sws.append(pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed))
+        for sw in sws:
+            sw.run(90, 8)
+        with FitBatch([(sp["w"], sp["u"], sp["v"], sp["weights"]) for sp in problems], [sp["lower"] for sp in problems],
+                      [sp["upper"] for sp in problems], swarmsize=S, seeds=seeds, variant=variant, fit_im=fit_im) as fb:
+            fb.set_geometry(geometry)
+            fb.run(90, 8)
+            st, best = fb.status(), fb.best()
+            for k, sw in enumerate(sws):
+                a, b = fb.state(k), sw.state()
+                for name in ("x", "v", "p", "fp"):
+                    np.testing.assert_array_equal(a[name], b[name], err_msg="fit %d %s" % (k, name))
+                ls = sw.status()
+                assert (st[k]["iteration"], st[k]["stop"], st[k]["fg"]) == (ls["iteration"], ls["stop"], ls["fg"]), k
+                xb, fbest = sw.best()
+                np.testing.assert_array_equal(best[k][0], xb)
+                assert best[k][1] == fbest
+        with pytest.raises(_cabi.NmrfitError) as ei:
+            FitBatch([(sp["w"], sp["u"], sp["v"], sp["weights"]) for sp in problems], [sp["lower"] for sp in problems],
+                     [sp["upper"] for sp in problems], swarmsize=S, seeds=seeds, variant="farfield", fit_im="sum")
+        assert ei.value.code == _cabi.E_UNSUPPORTED
+    finally:
+        _close(evs, sws)
+
+
 def test_fit_many_batches_what_it_can_and_equals_the_plain_loop(capsys):
     """nmrfit_amd.fit_many: jobs of equal shape go through one device batch, the others (another grid length, fit_im)
     through fit(); every result equals the plain loop's bit for bit, in job order."""
@@ -162,7 +203,7 @@ def test_fit_many_batches_what_it_can_and_equals_the_plain_loop(capsys):
         opts.append({"seed": 300 + k, "maxiter": 80, "swarmsize": 120})
     loop = [nmrfit_amd.fit(*job, summary=False, options=o) for job, o in zip(jobs, opts)]
     dict_jobs = [dict(data=j[0], lower=j[1], upper=j[2], options=o) for j, o in zip(jobs, opts)]
-    dict_jobs[3]["fit_im"] = True                     # cannot be batched: runs through fit()
+    dict_jobs[3]["fit_im"] = True                     # a group of one: runs through fit()
     loop[3] = nmrfit_amd.fit(*jobs[3], fit_im=True, summary=False, options=opts[3])
     capsys.readouterr()
     many = nmrfit_amd.fit_many(dict_jobs, threads=2)

@@ -27,7 +27,7 @@ def demangle(names):
 def resources(extra):
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
-        for src in ("objective_default.hip", "objective_farfield.hip", "objective_farfield32.hip", "objective_norec.hip", "objective_batch.hip", "objective.hip", "pso.hip", "batch.hip"):
+        for src in ("objective_default.hip", "objective_farfield.hip", "objective_farfield32.hip", "objective_norec.hip", "objective_batch.hip", "objective_batch_im.hip", "objective.hip", "pso.hip", "batch.hip"):
             if not os.path.exists(os.path.join(CSRC, src)):
                 continue
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
@@ -67,10 +67,11 @@ def main():
             label = "objective_kernel<%s,%s,fit_im=%d%s>" % (VARIANTS.get(v, v), "residual" if wr else "objective", fi,
                                                             ",8 waves" if m.group(4) == "8" else "")
             selectable = v in (0, 6, 7, 8)
-        mb = re.match(r"objective_batch_kernel<(\d+), (\d+), (true|false)>", name)
+        mb = re.match(r"objective_batch_kernel<(\d+), (\d+), (true|false), (\d+)>", name)
         if mb:
-            label = "objective_batch_kernel<%s,%s>" % (VARIANTS.get(int(mb.group(1)), mb.group(1)),
-                                                       "wave=particle" if mb.group(3) == "true" else "%s waves" % mb.group(2))
+            label = "objective_batch_kernel<%s,%s%s>" % (VARIANTS.get(int(mb.group(1)), mb.group(1)),
+                                                         "wave=particle" if mb.group(3) == "true" else "%s waves" % mb.group(2),
+                                                         ",fit_im=%s" % mb.group(4) if mb.group(4) != "0" else "")
         scratch = int(r.get("ScratchSize [bytes/lane]", "0"))
         # (s-spill: scalar registers parked in VGPR lanes -- v_writelane / v_readlane, which are VALU instructions: in a
         # loop they cost issue slots like arithmetic does)

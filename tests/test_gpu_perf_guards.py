@@ -59,3 +59,22 @@ def test_one_launch_generations_stay_fast(S, N, P, limit_us):
         sw.close()
     print("generation %d x %d x %d: %.2f us" % (S, N, P, best))
     assert best <= limit_us, best
+
+
+@pytest.mark.xfail(strict=False, reason="wall-clock guard, non-gating")
+def test_device_batched_default_fits_stay_fast():
+    """40 default fits (204 x 4096 x 6) as one device batch, stopping rule off: round 5 measured 2.0-2.3 us per fit and
+    generation (217-242 fits/s; four host threads with a context each, round 4: 94 fits/s = 5.3 us)."""
+    import time
+    from nmrfit_amd import synth
+    from nmrfit_amd.batch import FitBatch
+    K = 40
+    specs = [synth.make_spectrum(4096, 6, seed=100 + k % 8) for k in range(K)]
+    with FitBatch([(s["w"], s["u"], s["v"], s["weights"]) for s in specs], [s["lower"] for s in specs],
+                  [s["upper"] for s in specs], swarmsize=204, seeds=list(range(K)), minstep=-1.0, minfunc=-1.0) as fb:
+        fb.run(50, 50)
+        t0 = time.perf_counter()
+        fb.run(500, 500)
+        us = (time.perf_counter() - t0) / 500 / K * 1e6
+    print("device batch of %d default fits: %.2f us per fit and generation" % (K, us))
+    assert us <= 2.7, us

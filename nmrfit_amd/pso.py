@@ -291,9 +291,10 @@ class DeviceSwarm:
         _cabi.check(self._lib.nmrfit_pso_step(self._h))
 
     def set_handover(self, mode):
-        """How the personal-best / argmin kernel's workgroups hand over inside one launch (swarms of
-        up to 1024 particles): "fast" (default: fence-free agent-scope stores), "fenced" (release /
-        acquire fences) or "two_launch".  Bit-identical results; an A/B knob."""
+        """How the personal-best / argmin kernel's workgroups hand their results to the one that finishes (swarms of up
+        to 1024 particles whose generation is not finished inside the objective launch): "two_launch" (default since
+        round 5: nothing handed over inside a launch), "fast" (fence-free agent-scope stores) or "fenced" (release /
+        acquire fences).  Bit-identical results; an A/B knob."""
         if isinstance(mode, str):
             mode = {"fast": _cabi.HANDOVER_FAST, "fenced": _cabi.HANDOVER_FENCED,
                     "two_launch": _cabi.HANDOVER_TWO_LAUNCH}[mode.lower()]

@@ -31,7 +31,7 @@ def fit(data, lower, upper, expon=0.5, dynamic_weighting=True, fit_im=False, pro
     return f
 
 
-def fit_many(jobs, threads=4, batch=True, shard=False, **kwargs):
+def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, **kwargs):
     """Fit several spectra: ``jobs`` is a sequence of ``(data, lower, upper)`` triples (or dicts of ``fit``'s
     arguments); every job is fitted as ``fit`` would fit it with the same keyword arguments, and the list of
     FitUtility objects comes back in the order of ``jobs``.  Not in the reference (its users loop over
@@ -50,9 +50,24 @@ def fit_many(jobs, threads=4, batch=True, shard=False, **kwargs):
     * ``shard=True`` in a multi-GPU launch (one process per GPU, RANK / WORLD_SIZE / LOCAL_RANK set by the launcher):
       the JOBS are divided over the ranks -- rank r takes jobs r, r + world, ... on its own GPU -- and the results are
       gathered so that every rank returns the full list.  Replicas: no collective touches the fits themselves.  This is
-      the multi-GPU mode for many small fits (sharding one 204-particle swarm over GPUs is slower than one GPU)."""
+      the multi-GPU mode for many small fits (sharding one 204-particle swarm over GPUs is slower than one GPU).
+    * ``devices=[0, 1, ...]`` (or ``"all"``): the same replicas WITHOUT a launcher -- this one process drives several
+      GPUs, a host thread per device, job k on ``devices[k % len(devices)]``; each device runs its share as device
+      batches of its own.  Nothing crosses devices.  (``shard`` and ``devices`` exclude each other.)"""
     kwargs.setdefault("summary", False)
     jobs = [dict(job) if isinstance(job, dict) else dict(zip(("data", "lower", "upper"), job)) for job in jobs]
+    if devices is not None:
+        if shard:
+            raise ValueError("fit_many: shard=True divides the jobs over PROCESSES, devices=[...] over the GPUs of this "
+                             "process: use one of them")
+        if isinstance(devices, str):
+            if devices != "all":
+                raise ValueError("fit_many: devices must be a list of device indices or \"all\"")
+            devices = list(range(_cabi_device_count()))
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("fit_many: no devices")
+        return _fit_many_devices(jobs, threads, batch, kwargs, devices)
     if shard:
         from . import rendezvous
         rank, _, world = rendezvous.env_rank_world()
@@ -104,6 +119,24 @@ def _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, channel=None, l
             f = utils.FitUtility(job["data"], job["lower"], job["upper"], **args)
             f.params, f.error, f.seed = np.array(rec["params"]), rec["error"], rec["seed"]
             out[i] = f
+    return out
+
+
+def _fit_many_devices(jobs, threads, batch, kwargs, devices):
+    """Job k on devices[k % len(devices)], one host thread per device (the library releases the GIL inside its calls;
+    every call binds its own device), results back in job order."""
+    from concurrent.futures import ThreadPoolExecutor
+    shares = [list(range(i, len(jobs), len(devices))) for i in range(len(devices))]
+
+    def one(i):
+        opts = dict(kwargs.get("options", {}), device=devices[i])
+        mine = [dict(jobs[k], options=dict(opts, **jobs[k].get("options", {}), device=devices[i])) for k in shares[i]]
+        return _fit_many_local(mine, threads, batch, dict(kwargs, options=opts))
+    out = [None] * len(jobs)
+    with ThreadPoolExecutor(max_workers=len(devices)) as pool:
+        for idx, res in zip(shares, pool.map(one, range(len(devices)))):
+            for k, f in zip(idx, res):
+                out[k] = f
     return out
 
 

@@ -250,6 +250,28 @@ def test_batch_edge_shapes_two_parts_tiny_grid_no_peaks():
         _close(evs, sws)
 
 
+def test_fit_many_over_the_devices_of_one_process():
+    """fit_many(jobs, devices=[...]): a host thread per device, job k on devices[k % n], each share a device batch of
+    its own -- rehearsed with the one card listed twice: same results as the plain call, in job order."""
+    import nmrfit_amd
+    jobs = []
+    for k in range(9):
+        sp = synth.make_spectrum(4096, 3 + k % 4, seed=120 + k)
+        jobs.append(dict(data=synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"]), lower=list(sp["lower"]),
+                         upper=list(sp["upper"]), options={"seed": 700 + k, "maxiter": 50, "swarmsize": 64}))
+    want = nmrfit_amd.fit_many(jobs)
+    got = nmrfit_amd.fit_many(jobs, devices=[0, 0])
+    also = nmrfit_amd.fit_many(jobs, devices="all")
+    for a, b, c in zip(want, got, also):
+        np.testing.assert_array_equal(a.params, b.params)
+        np.testing.assert_array_equal(a.params, c.params)
+        assert a.error == b.error == c.error
+    with pytest.raises(ValueError):
+        nmrfit_amd.fit_many(jobs, devices=[0], shard=True)
+    with pytest.raises(ValueError):
+        nmrfit_amd.fit_many(jobs, devices=[])
+
+
 def test_batch_argument_validation():
     sp = synth.make_spectrum(4096, 3, seed=1)
     spec = (sp["w"], sp["u"], sp["v"], sp["weights"])

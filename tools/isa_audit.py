@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """
-Static audit of the hot kernel's gfx950 ISA (no GPU needed): compiles objective.hip to assembly
+Static audit of the hot kernel's gfx950 ISA (no GPU needed): compiles one of the kernel translation units
+(default objective_default.hip; --unit objective_batch.hip for the batched kernels) to assembly
 with the flags of csrc/build.sh, takes one instantiation of objective_kernel apart into basic
 blocks, and counts instructions by class in every block that sits inside a loop.
 
-    tools/isa_audit.py [--kernel objective_kernelILi0ELb0ELi0E] [--min 30] [--dump BLOCK] [-D...]
+    tools/isa_audit.py [--unit objective_farfield.hip] [--kernel objective_kernelILi0ELb0ELi0E] [--min 30] [--dump BLOCK] [-D...]
 
 The point of it: SQ_INSTS_VALU says 5.88 VALU instructions per (particle,
 point, peak) unit where the algebra needs ~4.6 + the Gaussians; this shows where the rest sits
@@ -21,11 +22,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nmrfit_amd", "csrc")
 
 
+UNIT = "objective_default.hip"
+if "--unit" in sys.argv:
+    i = sys.argv.index("--unit")
+    UNIT = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+
+
 def compile_asm(extra):
     out = os.path.join(tempfile.gettempdir(), "nmrfit_objective_%d.s" % os.getpid())
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fno-fast-math",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only",
-           os.path.join(CSRC, "objective.hip"), "-o", out] + extra
+           os.path.join(CSRC, UNIT), "-o", out] + extra
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return out
 

@@ -250,6 +250,26 @@ def test_batch_edge_shapes_two_parts_tiny_grid_no_peaks():
         _close(evs, sws)
 
 
+def test_full_length_default_fits_batched_equal_the_lone_fits():
+    """The reference's default fit at full length -- 204 particles, 2000 generations (nmrfit/utils.py:177-178), stopping
+    rule off so that every generation runs -- 18 spectra as one device batch (two parts, two streams, the wave geometry)
+    against 18 lone nmrfit_amd.fit calls: 4e5 objective evaluations per fit, params and error equal bit for bit."""
+    import contextlib
+    import io
+    import nmrfit_amd
+    jobs = []
+    for k in range(18):
+        sp = synth.make_spectrum(4096, 6, seed=200 + k)
+        jobs.append((synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"]), list(sp["lower"]), list(sp["upper"])))
+    with contextlib.redirect_stdout(io.StringIO()):
+        many = nmrfit_amd.fit_many([dict(data=j[0], lower=j[1], upper=j[2], options={"seed": 900 + k, "minstep": -1.0, "minfunc": -1.0})
+                                    for k, j in enumerate(jobs)])
+        lone = [nmrfit_amd.fit(*j, summary=False, options={"seed": 900 + k, "minstep": -1.0, "minfunc": -1.0}) for k, j in enumerate(jobs)]
+    for a, b in zip(many, lone):
+        np.testing.assert_array_equal(a.params, b.params)
+        assert a.error == b.error
+
+
 def test_fit_many_over_the_devices_of_one_process():
     """fit_many(jobs, devices=[...]): a host thread per device, job k on devices[k % n], each share a device batch of
     its own -- rehearsed with the one card listed twice: same results as the plain call, in job order."""

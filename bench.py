@@ -893,6 +893,21 @@ def main():
                                     "generations": {"min": min(gens), "max": max(gens), "mean": float(np.mean(gens))},
                                     "us_per_fit_generation": dtb * 1e6 / max(1.0, float(np.sum(gens))),
                                     "geometry": gm, "error_fit0": bestb[0][1]}
+            # ... and the user-level call, host side included: nmrfit_amd.fit_many on the same 40 spectra (weights and plans on
+            # the host, one device batch, results into FitUtility objects)
+            import contextlib
+            import io
+            import nmrfit_amd
+            jobs_b = [(synth.SynthData(q["w"], q["u"], q["v"], q["peaks"]), list(q["lower"]), list(q["upper"])) for q in specs]
+            e2e = {}
+            for key, rule in (("stopping_rule_off", {"minstep": -1.0, "minfunc": -1.0}), ("stopping_rule_on", {})):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    tb = time.perf_counter()
+                    res = nmrfit_amd.fit_many([dict(data=j[0], lower=j[1], upper=j[2], options=dict(rule, seed=7 + k, device=device))
+                                               for k, j in enumerate(jobs_b)])
+                    dtb = time.perf_counter() - tb
+                e2e[key] = {"wall_ms": dtb * 1e3, "fits_per_s": Kb / dtb, "error_fit0": float(res[0].error)}
+            batched_fit["fit_many_end_to_end"] = e2e
             batched_fit["note"] = ("nmrfit_amd.batch.FitBatch: context creation + generation 0 + generations + read-back of "
                                    "%d fits of the reference's default shape in ONE batch (what nmrfit_amd.fit_many builds); "
                                    "stopping_rule_off runs all 2000 generations of every fit (the work of "

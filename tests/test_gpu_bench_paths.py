@@ -160,6 +160,9 @@ def test_c4_rehearsal_four_ranks_on_one_gpu():
     assert bf["stopping_rule_off"]["fits_per_s"] > 2.0 * 1e3 / rf["wall_ms"]      # at least twice a loop of lone fits
     assert bf["stopping_rule_on"]["generations"]["max"] <= 2000 and bf["stopping_rule_on"]["fits_per_s"] > bf["stopping_rule_off"]["fits_per_s"]
     assert bf["stopping_rule_off"]["geometry"]["mode"] == "wave"
+    e2e = bf["fit_many_end_to_end"]      # the user-level call on the same spectra (its own weights: FitUtility._compute_weights)
+    assert 0.0 < e2e["stopping_rule_off"]["error_fit0"] < 0.05
+    assert e2e["stopping_rule_on"]["fits_per_s"] > e2e["stopping_rule_off"]["fits_per_s"] > 2.0 * 1e3 / rf["wall_ms"]
     # the sharded run carries the model its step time is to be judged against
     sm = four["scaling_model"]
     assert len(sm["expected_ms_per_step"]) == 2 and sm["max_rank_kernel_ms"] > 0 and sm["measured_over_expected"] is not None

@@ -250,6 +250,38 @@ def test_batch_edge_shapes_two_parts_tiny_grid_no_peaks():
         _close(evs, sws)
 
 
+@pytest.mark.parametrize("geometry", ["workgroup", "wave"])
+def test_batch_with_a_fit_that_never_has_a_finite_objective(geometry):
+    """pyswarm seeds g with x[0] while no particle has a finite objective (tests/test_pso_cpu.py pins that rule against the
+    restated loop): one fit of a batch whose spectrum is NaN (its fg stays +inf, its record carries x[0]) beside two
+    ordinary ones -- each still equals its lone swarm, and the ordinary ones are not disturbed by their neighbour."""
+    K, S, N = 3, 40, 4096
+    problems = _problems(K, N)
+    problems[0] = dict(problems[0], u=np.full(N, np.nan))
+    seeds = [61, 62, 63]
+    evs, sws = _lone_swarms(problems, S, seeds, "default")
+    try:
+        for sw in sws:
+            sw.run(25, 4)
+        with _batch(problems, S, seeds) as fb:
+            fb.set_geometry(geometry)
+            fb.run(25, 4)
+            st, best = fb.status(), fb.best()
+            for k, sw in enumerate(sws):
+                a, b = fb.state(k), sw.state()
+                for name in ("x", "v", "p", "fp", "fx"):
+                    np.testing.assert_array_equal(a[name], b[name], err_msg="fit %d %s" % (k, name))
+                ls = sw.status()
+                assert st[k]["iteration"] == ls["iteration"] and st[k]["stop"] == ls["stop"], k
+                assert (st[k]["fg"] == ls["fg"]) or (np.isinf(st[k]["fg"]) and np.isinf(ls["fg"])), k
+                xb, fbest = sw.best()
+                np.testing.assert_array_equal(best[k][0], xb)
+                assert best[k][1] == fbest or (np.isinf(fbest) and np.isinf(best[k][1]))
+        assert np.isinf(st[0]["fg"]) and np.isfinite(st[2]["fg"])
+    finally:
+        _close(evs, sws)
+
+
 def test_full_length_default_fits_batched_equal_the_lone_fits():
     """The reference's default fit at full length -- 204 particles, 2000 generations (nmrfit/utils.py:177-178), stopping
     rule off so that every generation runs -- 18 spectra as one device batch (two parts, two streams, the wave geometry)

@@ -38,6 +38,7 @@ struct BatchLaunch {
 };
 
 int launch_objective_batch(const BatchLaunch &a);      // objective_batch.hip (fit_im = 0)
-int launch_objective_batch_im(const BatchLaunch &a);   // objective_batch_im.hip (fit_im = 1, 2)
+int launch_objective_batch_im(const BatchLaunch &a);   // objective_batch_im.hip (fit_im = 1; forwards 2)
+int launch_objective_batch_im2(const BatchLaunch &a);  // objective_batch_im2.hip (fit_im = 2, DEFAULT)
 
 }  // namespace nmrfit

@@ -2,7 +2,7 @@
 // last-peak-only term, nmrfit/equations.py:197-209; "sum": every peak), in the two geometries that exist for it: a
 // four-wave workgroup per particle, a wave per particle.  DEFAULT and FARFIELD for fit_im = 1, DEFAULT for fit_im = 2
 // (what nmrfit_amd.fit selects: utils.default_variant).  A translation unit of its own: these are the slowest kernels
-// to compile.
+// to compile (the all-peak sum has a unit of its own, objective_batch_im2.hip).
 #include "objective_batch_kernel.h"
 
 namespace nmrfit {
@@ -34,7 +34,7 @@ int launch_objective_batch_im(const BatchLaunch &a)
         return NMRFIT_E_INVALID;
     }
     if (a.variant == NMRFIT_VARIANT_DEFAULT && a.fit_im == NMRFIT_FIT_IM_REFERENCE) return launch_batch_im<NMRFIT_VARIANT_DEFAULT, 1>(a);
-    if (a.variant == NMRFIT_VARIANT_DEFAULT && a.fit_im == NMRFIT_FIT_IM_SUM) return launch_batch_im<NMRFIT_VARIANT_DEFAULT, 2>(a);
+    if (a.variant == NMRFIT_VARIANT_DEFAULT && a.fit_im == NMRFIT_FIT_IM_SUM) return launch_objective_batch_im2(a);   // objective_batch_im2.hip
     if (a.variant == NMRFIT_VARIANT_FARFIELD && a.fit_im == NMRFIT_FIT_IM_REFERENCE) return launch_batch_im<NMRFIT_VARIANT_FARFIELD, 1>(a);
     set_error("device-batched fits with the imaginary channel: DEFAULT (fit_im 1, 2) and FARFIELD (fit_im 1) -- what nmrfit_amd.fit selects");
     return NMRFIT_E_UNSUPPORTED;

@@ -743,8 +743,9 @@ static int part_get_state(BatchPart *b, int32_t k, double *x, double *v, double 
 // A generation of a part is a few lock-step rounds of short waves: its last round drains with the SIMDs
 // half empty, its first starts with every wave in the latency-bound prologue.  Two parts on two streams fill each
 // other's gaps -- the launches of one generation of part A and part B are independent -- for 5-11 % more fits per
-// second (K = 40: 216 -> 241, K = 200: 238 -> 251; profiles/r05/batch_two_streams.txt).  From 16 fits on (each part
-// then still takes the wave = particle geometry); NMRFIT_BATCH_STREAMS=1 turns it off (A/B knob).
+// second (K = 40: 216 -> 241, K = 200: 238 -> 251; profiles/r05/batch_two_streams.txt; K = 6 ... 12: +3-8 %).  From 6
+// fits on (each part then still has the particles for the wave = particle geometry); NMRFIT_BATCH_STREAMS=1 turns it
+// off (A/B knob).
 struct nmrfit_batch {
     std::vector<BatchPart *> parts;
     std::vector<int32_t> first;      // first fit of each part (+ K at the end)
@@ -800,7 +801,7 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
     b->boff.resize((size_t)K + 1);
     b->boff[0] = 0;
     for (int32_t k = 0; k < K; ++k) b->boff[(size_t)k + 1] = b->boff[(size_t)k] + 4 + 3 * (int64_t)std::max(P[k], 0);
-    int nparts = (K >= 16) ? 2 : 1;
+    int nparts = (K >= 6) ? 2 : 1;
     if (const char *e = getenv("NMRFIT_BATCH_STREAMS")) nparts = std::max(1, std::min(atoi(e), (int)std::min<int32_t>(K, 8)));
     for (int p = 0; p <= nparts; ++p) b->first.push_back((int32_t)((int64_t)K * p / nparts));
     for (int p = 0; p < nparts; ++p) {

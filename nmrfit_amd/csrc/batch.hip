@@ -240,7 +240,7 @@ void plan_geometry(BatchPart *b)
             int wpb = 0;
             int64_t seg_len = 0;
             for (int w : {kWideWaves, kWavesPerBlock}) {
-                if (w == kWideWaves && b->fit_im != NMRFIT_FIT_IM_OFF) continue;   // (the imaginary channel has four-wave forms only)
+                if (b->fit_im != NMRFIT_FIT_IM_OFF) continue;   // (the imaginary channel: wave = particle only)
                 if (n_blocks < w) continue;
                 const int64_t sl = ((n_blocks + w - 1) / w) * blk_len;
                 if ((N + sl - 1) / sl != w) continue;

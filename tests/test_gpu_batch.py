@@ -151,10 +151,9 @@ def test_batch_farfield_variant_and_per_fit_constants():
         _close(evs, sws)
 
 
-@pytest.mark.parametrize("geometry", ["workgroup", "wave"])
 @pytest.mark.parametrize("fit_im,variant,N,P", [(True, "default", 4096, (6, 3, 5)), ("sum", "default", 4096, (4, 6, 2)),
                                                   (True, "farfield", 16384, (12, 9, 10))])
-def test_batch_with_the_imaginary_channel(fit_im, variant, N, P, geometry):
+def test_batch_with_the_imaginary_channel(fit_im, variant, N, P):
     """fit_im=True (the reference's last-peak-only imaginary term, nmrfit/equations.py:197-209) and "sum" in a device
     batch: still the lone swarms' trajectories, bit for bit, with pyswarm's rule on."""
     K, S = 3, 72
@@ -172,7 +171,7 @@ def test_batch_with_the_imaginary_channel(fit_im, variant, N, P, geometry):
             sw.run(90, 8)
         with FitBatch([(sp["w"], sp["u"], sp["v"], sp["weights"]) for sp in problems], [sp["lower"] for sp in problems],
                       [sp["upper"] for sp in problems], swarmsize=S, seeds=seeds, variant=variant, fit_im=fit_im) as fb:
-            fb.set_geometry(geometry)
+            assert fb.geometry()["mode"] == "wave"            # (the imaginary channel is batched in the wave = particle form)
             fb.run(90, 8)
             st, best = fb.status(), fb.best()
             for k, sw in enumerate(sws):

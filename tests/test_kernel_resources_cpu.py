@@ -43,7 +43,7 @@ def test_selectable_kernels_use_no_scratch_and_the_hot_two_fit_four_waves():
         m = re.match(r"(objective_batch_kernel<[^>]+>)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)", line)
         if m:
             out2[m.group(1)] = dict(vgpr=int(m.group(2)), scratch=int(m.group(4)), waves=int(m.group(5)))
-    assert len(out2) == 12, out.stdout[-2000:]      # six real-part forms, six with the imaginary channel
+    assert len(out2) == 9, out.stdout[-2000:]      # six real-part forms, three with the imaginary channel
     assert all(v["scratch"] <= 24 for v in out2.values()), out2
     for name in ("objective_batch_kernel<DEFAULT,wave=particle>", "objective_batch_kernel<FARFIELD,wave=particle>"):
         assert out2[name]["waves"] >= 4 and out2[name]["scratch"] <= 24, (name, out2[name])

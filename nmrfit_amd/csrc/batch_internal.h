@@ -34,7 +34,7 @@ struct BatchLaunch {
     size_t lds;
     unsigned aux_off;
     int variant;            // NMRFIT_VARIANT_DEFAULT or NMRFIT_VARIANT_FARFIELD
-    int fit_im;             // NMRFIT_FIT_IM_* (the imaginary channel: four-wave forms only)
+    int fit_im;             // NMRFIT_FIT_IM_* (the imaginary channel: wave = particle form only)
 };
 
 int launch_objective_batch(const BatchLaunch &a);      // objective_batch.hip (fit_im = 0)

@@ -332,10 +332,7 @@ __device__ __forceinline__ void objective_body(
     // only, never on where the segment starts.
     double zr = 1.0, zi = 0.0;
     const int64_t blk_len = (int64_t)blk_chunks * kChunk;
-    if (!shared) {   // (shared prologue: made once per workgroup above)
-        sincos_fast((p1 * 64.0) * invN, &ri, &rr);
-        rr = wave_uniform(rr);
-        ri = wave_uniform(ri);
+    if (!shared) {   // (shared prologue: made once per workgroup above; the rotation step comes with the block seeds below)
         double lr, li;
         sincos_fast(p0 + (p1 * (double)lane) * invN, &li, &lr);
         lseed[lane] = lr;
@@ -345,10 +342,22 @@ __device__ __forceinline__ void objective_body(
         const int64_t n_blocks = n_blocks_i;
         const int64_t b0 = (int64_t)seg * seg_blocks;
         const int64_t nb = (seg_blocks < n_blocks - b0) ? seg_blocks : n_blocks - b0;   // blocks of [j0, j1)
-        if (lane < nb) {
+        if (shared) {
+            if (lane < nb) {
+                double er, ei;
+                sincos_fast((p1 * (double)((b0 + lane) * blk_len)) * invN, &ei, &er);
+                seeds[lane] = make_double2(er, ei);
+            }
+        } else {
+            // ... and, one particle per wave, the rotation step exp(i p1 64/N) in the same call: lane nb (<= 16) takes it.
+            // The same function of the same argument as a call of its own: the same bits.
+            const double m = (lane < nb) ? (double)((b0 + lane) * blk_len) : 64.0;
             double er, ei;
-            sincos_fast((p1 * (double)((b0 + lane) * blk_len)) * invN, &ei, &er);
-            seeds[lane] = make_double2(er, ei);
+            sincos_fast((p1 * m) * invN, &ei, &er);
+            if (lane < nb) seeds[lane] = make_double2(er, ei);
+            const int rl = (nb > 0) ? (int)nb : 0;   // (a segment without blocks: every lane took the step)
+            rr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(er), rl), __builtin_amdgcn_readlane(__double2loint(er), rl));
+            ri = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ei), rl), __builtin_amdgcn_readlane(__double2loint(ei), rl));
         }
         wave_lds_fence();   // same-wave LDS write -> read
     }
@@ -378,10 +387,10 @@ __device__ __forceinline__ void objective_body(
     // near-peak and Gaussian-window masks of the two chunks in scalar registers.  Either half runs the same
     // operations in the same order, so a chunk's coefficients do not depend on which half made them, nor on when.
     auto expand_pair = [&](const int64_t jbE) {
-        const double2 mm = chunk_minmax[jbE / kChunk];
+        const double2 mm = global_table(chunk_minmax, jbE / kChunk);
         const bool has_next = jbE + kChunk < j1;                  // wave-uniform
         double2 mn = mm;
-        if (has_next) mn = chunk_minmax[jbE / kChunk + 1];
+        if (has_next) mn = global_table(chunk_minmax, jbE / kChunk + 1);
         const bool upper = lane >= 32;
         const int k = lane & 31;
         const double lo_w = upper ? mn.x : mm.x, hi_w = upper ? mn.y : mm.y;
@@ -479,10 +488,10 @@ __device__ __forceinline__ void objective_body(
             }
         } else if (full) {
             // (grid_slot order: the lane's points 2m, 2m+1 are one 16-byte pair -> global_load_dwordx4)
-            const double2 *wp = lane_ptr(wc + jb, lane);
+            const global_pairs wp = lane_ptr(wc + jb, lane);
 #pragma unroll
             for (int m = 0; m < kPointsPerLane / 2; ++m) {
-                const double2 d = wp[m * kWave];
+                const f64x2 d = wp[m * kWave];
                 wv[2 * m] = d.x;
                 wv[2 * m + 1] = d.y;
             }
@@ -507,7 +516,7 @@ __device__ __forceinline__ void objective_body(
             }
         } else {
             double2 mm = make_double2(0.0, 0.0);
-            if (kSkip) mm = chunk_minmax[jb / kChunk];
+            if (kSkip) mm = global_table(chunk_minmax, jb / kChunk);
             if constexpr (kFar) {
                 // ---- far-field form --------------------------------------------------------
                 // For a peak whose centre is far from this chunk (rho = chunk half-span /
@@ -713,7 +722,7 @@ __device__ __forceinline__ void objective_body(
         if constexpr (FIT_IM == 2) {
 #pragma unroll
             for (int q = 0; q < kPointsPerLane; ++q) iacc[q] = 0.0;
-            const double2 mi2 = chunk_minmax[jb / kChunk];
+            const double2 mi2 = global_table(chunk_minmax, jb / kChunk);
             const double icen = wave_uniform(0.5 * (mi2.x + mi2.y));
             const double ihalf = wave_uniform(0.5 * (mi2.y - mi2.x));
             double isum = 0.0;     // lane l: coefficient of order l >> 2 (all 4 lanes of a quad)
@@ -844,10 +853,10 @@ __device__ __forceinline__ void objective_body(
                 tq[q] = stage[2 * kChunk + o];
             }
         } else if (full) {
-            const double2 *up = lane_ptr(u + jb, lane), *vp = lane_ptr(v + jb, lane), *tp = lane_ptr(wt + jb, lane);
+            const global_pairs up = lane_ptr(u + jb, lane), vp = lane_ptr(v + jb, lane), tp = lane_ptr(wt + jb, lane);
 #pragma unroll
             for (int m = 0; m < kPointsPerLane / 2; ++m) {
-                const double2 du = up[m * kWave], dv = vp[m * kWave], dt = tp[m * kWave];
+                const f64x2 du = up[m * kWave], dv = vp[m * kWave], dt = tp[m * kWave];
                 uq[2 * m] = du.x;
                 uq[2 * m + 1] = du.y;
                 vq[2 * m] = dv.x;

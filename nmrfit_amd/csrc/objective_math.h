@@ -207,17 +207,45 @@ __device__ __forceinline__ double vector_f64(double x)
 // point of use -- otherwise the compiler hoists `array + lane` out of the chunk loop as a 64-bit per-lane pointer for
 // each of the four arrays (8 VGPRs held across the loop, a v_lshl_add_u64 per array per chunk) instead of using the
 // scalar-base + 32-bit-offset form of global_load.
-__device__ __forceinline__ const double2 *lane_ptr(const double *uniform_base, int lane)
+// The result is typed as what it is, device global memory: for a base that came out of a descriptor table (the batched
+// kernel) the compiler cannot tell and would emit flat_load through a 64-bit per-lane address (a v_lshl_add_u64 per
+// array and chunk, and a wait on the LDS counter with every load).
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef const f64x2 __attribute__((address_space(1))) *global_pairs;
+__device__ __forceinline__ global_pairs lane_ptr(const double *uniform_base, int lane)
 {
     unsigned off = (unsigned)lane * 16u;
     asm volatile("" : "+v"(off));
-    return reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(uniform_base) + (size_t)off);
+    return reinterpret_cast<global_pairs>(reinterpret_cast<const char __attribute__((address_space(1))) *>((uintptr_t)uniform_base) + (size_t)off);
+}
+// ... and a wave-uniform table in global memory (the chunks' [min, max] of w): scalar loads
+__device__ __forceinline__ double2 global_table(const double2 *p, int64_t i)
+{
+    const f64x2 d = reinterpret_cast<global_pairs>((uintptr_t)p)[i];
+    return make_double2(d.x, d.y);
 }
 
+// Sum over the wave's lanes, in lane 0 (the other lanes hold partial sums nobody reads): the tree x[l] += x[l + off],
+// off = 32, 16, ..., 1.  Below 32 the partner comes through ds_swizzle (lane l reads lane l ^ off: for the lanes that
+// still count, l < off, that IS lane l + off) -- no address arithmetic, where __shfl_down costs a compare, a select
+// and a shift-add per step, once per block of the grid (every chunk of a short grid).  Same operands, same order:
+// the same bits as the plain shuffle tree.
+template <int XOR>
+__device__ __forceinline__ double swizzle_xor(double x)
+{
+    constexpr int pattern = (XOR << 10) | 0x1f;   // bit-mask mode: and 0x1f, or 0, xor XOR (within 32 lanes)
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), pattern);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), pattern);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double x)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
+    x += __shfl_down(x, 32, kWave);
+    x += swizzle_xor<16>(x);
+    x += swizzle_xor<8>(x);
+    x += swizzle_xor<4>(x);
+    x += swizzle_xor<2>(x);
+    x += swizzle_xor<1>(x);
     return x;
 }
 

@@ -125,6 +125,8 @@ __device__ __forceinline__ void objective_body(
     constexpr bool kStage = (VARIANT == NMRFIT_VARIANT_STAGED);
     // STAGED: w of the NEXT chunk is requested in the epilogue of the current one, the first chunk's before the
     // prologue's barrier (measured on its own for the selectable kernels in round 4: slower everywhere, not kept)
+    // (round 5, the same prefetch alone in the one-particle-per-wave kernels of the device batches, where a chunk of six
+    // peaks is short: the eight values cost the direct kernel 56 bytes of scratch per lane at its 128 registers, -5 %)
     constexpr bool kPrefW = kStage;
     // per-wave table of block seeds (<= 16 blocks per grid); the shared-prologue area (rotation step,
     // per-lane phase seeds, flags); then (kStage) the per-wave staging area for one chunk of u, v,
@@ -242,11 +244,13 @@ __device__ __forceinline__ void objective_body(
             int elo = pos ? ilogb(ia) : -100000;
             if (ehi > 100000) ehi = 100000;                              // inf / overflow
             if (!have) ehi = elo = 0;                                    // beyond the last peak: no factor
-#pragma unroll
-            for (int m = 1; m < 8; m <<= 1) {
-                ehi += __shfl_xor(ehi, m, kWave);
-                elo += __shfl_xor(elo, m, kWave);
-            }
+            // (sums over the aligned groups of eight lanes: ds_swizzle, lane l reads lane l ^ m)
+            ehi += __builtin_amdgcn_ds_swizzle(ehi, (1 << 10) | 0x1f);
+            elo += __builtin_amdgcn_ds_swizzle(elo, (1 << 10) | 0x1f);
+            ehi += __builtin_amdgcn_ds_swizzle(ehi, (2 << 10) | 0x1f);
+            elo += __builtin_amdgcn_ds_swizzle(elo, (2 << 10) | 0x1f);
+            ehi += __builtin_amdgcn_ds_swizzle(ehi, (4 << 10) | 0x1f);
+            elo += __builtin_amdgcn_ds_swizzle(elo, (4 << 10) | 0x1f);
             // every group of (up to) 8 peaks must have positive amplitudes and a denominator that
             // stays within 2^+-1000 for kBatchInv points; ONE flag per particle -- all groups
             // qualify or none does -- keeps the chunk loop free of a per-group branch (whose two

@@ -258,8 +258,10 @@ __device__ __forceinline__ bool swarm_prologue_wave(const PsoFused &upd, double 
     if (upd.pending != 0u) {
         // ---- deferred fold: first index of the minimum over this swarm's fp (np.argmin), four loads in flight per lane
         const auto fpb = gp + S * D;
+        // (indices as 32-bit integers -- S is a launch-checked int -- and the partners below lane 32 through ds_swizzle:
+        // lane l reads lane l ^ off, which for the lanes that still count, l < off, is lane l + off)
         double best = INFINITY;
-        long long bi = 0x7fffffffffffffffLL;
+        int bi32 = 0x7fffffff;
         for (int64_t b0 = 0; b0 < S; b0 += 4 * kWave) {
             double vv[4];
 #pragma unroll
@@ -271,20 +273,23 @@ __device__ __forceinline__ bool swarm_prologue_wave(const PsoFused &upd, double 
             for (int k = 0; k < 4; ++k)
                 if (vv[k] < best) {   // strict: the lowest index wins ties within a lane (indices ascend)
                     best = vv[k];
-                    bi = b0 + (long long)k * kWave + lane;
+                    bi32 = (int)b0 + k * kWave + lane;
                 }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ob = __shfl_down(best, off, kWave);
-            const long long oi = __shfl_down(bi, off, kWave);
-            if (lex_less(ob, oi, best, bi)) {
+        auto take = [&](const double ob, const int oi) {
+            if (ob < best || (ob == best && oi < bi32)) {
                 best = ob;
-                bi = oi;
+                bi32 = oi;
             }
-        }
+        };
+        take(__shfl_down(best, 32, kWave), __shfl_down(bi32, 32, kWave));
+        take(swizzle_xor<16>(best), __builtin_amdgcn_ds_swizzle(bi32, (16 << 10) | 0x1f));
+        take(swizzle_xor<8>(best), __builtin_amdgcn_ds_swizzle(bi32, (8 << 10) | 0x1f));
+        take(swizzle_xor<4>(best), __builtin_amdgcn_ds_swizzle(bi32, (4 << 10) | 0x1f));
+        take(swizzle_xor<2>(best), __builtin_amdgcn_ds_swizzle(bi32, (2 << 10) | 0x1f));
+        take(swizzle_xor<1>(best), __builtin_amdgcn_ds_swizzle(bi32, (1 << 10) | 0x1f));
         const double fc = wave_uniform(best);
-        bi = (long long)__builtin_amdgcn_readfirstlane((int)bi);   // (an index below 2^31: S is a launch-checked int)
+        long long bi = (long long)__builtin_amdgcn_readfirstlane(bi32);
         if (bi >= S || bi < 0) bi = 0;   // every fp is +inf: np.argmin -> 0, and the row is x[0] (pso.hip, argmin_block)
         const auto src = (fc < INFINITY) ? gp + bi * D : gx_in;
         const double c0 = have0 ? src[lane] : 0.0;   // the second (and last) round trip of the prologue
@@ -311,8 +316,7 @@ __device__ __forceinline__ bool swarm_prologue_wave(const PsoFused &upd, double 
                 acc += df * df;
             }
             if (stop_code == 0 && fc < fg) {
-                for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-                acc = __shfl(acc, 0, 64);
+                acc = wave_uniform(wave_sum(acc));   // (the same tree as pso.hip's shuffle loop: x[l] += x[l + off])
                 const double stepsize = sqrt(acc);
                 if (fabs(fg - fc) <= upd.minfunc)
                     code = 1;

@@ -913,8 +913,9 @@ def main():
                                    "stopping_rule_off runs all 2000 generations of every fit (the work of "
                                    "reference_default_fit x %d), stopping_rule_on is pyswarm's rule with its defaults "
                                    "(1e-8): every fit stops on its own.  Ceiling of the rule-off case by instruction count: "
-                                   "~4800 fp64 VALU instructions per particle and generation (profiles/r05) -> ~285 fits/s "
-                                   "at full issue rate" % (Kb, Kb))
+                                   "~4500 fp64 VALU instructions per particle and generation (profiles/r05/batch_instr_model.txt) "
+                                   "-> ~330 fits/s if every issue slot of a 2.4 GHz clock were used; the kernel holds ~0.8 "
+                                   "of that, like the headline kernel" % (Kb, Kb))
         except Exception as e:      # reported, never fatal for the headline
             batched_fit = {"error": repr(e)}
     # the host-pointer entry point (X uploaded, f downloaded every call): the PCIe-inclusive

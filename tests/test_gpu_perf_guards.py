@@ -63,8 +63,8 @@ def test_one_launch_generations_stay_fast(S, N, P, limit_us):
 
 @pytest.mark.xfail(strict=False, reason="wall-clock guard, non-gating")
 def test_device_batched_default_fits_stay_fast():
-    """40 default fits (204 x 4096 x 6) as one device batch, stopping rule off: round 5 measured 2.0-2.3 us per fit and
-    generation (217-242 fits/s; four host threads with a context each, round 4: 94 fits/s = 5.3 us)."""
+    """40 default fits (204 x 4096 x 6) as one device batch, stopping rule off: round 5 measured 1.9-2.3 us per fit and
+    generation (217-262 fits/s; four host threads with a context each, round 4: 94 fits/s = 5.3 us)."""
     import time
     from nmrfit_amd import synth
     from nmrfit_amd.batch import FitBatch

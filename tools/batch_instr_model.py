@@ -14,7 +14,7 @@ for sub in sorted(glob.glob(os.path.join(d, "n*_p*"))):
         continue
     m = re.match(r"n(\d+)_p(\d+)$", os.path.basename(sub))
     N, P = int(m.group(1)), int(m.group(2))
-    fs = glob.glob(os.path.join(sub, "*", "*_counter_collection.csv"))
+    fs = sorted(glob.glob(os.path.join(sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)   # newest run
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[-1])):
         if "objective_batch_kernel" in r["Kernel_Name"]:

@@ -12,7 +12,11 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 prefix = sys.argv[3] if len(sys.argv) > 3 else "bench_c3"
 os.makedirs(dst, exist_ok=True)
-stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1]
+def total_ns(path):     # (the bench's child processes write stats files of their own: the main process ran longest)
+    return sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(path)))
+
+
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=total_ns)
 shutil.copy(stats, os.path.join(dst, prefix + "_kernel_stats.csv"))
 keep = ["Dispatch_Id", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
         "Counter_Name", "Counter_Value"]

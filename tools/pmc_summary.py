@@ -14,9 +14,14 @@ def main():
     d = sys.argv[1]
     kname = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "objective_kernel"
     out = {"kernel": kname}
+    def total_ns(path):
+        return sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(path)))
+    # (newest run of this tag; a bench run's child processes write stats files of their own -- the main process ran longest)
     st = sorted(glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if st:
-        rows = list(csv.DictReader(open(st[-1])))     # newest run of this tag
+        newest = os.path.getmtime(st[-1])
+        st = [max((f for f in st if newest - os.path.getmtime(f) < 600), key=total_ns)]
+        rows = list(csv.DictReader(open(st[-1])))
         def short(n):      # "void nmrfit::(anonymous namespace)::objective_kernel<0, false, 0, 4>(double const*, ...)"
             n = n.replace("nmrfit::(anonymous namespace)::", "").replace("void ", "")
             return n.split("(")[0][-60:]

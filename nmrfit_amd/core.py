@@ -43,7 +43,9 @@ def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, **kwargs):
     * ``batch=True`` (default): jobs of equal grid length, swarm size, kernel variant and ``fit_im`` are fitted as
       ONE device batch -- one kernel launch per swarm generation for all of them (nmrfit_amd.batch.FitBatch,
       csrc/batch.hip).  A 204-particle swarm fills a fraction of an MI355X; a batch fills it.  Each fit's ``params`` and
-      ``error`` are bit-identical to what ``fit`` returns for it alone with the same ``options['seed']``.
+      ``error`` are bit-identical to what ``fit`` returns for it alone with the same ``options['seed']``.  Long job
+      lists go through batches of about ``nmrfit_amd.core.BATCH_JOBS`` (64) jobs: a second host thread prepares the next
+      batch (error weights, plans, device state) while the device runs the current one.
     * whatever cannot be batched (``polish``, a lone shape, more than 132 peaks) runs through ``fit`` on ``threads`` host
       threads, each fit with its own context and HIP stream -- serially when ``options['exchange']`` is given: a
       communicator serves one swarm at a time.
@@ -145,6 +147,12 @@ def _cabi_device_count():
     return _cabi.device_count()
 
 
+# Jobs per device batch in fit_many.  From ~40 default-size fits on a batch holds the MI355X's issue rate
+# (DESIGN.md 4.5), so longer job lists are cut into batches of about this many: the host prepares batch c + 1
+# (error weights, plans, the batch's device state) on a second thread while the device runs batch c.
+BATCH_JOBS = 64
+
+
 def _fit_many_local(jobs, threads, batch, kwargs):
     from concurrent.futures import ThreadPoolExecutor
     fits = []
@@ -153,18 +161,57 @@ def _fit_many_local(jobs, threads, batch, kwargs):
         fits.append(utils.FitUtility(args.pop("data"), args.pop("lower"), args.pop("upper"), **args))
     alone = list(range(len(fits)))
     if batch and len(fits) > 1:
-        plans = [f._plan() for f in fits]
-        groups = {}
-        for i, (f, plan) in enumerate(zip(fits, plans)):
-            key = f._batch_key(plan)
-            if key is not None:
-                groups.setdefault(key, []).append(i)
-        alone = []
+        n = len(fits)
+        nspans = -(-n // BATCH_JOBS)
+        size = -(-n // nspans)
+        spans = [range(a, min(a + size, n)) for a in range(0, n, size)]
+
+        def prepare(span):
+            """Plans of the span's fits, its device batches ready to run, and what found no partner in the span."""
+            plans = {i: fits[i]._plan() for i in span}
+            groups = {}
+            for i in span:
+                groups.setdefault(fits[i]._batch_key(plans[i]), []).append(i)
+            ready, single = [], []
+            for key, idx in groups.items():
+                if key is not None and len(idx) > 1:
+                    ready.append(_batch_create([fits[i] for i in idx], [plans[i] for i in idx], key) + (idx,))
+                else:
+                    single.extend((i, key, plans[i]) for i in idx)
+            return ready, single
+
+        leftover = []
         batched = set()
-        for key, idx in groups.items():
-            if len(idx) > 1:
-                _fit_batch([fits[i] for i in idx], [plans[i] for i in idx], key)
-                batched.update(idx)
+        with ThreadPoolExecutor(max_workers=1) as host:
+            pending = host.submit(prepare, spans[0])
+            try:
+                for c in range(len(spans)):
+                    ready, single = pending.result()
+                    pending = host.submit(prepare, spans[c + 1]) if c + 1 < len(spans) else None
+                    leftover.extend(single)
+                    while ready:
+                        fb, bfits, bplans, key, idx = ready.pop(0)
+                        _batch_finish(fb, bfits, bplans, key)
+                        batched.update(idx)
+            except BaseException:
+                if pending is not None:      # (batches made for a span that will not run)
+                    try:
+                        for made in pending.result()[0]:
+                            made[0].close()
+                    except Exception:
+                        pass
+                for made in locals().get("ready", []):
+                    made[0].close()
+                raise
+        # what found no partner inside its span may have one in another
+        groups = {}
+        for i, key, plan in leftover:
+            if key is not None:
+                groups.setdefault(key, []).append((i, plan))
+        for key, members in groups.items():
+            if len(members) > 1:
+                _fit_batch([fits[i] for i, _ in members], [plan for _, plan in members], key)
+                batched.update(i for i, _ in members)
         alone = [i for i in range(len(fits)) if i not in batched]
     if not alone:
         return fits
@@ -178,16 +225,27 @@ def _fit_many_local(jobs, threads, batch, kwargs):
     return fits
 
 
+def _batch_create(fits, plans, key):
+    """The device state of one batch (spectra, weights, boxes, swarms) -- everything up to the first launch."""
+    from .batch import FitBatch
+    device, _, swarmsize, variant, _, _, fit_im = key
+    spectra = [(f.data.w, f.data.u, f.data.v, f.weights) for f in fits]
+    kw = {name: [p['kw'][name] for p in plans] for name in ("omega", "phip", "phig", "minstep", "minfunc")}
+    fb = FitBatch(spectra, [f.lower for f in fits], [f.upper for f in fits], swarmsize=swarmsize,
+                  seeds=[p['seed'] for p in plans], variant=variant, fit_im=fit_im, device=device, **kw)
+    return fb, fits, plans, key
+
+
 def _fit_batch(fits, plans, key):
     """One device batch: FitBatch over the fits' spectra, run to the common maxiter, results into the FitUtility objects
     (what FitUtility.fit does for one, utils.py:164-189)."""
-    from .batch import FitBatch
+    _batch_finish(*_batch_create(fits, plans, key))
+
+
+def _batch_finish(fb, fits, plans, key):
     from .pso import STOP_MESSAGES
-    device, _, swarmsize, variant, maxiter, check_every, fit_im = key
-    spectra = [(f.data.w, f.data.u, f.data.v, f.weights) for f in fits]
-    kw = {name: [p['kw'][name] for p in plans] for name in ("omega", "phip", "phig", "minstep", "minfunc")}
-    with FitBatch(spectra, [f.lower for f in fits], [f.upper for f in fits], swarmsize=swarmsize,
-                  seeds=[p['seed'] for p in plans], variant=variant, fit_im=fit_im, device=device, **kw) as fb:
+    maxiter, check_every = key[4], key[5]
+    with fb:
         fb.run(maxiter, check_every)
         status = fb.status()
         best = fb.best()

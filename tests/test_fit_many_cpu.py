@@ -68,6 +68,45 @@ def test_jobs_with_a_communicator_run_one_after_another(monkeypatch):
     assert sorted(t for _, t in calls) == [0, 1, 2, 3, 4] and [f.options["tag"] for f in out] == [0, 1, 2, 3, 4]
 
 
+def test_long_job_lists_go_through_spans_and_leftovers_find_partners(monkeypatch):
+    """The host side of the pipeline (no device: the batch's creation and run are replaced): a list longer than
+    BATCH_JOBS is cut into spans of equal size, every span's groups of equal key become batches made on the second
+    thread and run on the calling one in span order, a job without a partner inside its span is batched with the
+    leftovers of the other spans, and what stays alone goes through fit()."""
+    monkeypatch.setattr(core, "BATCH_JOBS", 4)
+    made, ran, lone = [], [], []
+
+    class FakeBatch:
+        def close(self):
+            pass
+
+    def fake_create(fits, plans, key):
+        made.append((threading.get_ident(), [f.options["tag"] for f in fits]))
+        return FakeBatch(), fits, plans, key
+
+    def fake_finish(fb, fits, plans, key):
+        ran.append((threading.get_ident(), [f.options["tag"] for f in fits]))
+        for f in fits:
+            f.params, f.error = np.zeros(len(f.lower)), 0.0
+
+    def fake_fit(self):
+        lone.append(self.options["tag"])
+        self.params, self.error = np.zeros(len(self.lower)), 0.0
+    monkeypatch.setattr(core, "_batch_create", fake_create)
+    monkeypatch.setattr(core, "_batch_finish", fake_finish)
+    monkeypatch.setattr(utils.FitUtility, "fit", fake_fit)
+    # 10 jobs -> 3 spans of 4, 4, 2.  Grid lengths: span 0 = [A A A B], span 1 = [A A B C], span 2 = [A A]
+    lengths = [1024, 1024, 1024, 2048, 1024, 1024, 2048, 4096, 1024, 1024]
+    jobs = [_job(n, 2, 20 + k, options={"tag": k}) for k, n in enumerate(lengths)]
+    out = core.fit_many(jobs, threads=1)
+    assert [f.options["tag"] for f in out] == list(range(10)) and all(f.error == 0.0 for f in out)
+    me = threading.get_ident()
+    assert [tags for _, tags in ran] == [[0, 1, 2], [4, 5], [8, 9], [3, 6]]      # spans in order, then the leftovers' batch
+    assert all(tid == me for tid, _ in ran)                                      # the device is driven from the calling thread
+    assert [tags for _, tags in made[:3]] == [[0, 1, 2], [4, 5], [8, 9]] and all(tid != me for tid, _ in made[:3])
+    assert lone == [7]                                                           # the only 4096-point job
+
+
 def test_small_shard_warning():
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")

@@ -301,6 +301,24 @@ def test_full_length_default_fits_batched_equal_the_lone_fits():
         assert a.error == b.error
 
 
+def test_fit_many_in_several_batches_equals_the_plain_loop(monkeypatch):
+    """A job list longer than BATCH_JOBS: several device batches, the next one prepared on a second thread while the
+    current one runs, leftovers of the spans batched together -- every fit bit-identical to the plain loop."""
+    import nmrfit_amd
+    from nmrfit_amd import core
+    monkeypatch.setattr(core, "BATCH_JOBS", 5)
+    lengths = [1024] * 4 + [1536] + [1024] * 3 + [1536, 2048] + [1024] * 3       # 13 jobs: spans of 5, 5, 3
+    jobs = []
+    for k, n in enumerate(lengths):
+        sp = synth.make_spectrum(n, 2 + k % 3, seed=300 + k)
+        jobs.append(dict(data=synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"]), lower=list(sp["lower"]),
+                         upper=list(sp["upper"]), options={"seed": 50 + k, "swarmsize": 40, "maxiter": 60}))
+    many = nmrfit_amd.fit_many(jobs)
+    for k, job in enumerate(jobs):
+        one = nmrfit_amd.fit(job["data"], job["lower"], job["upper"], summary=False, options=job["options"])
+        assert np.array_equal(many[k].params, one.params) and many[k].error == one.error, k
+
+
 def test_fit_many_over_the_devices_of_one_process():
     """fit_many(jobs, devices=[...]): a host thread per device, job k on devices[k % n], each share a device batch of
     its own -- rehearsed with the one card listed twice: same results as the plain call, in job order."""

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NMRFIT_ABI_VERSION 5
+#define NMRFIT_ABI_VERSION 6
 
 enum {
     NMRFIT_OK = 0,
@@ -139,6 +139,16 @@ int nmrfit_residual_batch(nmrfit_ctx *ctx, int64_t B, int32_t P, const double *X
  * w_out == NULL evaluates on the context's own grid (Nout is then ignored and taken as N). */
 int nmrfit_contributions(nmrfit_ctx *ctx, int32_t P, const double *x, int64_t Nout, const double *w_out,
                          double *real_out, double *imag_out);
+/* The whole of FitUtility.generate_result for one parameter vector (ABI 6; nmrfit/utils.py:226-295), one launch.  Besides
+ * the per-peak contributions above (real_out / imag_out: both or neither), any of which may be NULL:
+ *   fit_out   4 x Nout: V_fit and I_fit, the contributions summed peak after peak from zero (utils.py:276-277), then
+ *             u_fit and v_fit = ps2(V_fit, I_fit, inv=True, p0, p1) (utils.py:284; nmrfit/proc_autophase.py:9-36: the
+ *             phase ramp p0 + (p1 j)/Nout runs over the index of the OUTPUT grid)
+ *   data_out  2 x N: V, I = ps2(u, v, p0, p1) of the context's spectrum -- what data.shift_phase(method='manual', p0, p1)
+ *             stores (utils.py:251; nmrfit/containers.py:68-78)
+ * with p0, p1 = x[0], x[1]. */
+int nmrfit_generate_result(nmrfit_ctx *ctx, int32_t P, const double *x, int64_t Nout, const double *w_out,
+                           double *real_out, double *imag_out, double *fit_out, double *data_out);
 
 /* device-pointer forms (asynchronous on the context's stream) */
 int nmrfit_objective_batch_dev(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, double *df_out);
@@ -245,6 +255,16 @@ int nmrfit_batch_destroy(nmrfit_batch *batch);
 int nmrfit_batch_run(nmrfit_batch *batch, int64_t maxiter, int32_t check_every);
 int nmrfit_batch_status(nmrfit_batch *batch, int64_t *iteration, int32_t *stop_code, double *fg);
 int nmrfit_batch_best(nmrfit_batch *batch, double *x_best, double *f_best);
+/* FitUtility.generate_result (nmrfit/utils.py:226-295; README.md:64-72: fit -> generate_result) for EVERY fit of the
+ * batch at its best position, ONE launch over the batch's resident grids and best rows (ABI 6) -- no context, no upload
+ * of spectra per fit.  Outputs as nmrfit_generate_result's, fit after fit:
+ *   w_out     NULL: every fit on its own grid (Nout ignored, taken as N); else K x Nout, fit k's output grid (the
+ *             reference's np.linspace(w.min(), w.max(), int(scale * N)), utils.py:236)
+ *   real_out, imag_out   (sum_k P[k]) x Nout, the peaks of fit 0, then of fit 1, ... (both or neither)
+ *   fit_out   K x 4 x Nout (V_fit, I_fit, u_fit, v_fit of each fit);  data_out  K x 2 x N (V, I of each spectrum)
+ * Every value is bit-identical to what nmrfit_generate_result returns for that fit alone. */
+int nmrfit_batch_contributions(nmrfit_batch *batch, int64_t Nout, const double *w_out, double *real_out, double *imag_out,
+                               double *fit_out, double *data_out);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ VARIANT_DEFAULT, VARIANT_BASELINE, VARIANT_NOSKIP, VARIANT_SINGLE, VARIANT_QUAD,
 VARIANT_NOREC = 7
 VARIANT_FARFIELD32 = 8     # opt-in mixed precision: the far-field kernel's shared polynomial in packed fp32
 HANDOVER_FAST, HANDOVER_FENCED, HANDOVER_TWO_LAUNCH = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 _VARIANT_NAMES = {"default": 0, "baseline": 1, "noskip": 2, "single": 3, "quad": 4, "staged": 5, "farfield": 6,
                   "norec": 7, "farfield32": 8}
 
@@ -75,6 +75,7 @@ ALL_SIGNATURES = {
     "nmrfit_objective_batch": [_VP, _I64, _I32, _VP, _INT, _VP],
     "nmrfit_residual_batch": [_VP, _I64, _I32, _VP, _VP, _VP],
     "nmrfit_contributions": [_VP, _I32, _VP, _I64, _VP, _VP, _VP],
+    "nmrfit_generate_result": [_VP, _I32, _VP, _I64, _VP, _VP, _VP, _VP, _VP],
     "nmrfit_objective_batch_dev": [_VP, _I64, _I32, _VP, _VP],
     "nmrfit_residual_batch_dev": [_VP, _I64, _I32, _VP, _VP, _VP],
     "nmrfit_dev_alloc": [_VP, _I64, _c_void_pp],
@@ -122,6 +123,7 @@ ALL_SIGNATURES = {
     "nmrfit_batch_run": [_VP, _I64, _I32],
     "nmrfit_batch_status": [_VP, _VP, _VP, _VP],
     "nmrfit_batch_best": [_VP, _VP, _VP],
+    "nmrfit_batch_contributions": [_VP, _I64, _VP, _VP, _VP, _VP, _VP],
     "nmrfit_batch_step": [_VP],
     "nmrfit_batch_synchronize": [_VP],
     "nmrfit_batch_set_geometry": [_VP, _INT],

@@ -39,6 +39,7 @@ class FitBatch:
             raise ValueError("FitBatch: as many boxes as spectra, at least one")
         N = len(spectra[0][0])
         planes = [np.empty((K, N)) for _ in range(4)]
+        self._w_range = [(np.min(sp[0]), np.max(sp[0])) for sp in spectra]      # (generate: the upsampled grids' ends)
         for k, sp in enumerate(spectra):
             if any(len(a) != N for a in sp):
                 raise ValueError("FitBatch: every spectrum of a batch has the same length (fit %d differs)" % k)
@@ -113,6 +114,39 @@ class FitBatch:
         f = np.empty(self.K)
         _cabi.check(self._lib.nmrfit_batch_best(self._h, _cabi.ptr(x), _cabi.ptr(f)))
         return [(x[self.offsets[k]:self.offsets[k + 1]].copy(), float(f[k])) for k in range(self.K)]
+
+    def generate(self, scale=1, grids=None):
+        """FitUtility.generate_result for every fit of the batch at its best position (nmrfit/utils.py:226-295), ONE launch
+        from the batch's resident spectra.  ``scale`` == 1: on each fit's own grid; else on
+        ``np.linspace(w.min(), w.max(), int(scale * N))`` per fit (utils.py:236; ``grids``: the K output grids, K x Nout,
+        if the caller has them).  Returns per fit a dict with ``w`` (None when scale == 1: the fit's own grid), ``real``,
+        ``imag`` ([P_k, Nout] each), ``V, I, u, v`` (the fit: utils.py:276-284) and ``data_V, data_I`` (the spectrum rotated
+        by the fitted phase, what data.shift_phase(method='manual') stores, utils.py:251) -- all views of four arrays."""
+        K, N = self.K, self.N
+        if scale == 1.0 and grids is None:
+            wout, n = None, N
+        else:
+            if grids is None:
+                n = int(scale * N)
+                grids = np.stack([np.linspace(lo, hi, n) for lo, hi in self._w_range])
+            wout = _cabi.f64(grids)
+            if wout.ndim != 2 or wout.shape[0] != K:
+                raise ValueError("FitBatch.generate: grids must be K x Nout")
+            n = wout.shape[1]
+        rows = int(self.P.sum())
+        real = np.empty((rows, n))
+        imag = np.empty((rows, n))
+        fit = np.empty((K, 4, n))
+        data = np.empty((K, 2, N))
+        _cabi.check(self._lib.nmrfit_batch_contributions(self._h, n, _cabi.ptr(wout), _cabi.ptr(real), _cabi.ptr(imag),
+                                                         _cabi.ptr(fit), _cabi.ptr(data)))
+        out, row = [], 0
+        for k in range(K):
+            p = int(self.P[k])
+            out.append(dict(w=None if wout is None else wout[k], real=real[row:row + p], imag=imag[row:row + p],
+                            V=fit[k, 0], I=fit[k, 1], u=fit[k, 2], v=fit[k, 3], data_V=data[k, 0], data_I=data[k, 1]))
+            row += p
+        return out
 
     # -- diagnostics (include/nmrfit_amd_diag.h) ----------------------------------------------------
     def step(self):

@@ -31,7 +31,7 @@ def fit(data, lower, upper, expon=0.5, dynamic_weighting=True, fit_im=False, pro
     return f
 
 
-def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, **kwargs):
+def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, generate=False, **kwargs):
     """Fit several spectra: ``jobs`` is a sequence of ``(data, lower, upper)`` triples (or dicts of ``fit``'s
     arguments); every job is fitted as ``fit`` would fit it with the same keyword arguments, and the list of
     FitUtility objects comes back in the order of ``jobs``.  Not in the reference (its users loop over
@@ -44,15 +44,25 @@ def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, **kwargs):
       ONE device batch -- one kernel launch per swarm generation for all of them (nmrfit_amd.batch.FitBatch,
       csrc/batch.hip).  A 204-particle swarm fills a fraction of an MI355X; a batch fills it.  Each fit's ``params`` and
       ``error`` are bit-identical to what ``fit`` returns for it alone with the same ``options['seed']``.  Long job
-      lists go through batches of about ``nmrfit_amd.core.BATCH_JOBS`` (64) jobs: a second host thread prepares the next
-      batch (error weights, plans, device state) while the device runs the current one.
-    * whatever cannot be batched (``polish``, a lone shape, more than 132 peaks) runs through ``fit`` on ``threads`` host
-      threads, each fit with its own context and HIP stream -- serially when ``options['exchange']`` is given: a
-      communicator serves one swarm at a time.
+      lists go through batches of about ``nmrfit_amd.core.BATCH_JOBS`` (64) jobs, three stages in flight: a second host
+      thread prepares the next batch (error weights, plans, device state) while the device runs the current one and a
+      third reads back the one before.
+    * ``generate=True`` (or a number: the ``scale`` of ``FitUtility.generate_result``): the rest of the reference's
+      per-spectrum script, README.md:64-72 -- every returned fit has had ``generate_result(scale)`` called on it
+      (nmrfit/utils.py:226-295: ``u, v, V, I, w, real_contribs, imag_contribs``; ``calculate_area_fraction()`` then
+      needs nothing more).  For the fits of a device batch that is ONE launch over the batch's resident spectra and best
+      positions (nmrfit_batch_contributions, csrc/result.hip) instead of a context, four uploads and a launch per fit;
+      the values are bit-identical to the lone call's.  The data objects get ``p0, p1, V, I`` set to what
+      ``data.shift_phase(method='manual', p0, p1)`` computes (nmrfit/containers.py:68-78) from the same launch; the
+      method itself is called only on the lone path.
+    * whatever cannot be batched (``polish``, a lone shape, more than 132 peaks, a batch the device refuses) runs
+      through ``fit`` on ``threads`` host threads, each fit with its own context and HIP stream -- serially when
+      ``options['exchange']`` is given: a communicator serves one swarm at a time.
     * ``shard=True`` in a multi-GPU launch (one process per GPU, RANK / WORLD_SIZE / LOCAL_RANK set by the launcher):
       the JOBS are divided over the ranks -- rank r takes jobs r, r + world, ... on its own GPU -- and the results are
-      gathered so that every rank returns the full list.  Replicas: no collective touches the fits themselves.  This is
-      the multi-GPU mode for many small fits (sharding one 204-particle swarm over GPUs is slower than one GPU).
+      gathered so that every rank returns the full list (``params``, ``error``, ``seed``; the arrays of ``generate`` stay
+      on the rank that made them).  Replicas: no collective touches the fits themselves.  This is the multi-GPU mode
+      for many small fits (sharding one 204-particle swarm over GPUs is slower than one GPU).
     * ``devices=[0, 1, ...]`` (or ``"all"``): the same replicas WITHOUT a launcher -- this one process drives several
       GPUs, a host thread per device, job k on ``devices[k % len(devices)]``; each device runs its share as device
       batches of its own.  Nothing crosses devices.  (``shard`` and ``devices`` exclude each other.)"""
@@ -69,13 +79,13 @@ def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, **kwargs):
         devices = [int(d) for d in devices]
         if not devices:
             raise ValueError("fit_many: no devices")
-        return _fit_many_devices(jobs, threads, batch, kwargs, devices)
+        return _fit_many_devices(jobs, threads, batch, kwargs, devices, generate)
     if shard:
         from . import rendezvous
         rank, _, world = rendezvous.env_rank_world()
         if world > 1:
-            return _fit_many_sharded(jobs, threads, batch, kwargs, rank, world)
-    return _fit_many_local(jobs, threads, batch, kwargs)
+            return _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, generate=generate)
+    return _fit_many_local(jobs, threads, batch, kwargs, generate)
 
 
 def _result_record(f):
@@ -83,7 +93,19 @@ def _result_record(f):
     return dict(params=list(map(float, f.params)), error=float(f.error), seed=getattr(f, "seed", None))
 
 
-def _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, channel=None, local=None):
+def _with_device(job, shared_options, device, force=False):
+    """The job with ``device`` in ITS OWN options: a job's ``options`` dict replaces the shared one when the two are
+    merged (dict(kwargs, **job)), so a device that only sits in the shared options is lost for every job that brings a
+    seed or a maxiter.  ``force``: the caller assigns the device (devices=[...]); otherwise a device the job or the
+    shared options name wins."""
+    opts = dict(shared_options)
+    opts.update(job.get("options") or {})
+    if force or opts.get("device") is None:
+        opts["device"] = device
+    return dict(job, options=opts)
+
+
+def _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, channel=None, local=None, generate=False):
     """Jobs r, r + world, ... on this rank's GPU; every rank returns every result (the other ranks' as FitUtility
     objects holding ``params`` / ``error`` / ``seed``; their ``weights`` are recomputed on demand only by ``fit``)."""
     import json
@@ -96,14 +118,17 @@ def _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, channel=None, l
             sys.stderr.write("nmrfit: %s\n" % note)
 
         def local(my_jobs):
-            opts = dict(kwargs.get("options", {}))
-            opts.setdefault("device", device)
-            return _fit_many_local(my_jobs, threads, batch, dict(kwargs, options=opts))
-    done = local([jobs[i] for i in mine])
+            return _fit_many_local(my_jobs, threads, batch, kwargs, generate)
+    else:
+        device = None
+    # the ranks meet BEFORE they fit: a mis-launched world shows at once, and the channel's connect deadline does not
+    # have to cover the slowest rank's share of the work
     own = channel is None
     if own:
         channel = rendezvous.Channel()
     try:
+        shared = kwargs.get("options") or {}
+        done = local([_with_device(jobs[i], shared, device) if device is not None else jobs[i] for i in mine])
         # (JSON, not pickle: what arrives from another rank is data, never code; repr round-trips a float64 exactly)
         parts = channel.all_gather(json.dumps([[i, _result_record(f)] for i, f in zip(mine, done)]).encode())
     finally:
@@ -124,16 +149,16 @@ def _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, channel=None, l
     return out
 
 
-def _fit_many_devices(jobs, threads, batch, kwargs, devices):
+def _fit_many_devices(jobs, threads, batch, kwargs, devices, generate=False):
     """Job k on devices[k % len(devices)], one host thread per device (the library releases the GIL inside its calls;
     every call binds its own device), results back in job order."""
     from concurrent.futures import ThreadPoolExecutor
     shares = [list(range(i, len(jobs), len(devices))) for i in range(len(devices))]
+    shared = kwargs.get("options") or {}
 
     def one(i):
-        opts = dict(kwargs.get("options", {}), device=devices[i])
-        mine = [dict(jobs[k], options=dict(opts, **jobs[k].get("options", {}), device=devices[i])) for k in shares[i]]
-        return _fit_many_local(mine, threads, batch, dict(kwargs, options=opts))
+        mine = [_with_device(jobs[k], shared, devices[i], force=True) for k in shares[i]]
+        return _fit_many_local(mine, threads, batch, kwargs, generate)
     out = [None] * len(jobs)
     with ThreadPoolExecutor(max_workers=len(devices)) as pool:
         for idx, res in zip(shares, pool.map(one, range(len(devices)))):
@@ -149,16 +174,20 @@ def _cabi_device_count():
 
 # Jobs per device batch in fit_many.  From ~40 default-size fits on a batch holds the MI355X's issue rate
 # (DESIGN.md 4.5), so longer job lists are cut into batches of about this many: the host prepares batch c + 1
-# (error weights, plans, the batch's device state) on a second thread while the device runs batch c.
+# (error weights, plans, the batch's device state) on a second thread while the device runs batch c and a third thread
+# reads back batch c - 1 (status, best positions, the reconstruction of generate=...).
 BATCH_JOBS = 64
 
 
-def _fit_many_local(jobs, threads, batch, kwargs):
+def _fit_many_local(jobs, threads, batch, kwargs, generate=False):
     from concurrent.futures import ThreadPoolExecutor
+    from ._cabi import NmrfitError
+    scale = 1 if generate is True else generate      # (False: no reconstruction)
     fits = []
     for job in jobs:
         args = dict(kwargs, **job)
         fits.append(utils.FitUtility(args.pop("data"), args.pop("lower"), args.pop("upper"), **args))
+    plans = {}
     alone = list(range(len(fits)))
     if batch and len(fits) > 1:
         n = len(fits)
@@ -166,62 +195,80 @@ def _fit_many_local(jobs, threads, batch, kwargs):
         size = -(-n // nspans)
         spans = [range(a, min(a + size, n)) for a in range(0, n, size)]
 
-        def prepare(span):
-            """Plans of the span's fits, its device batches ready to run, and what found no partner in the span."""
-            plans = {i: fits[i]._plan() for i in span}
+        def group(members):
+            """Device batches of the members that have a partner, ready to run; the others as (index, key)."""
             groups = {}
-            for i in span:
-                groups.setdefault(fits[i]._batch_key(plans[i]), []).append(i)
+            for i, key in members:
+                groups.setdefault(key, []).append(i)
             ready, single = [], []
             for key, idx in groups.items():
                 if key is not None and len(idx) > 1:
-                    ready.append(_batch_create([fits[i] for i in idx], [plans[i] for i in idx], key) + (idx,))
-                else:
-                    single.extend((i, key, plans[i]) for i in idx)
+                    try:
+                        ready.append(_batch_create([fits[i] for i in idx], [plans[i] for i in idx], key) + (idx,))
+                        continue
+                    except NmrfitError:
+                        # the device refused this batch (LDS budget of its peak counts, memory): its fits run one by one
+                        key = None
+                single.extend((i, key) for i in idx)
             return ready, single
+
+        def prepare(span):
+            for i in span:
+                plans[i] = fits[i]._plan()
+            return group([(i, fits[i]._batch_key(plans[i])) for i in span])
 
         leftover = []
         batched = set()
-        with ThreadPoolExecutor(max_workers=1) as host:
+        made = []          # every batch created and not yet closed (closed by _batch_collect, or below on an error)
+        with ThreadPoolExecutor(max_workers=1) as host, ThreadPoolExecutor(max_workers=1) as post:
             pending = host.submit(prepare, spans[0])
+            posted = []
             try:
+                def run(ready):
+                    made.extend(r[0] for r in ready)
+                    for fb, bfits, bplans, key, idx in ready:
+                        fb.run(key[4], key[5])           # (maxiter, check_every): the device's generations, this thread
+                        posted.append(post.submit(_batch_collect, fb, bfits, bplans, key, scale))
+                        batched.update(idx)
                 for c in range(len(spans)):
                     ready, single = pending.result()
                     pending = host.submit(prepare, spans[c + 1]) if c + 1 < len(spans) else None
                     leftover.extend(single)
-                    while ready:
-                        fb, bfits, bplans, key, idx = ready.pop(0)
-                        _batch_finish(fb, bfits, bplans, key)
-                        batched.update(idx)
+                    run(ready)
+                # what found no partner inside its span may have one in another
+                ready, _ = group([(i, key) for i, key in leftover if key is not None])
+                run(ready)
+                for p in posted:
+                    p.result()
             except BaseException:
                 if pending is not None:      # (batches made for a span that will not run)
                     try:
-                        for made in pending.result()[0]:
-                            made[0].close()
+                        made.extend(r[0] for r in pending.result()[0])
                     except Exception:
                         pass
-                for made in locals().get("ready", []):
-                    made[0].close()
+                for p in posted:
+                    try:
+                        p.result()
+                    except Exception:
+                        pass
+                for fb in made:
+                    fb.close()
                 raise
-        # what found no partner inside its span may have one in another
-        groups = {}
-        for i, key, plan in leftover:
-            if key is not None:
-                groups.setdefault(key, []).append((i, plan))
-        for key, members in groups.items():
-            if len(members) > 1:
-                _fit_batch([fits[i] for i, _ in members], [plan for _, plan in members], key)
-                batched.update(i for i, _ in members)
         alone = [i for i in range(len(fits)) if i not in batched]
     if not alone:
         return fits
+
+    def lone(i):
+        fits[i].fit(plan=plans.get(i))
+        if scale is not False:
+            fits[i].generate_result(scale)
     with_exchange = any(fits[i].options.get("exchange") is not None for i in alone)
     if threads <= 1 or len(alone) <= 1 or with_exchange:
         for i in alone:
-            fits[i].fit()
+            lone(i)
         return fits
     with ThreadPoolExecutor(max_workers=int(threads)) as pool:
-        list(pool.map(lambda i: fits[i].fit(), alone))
+        list(pool.map(lone, alone))
     return fits
 
 
@@ -236,23 +283,35 @@ def _batch_create(fits, plans, key):
     return fb, fits, plans, key
 
 
-def _fit_batch(fits, plans, key):
+def _fit_batch(fits, plans, key, generate=False):
     """One device batch: FitBatch over the fits' spectra, run to the common maxiter, results into the FitUtility objects
-    (what FitUtility.fit does for one, utils.py:164-189)."""
-    _batch_finish(*_batch_create(fits, plans, key))
+    (what FitUtility.fit does for one, utils.py:164-189; with ``generate`` also what generate_result does)."""
+    fb, fits, plans, key = _batch_create(fits, plans, key)
+    try:
+        fb.run(key[4], key[5])
+    except BaseException:
+        fb.close()
+        raise
+    _batch_collect(fb, fits, plans, key, 1 if generate is True else generate)
 
 
-def _batch_finish(fb, fits, plans, key):
+def _batch_collect(fb, fits, plans, key, scale=False):
+    """What follows a batch's generations: stop codes, best positions and -- ``scale`` not False -- the reconstruction
+    of every fit in one launch (FitBatch.generate), stored into the FitUtility objects; closes the batch."""
     from .pso import STOP_MESSAGES
-    maxiter, check_every = key[4], key[5]
+    maxiter = key[4]
     with fb:
-        fb.run(maxiter, check_every)
         status = fb.status()
         best = fb.best()
-    for f, p, st, (x, fx) in zip(fits, plans, status, best):
+        results = fb.generate(scale) if scale is not False else None
+    for k, (f, p, st, (x, fx)) in enumerate(zip(fits, plans, status, best)):
         # (pyswarm's closing line, once per fit like the plain loop prints it)
         if st["stop"]:
             print(STOP_MESSAGES[st["stop"]].format(minfunc=p['kw']['minfunc'], minstep=p['kw']['minstep']))
         else:
             print('Stopping search: maximum iterations reached --> {:}'.format(maxiter))
         f._finish(x, fx)
+        if results is not None:
+            r = results[k]
+            f._store_result(f.data.w if r["w"] is None else r["w"], r["real"], r["imag"],
+                            (r["V"], r["I"], r["u"], r["v"]), (r["data_V"], r["data_I"]), call_shift_phase=False)

@@ -17,6 +17,7 @@
 // pending or not; + plain evaluation), so a generation costs the host one launch and no copies.
 #include "batch_internal.h"
 #include "nmrfit_amd_diag.h"
+#include "result_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -41,6 +42,10 @@ struct BatchPart {
     nmrfit::BatchFit *d_tables = nullptr;   // [9][K]: t = xp + 2 b + 4 pending (fused generations), 8 = plain evaluation
     double *d_summary = nullptr;         // [K][4]: generations, stop code, fg, best_f   (written by batch_tail_kernel)
     double *d_bestx = nullptr;           // [Dsum]: best_x rows, concatenated
+    std::vector<nmrfit::BatchFit> h_fits;   // host copy of table 0: every fit's array pointers and grid constants
+    int64_t Psum = 0;
+    // scratch of a reconstruction call in flight (nmrfit_batch_contributions): device block, and what goes where on the host
+    void *d_result = nullptr;
     // launch geometry: [0] workgroup = particle, [1] wave = particle
     nmrfit::BatchLaunch geom[2];
     bool geom_ok[2] = {false, false};
@@ -397,6 +402,7 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
         b->boff[(size_t)k] = b->Dsum;
         b->Dsum += b->D[(size_t)k];
         b->Pmax = std::max(b->Pmax, P[k]);
+        b->Psum += P[k];
     }
     for (int64_t d = 0; d < b->Dsum; ++d)
         if (!(upper[d] > lower[d])) {   // pyswarm: assert np.all(ub > lb)
@@ -541,6 +547,7 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
     }
     for (int t = 0; t < 8; ++t)
         for (int32_t k = 0; k < K; ++k) tabs[(size_t)t * (size_t)K + (size_t)k].upd.xrow_off = xrow_offset(b, b->mode);
+    b->h_fits.assign(tabs.begin(), tabs.begin() + K);
     BATCH_HIP(hipMemcpyAsync(b->d_tables, tabs.data(), tabs.size() * sizeof(BatchFit), hipMemcpyHostToDevice, b->stream));
     BATCH_HIP(hipMemcpyAsync(b->d_bestx + b->Dsum, b->boff.data(), (size_t)K * sizeof(int64_t), hipMemcpyHostToDevice, b->stream));
     // ---- spectra: four uploads, one scatter kernel, one chunk-table kernel
@@ -579,6 +586,7 @@ static int part_destroy(BatchPart *b)
     if (!b) return NMRFIT_OK;
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->d_result) (void)hipFree(b->d_result);
     if (b->d_block) (void)hipFree(b->d_block);
     if (b->stream) give_stream(b->device, b->stream);
     delete b;
@@ -669,6 +677,82 @@ static int part_best(BatchPart *b, double *x_best, double *f_best)
         NMRFIT_HIP(hipMemcpyAsync(x_best, b->d_bestx, (size_t)b->Dsum * sizeof(double), hipMemcpyDeviceToHost, b->stream));
         NMRFIT_HIP(hipStreamSynchronize(b->stream));
     }
+    return NMRFIT_OK;
+}
+
+
+// FitUtility.generate_result (nmrfit/utils.py:226-295) for every fit of the part at its best position: ONE launch of the
+// reconstruction kernel (result.hip) over the part's resident grids and best rows, enqueued on the part's stream with
+// the copies back to the host; part_contributions_finish waits for it.  The host pointers are this part's shares.
+static int part_contributions_enqueue(BatchPart *b, int64_t Nout, const double *w_out, double *real_out, double *imag_out,
+                                      double *fit_out, double *data_out)
+{
+    int rc = bind_batch(b);
+    if (rc != NMRFIT_OK) return rc;
+    if (!b->initialized) {
+        set_error("nmrfit_batch_contributions before the first generation");
+        return NMRFIT_E_STATE;
+    }
+    if (b->d_result) {
+        set_error("nmrfit_batch_contributions: a reconstruction of this batch is still in flight");
+        return NMRFIT_E_STATE;
+    }
+    if ((rc = flush_fold(b)) != NMRFIT_OK) return rc;   // (the tail launch leaves every fit's best row in d_bestx)
+    const int32_t K = b->K;
+    const int64_t N = b->N, Nn = w_out ? Nout : N;
+    const int64_t n_contrib = real_out ? b->Psum * Nn : 0, n_fit = fit_out ? (int64_t)K * 4 * Nn : 0,
+                  n_data = data_out ? (int64_t)K * 2 * N : 0, n_w = w_out ? (int64_t)K * Nout : 0;
+    if (2 * n_contrib + n_fit + n_data == 0) return NMRFIT_OK;
+    const size_t jobs_bytes = ((size_t)K * sizeof(ResultJob) + 255) & ~(size_t)255;
+    NMRFIT_HIP(hipMalloc(&b->d_result, jobs_bytes + (size_t)(n_w + 2 * n_contrib + n_fit + n_data) * sizeof(double)));
+    unsigned char *base = reinterpret_cast<unsigned char *>(b->d_result);
+    double *d_w = reinterpret_cast<double *>(base + jobs_bytes);
+    double *d_real = d_w + n_w, *d_imag = d_real + n_contrib, *d_fit = d_imag + n_contrib, *d_data = d_fit + n_fit;
+    std::vector<ResultJob> jobs((size_t)K);
+    int64_t prow = 0;
+    for (int32_t k = 0; k < K; ++k) {
+        const BatchFit &f = b->h_fits[(size_t)k];
+        ResultJob &j = jobs[(size_t)k];
+        j = ResultJob{};
+        j.wc = f.wc;
+        j.w_plain = w_out ? d_w + (int64_t)k * Nout : nullptr;
+        j.x = b->d_bestx + b->boff[(size_t)k];
+        j.u = f.u;
+        j.v = f.v;
+        j.w0 = f.w0;
+        j.wspan = f.wspan;
+        j.Nout = Nn;
+        j.N = N;
+        j.P = f.P;
+        j.real = real_out ? d_real + prow * Nn : nullptr;
+        j.imag = real_out ? d_imag + prow * Nn : nullptr;
+        j.fit = fit_out ? d_fit + (int64_t)k * 4 * Nn : nullptr;
+        j.data = data_out ? d_data + (int64_t)k * 2 * N : nullptr;
+        prow += f.P;
+    }
+    hipStream_t st = b->stream;
+    // (pageable host memory: the copy has left `jobs` when hipMemcpyAsync returns)
+    NMRFIT_HIP(hipMemcpyAsync(base, jobs.data(), (size_t)K * sizeof(ResultJob), hipMemcpyHostToDevice, st));
+    if (n_w) NMRFIT_HIP(hipMemcpyAsync(d_w, w_out, (size_t)n_w * sizeof(double), hipMemcpyHostToDevice, st));
+    if ((rc = launch_result_jobs(st, reinterpret_cast<const ResultJob *>(base), K, std::max(Nn, data_out ? N : 0), b->Pmax)) != NMRFIT_OK)
+        return rc;
+    if (n_contrib) {
+        NMRFIT_HIP(hipMemcpyAsync(real_out, d_real, (size_t)n_contrib * sizeof(double), hipMemcpyDeviceToHost, st));
+        NMRFIT_HIP(hipMemcpyAsync(imag_out, d_imag, (size_t)n_contrib * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if (n_fit) NMRFIT_HIP(hipMemcpyAsync(fit_out, d_fit, (size_t)n_fit * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (n_data) NMRFIT_HIP(hipMemcpyAsync(data_out, d_data, (size_t)n_data * sizeof(double), hipMemcpyDeviceToHost, st));
+    return NMRFIT_OK;
+}
+
+static int part_contributions_finish(BatchPart *b)
+{
+    if (!b->d_result) return NMRFIT_OK;
+    (void)hipSetDevice(b->device);
+    const hipError_t e = hipStreamSynchronize(b->stream);
+    (void)hipFree(b->d_result);
+    b->d_result = nullptr;
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(reconstruction)", __FILE__, __LINE__);
     return NMRFIT_OK;
 }
 
@@ -889,6 +973,33 @@ int nmrfit_batch_best(nmrfit_batch *b, double *x_best, double *f_best)
     for (size_t p = 0; rc == NMRFIT_OK && p < b->parts.size(); ++p) {
         const int32_t f0 = b->first[p];
         rc = part_best(b->parts[p], x_best ? x_best + b->boff[(size_t)f0] : nullptr, f_best ? f_best + f0 : nullptr);
+    }
+    return rc;
+}
+
+int nmrfit_batch_contributions(nmrfit_batch *b, int64_t Nout, const double *w_out, double *real_out, double *imag_out,
+                               double *fit_out, double *data_out)
+{
+    int rc = check_batch_handle(b);
+    if (rc != NMRFIT_OK) return rc;
+    if ((w_out && Nout <= 0) || (!real_out != !imag_out)) {
+        set_error("nmrfit_batch_contributions: Nout > 0 with an output grid; real_out and imag_out together or not at all");
+        return NMRFIT_E_INVALID;
+    }
+    // every part enqueues its launch and copies on its own stream, then all are waited for
+    int64_t prow = 0;
+    for (size_t p = 0; p < b->parts.size() && rc == NMRFIT_OK; ++p) {
+        BatchPart *q = b->parts[p];
+        const int32_t f0 = b->first[p];
+        const int64_t Nn = w_out ? Nout : q->N;
+        rc = part_contributions_enqueue(q, Nout, w_out ? w_out + (int64_t)f0 * Nout : nullptr, real_out ? real_out + prow * Nn : nullptr,
+                                        imag_out ? imag_out + prow * Nn : nullptr, fit_out ? fit_out + (int64_t)f0 * 4 * Nn : nullptr,
+                                        data_out ? data_out + (int64_t)f0 * 2 * q->N : nullptr);
+        prow += q->Psum;
+    }
+    for (BatchPart *q : b->parts) {
+        const int rc2 = part_contributions_finish(q);
+        if (rc == NMRFIT_OK) rc = rc2;
     }
     return rc;
 }

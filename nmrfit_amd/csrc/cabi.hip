@@ -3,6 +3,7 @@
 // device memory and HIP-event timing helpers.  No exception leaves this file.
 #include "nmrfit_internal.h"
 #include "nmrfit_amd_diag.h"
+#include "result_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -482,20 +483,26 @@ int nmrfit_objective_batch(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *
     return NMRFIT_OK;
 }
 
-int nmrfit_contributions(nmrfit_ctx *ctx, int32_t P, const double *x, int64_t Nout, const double *w_out,
-                         double *real_out, double *imag_out)
+// The reconstruction of ONE fit through the kernel of result.hip: scratch device memory for the parameter vector, the
+// optional output grid and the outputs, one launch, the copies back.  (A device batch does the same for all its fits in
+// one launch from its resident state: nmrfit_batch_contributions, batch.hip.)
+static int generate_one(nmrfit_ctx *ctx, int32_t P, const double *x, int64_t Nout, const double *w_out, double *real_out,
+                        double *imag_out, double *fit_out, double *data_out, const char *who)
 {
     int rc = bind(ctx);
     if (rc != NMRFIT_OK) return rc;
-    if (P < 0 || P > kMaxPeaks || !x || Nout < 0 || (P > 0 && Nout > 0 && (!real_out || !imag_out))) {
-        set_error("nmrfit_contributions: bad arguments");
+    if (!w_out) Nout = ctx->N;
+    if (P < 0 || P > kMaxPeaks || !x || Nout < 0 || (P > 0 && Nout > 0 && (!real_out != !imag_out))) {
+        set_error(std::string(who) + ": bad arguments");
         return NMRFIT_E_INVALID;
     }
-    if (!w_out) Nout = ctx->N;
-    const int64_t n = (int64_t)P * Nout;
-    if (n == 0) return NMRFIT_OK;
+    const int64_t N = ctx->N;
+    const int64_t n_contrib = real_out ? (int64_t)P * Nout : 0;
+    const int64_t n_fit = fit_out ? 4 * Nout : 0, n_data = data_out ? 2 * N : 0;
+    const int64_t n_out = 2 * n_contrib + n_fit + n_data;
+    if (n_out == 0) return NMRFIT_OK;
     const int64_t D = 4 + 3 * (int64_t)P;
-    double *d_x = nullptr, *d_w = nullptr, *d_out = nullptr;
+    double *d_in = nullptr, *d_out = nullptr;
     hipStream_t st = ctx->stream;
 #define CB_HIP(call)                                              \
     do {                                                          \
@@ -505,28 +512,57 @@ int nmrfit_contributions(nmrfit_ctx *ctx, int32_t P, const double *x, int64_t No
             goto done;                                            \
         }                                                         \
     } while (0)
-    CB_HIP(hipMalloc((void **)&d_x, (size_t)D * sizeof(double)));
-    CB_HIP(hipMalloc((void **)&d_out, (size_t)(2 * n) * sizeof(double)));
-    CB_HIP(hipMemcpyAsync(d_x, x, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
-    if (w_out) {
-        // centre on the host with the context's offset: the kernel works on w - w0
-        std::vector<double> wc((size_t)Nout);
-        for (int64_t j = 0; j < Nout; ++j) wc[(size_t)j] = w_out[j] - ctx->w0;
-        CB_HIP(hipMalloc((void **)&d_w, (size_t)Nout * sizeof(double)));
-        CB_HIP(hipMemcpy(d_w, wc.data(), (size_t)Nout * sizeof(double), hipMemcpyHostToDevice));
+    CB_HIP(hipMalloc((void **)&d_in, (size_t)(D + (w_out ? Nout : 0)) * sizeof(double)));
+    CB_HIP(hipMalloc((void **)&d_out, (size_t)n_out * sizeof(double)));
+    CB_HIP(hipMemcpyAsync(d_in, x, (size_t)D * sizeof(double), hipMemcpyHostToDevice, st));
+    if (w_out) CB_HIP(hipMemcpyAsync(d_in + D, w_out, (size_t)Nout * sizeof(double), hipMemcpyHostToDevice, st));
+    {
+        ResultJob job{};
+        job.wc = ctx->d_wc;
+        job.w_plain = w_out ? d_in + D : nullptr;   // (centred in the kernel with the context's offset: it works on w - w0)
+        job.x = d_in;
+        job.u = ctx->d_u;
+        job.v = ctx->d_v;
+        job.w0 = ctx->w0;
+        job.wspan = ctx->wspan;
+        job.Nout = Nout;
+        job.N = N;
+        job.P = P;
+        job.real = real_out ? d_out : nullptr;
+        job.imag = real_out ? d_out + n_contrib : nullptr;
+        job.fit = fit_out ? d_out + 2 * n_contrib : nullptr;
+        job.data = data_out ? d_out + 2 * n_contrib + n_fit : nullptr;
+        if ((rc = launch_result_one(st, job)) != NMRFIT_OK) goto done;
+        if (n_contrib) {
+            CB_HIP(hipMemcpyAsync(real_out, job.real, (size_t)n_contrib * sizeof(double), hipMemcpyDeviceToHost, st));
+            CB_HIP(hipMemcpyAsync(imag_out, job.imag, (size_t)n_contrib * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+        if (n_fit) CB_HIP(hipMemcpyAsync(fit_out, job.fit, (size_t)n_fit * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (n_data) CB_HIP(hipMemcpyAsync(data_out, job.data, (size_t)n_data * sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    rc = launch_contributions(ctx, P, d_x, Nout, w_out ? d_w : ctx->d_wc, d_out, d_out + n, /*grid_order=*/w_out == nullptr);
-    if (rc != NMRFIT_OK) goto done;
-    CB_HIP(hipMemcpyAsync(real_out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-    CB_HIP(hipMemcpyAsync(imag_out, d_out + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     CB_HIP(hipStreamSynchronize(st));
 #undef CB_HIP
 done:
     if (rc != NMRFIT_OK) (void)hipStreamSynchronize(st);
-    if (d_x) (void)hipFree(d_x);
-    if (d_w) (void)hipFree(d_w);
+    if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     return rc;
+}
+
+int nmrfit_contributions(nmrfit_ctx *ctx, int32_t P, const double *x, int64_t Nout, const double *w_out,
+                         double *real_out, double *imag_out)
+{
+    if (P > 0 && (w_out ? Nout > 0 : true) && (!real_out || !imag_out)) {
+        set_error("nmrfit_contributions: bad arguments");
+        return NMRFIT_E_INVALID;
+    }
+    return generate_one(ctx, P, x, Nout, w_out, real_out, imag_out, nullptr, nullptr, "nmrfit_contributions");
+}
+
+int nmrfit_generate_result(nmrfit_ctx *ctx, int32_t P, const double *x, int64_t Nout, const double *w_out,
+                           double *real_out, double *imag_out, double *fit_out, double *data_out)
+{
+    return generate_one(ctx, P, x, Nout, w_out, real_out, imag_out, fit_out, data_out, "nmrfit_generate_result");
 }
 
 int nmrfit_residual_batch(nmrfit_ctx *ctx, int64_t B, int32_t P, const double *X, double *R_out, double *f_out)

@@ -153,8 +153,4 @@ int comm_all_gather(nmrfit_comm *c, hipStream_t stream, const double *d_send, in
 nmrfit_ctx *comm_ctx(const nmrfit_comm *c);       // the context a communicator was created on
 bool comm_attach(nmrfit_comm *c);                 // claim it for ONE swarm (false: another swarm holds it); destroy order guard
 void comm_detach(nmrfit_comm *c);
-// per-peak real/imag contributions on a (centred) output grid resident on the device
-// (grid_order: d_wc_out is the context's own centred grid, stored in grid_slot order)
-int launch_contributions(nmrfit_ctx *ctx, int32_t P, const double *dx, int64_t Nout, const double *d_wc_out,
-                         double *d_real, double *d_imag, bool grid_order);
 }  // namespace nmrfit

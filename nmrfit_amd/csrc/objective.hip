@@ -1,6 +1,6 @@
 // objective.hip -- host side of the hot path: launch geometry (segments per particle, waves per workgroup), the LDS
 // budget that picks the kernel form, and the launch itself (launch_objective); plus the small kernels around it
-// (block-sum finalisation, per-peak contributions for generate_result, grid preparation).  The objective kernel is
+// (block-sum finalisation, grid preparation; the post-fit reconstruction is result.hip).  The objective kernel is
 // objective_kernel.h; its instantiations live in objective_{default,farfield,norec}.hip.
 #include "objective_launch.h"
 #include "objective_math.h"
@@ -21,34 +21,6 @@ __global__ void finalize_kernel(const double *__restrict__ partial, int64_t S, i
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     f[i] = finalize_value(partial + i * n_chunks * (fit_im ? 2 : 1), n_chunks, N, fit_im);
-}
-
-// Per-peak real and imaginary contributions on an output grid (FitUtility.generate_result,
-// nmrfit/utils.py:262-281): real[k, j] = voigt(w_j; r, yoff, peak k) (equations.py:141-147),
-// imag[k, j] = its Kramers-Kronig partner in closed form.  One thread per (peak, point).
-__global__ void contributions_kernel(const double *__restrict__ wc_out, int64_t Nout, const double *__restrict__ x,
-                                     int P, double w0, double wspan, double *__restrict__ real_out,
-                                     double *__restrict__ imag_out, int grid_order)
-{
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)P * Nout) return;
-    const int k = (int)(idx / Nout);
-    const int64_t j = idx - (int64_t)k * Nout;
-    const double r = x[2], yoff = x[3];
-    const double width = x[4 + 3 * k], loc = x[5 + 3 * k], a = x[6 + 3 * k];
-    const double ihw = 2.0 / width;
-    const double locc = loc - w0;
-    const double lim = 1.0e18 / (wspan + fabs(locc));
-    PeakLor rec;
-    rec.ihw = (fabs(ihw) > lim) ? copysign(lim, ihw) : ihw;
-    rec.c = -locc * rec.ihw;
-    rec.al = a * r * ihw * kInvPi;
-    rec.ag2 = 2.0 * a * (1.0 - r) * ihw * kSqrtLn2OverPi;
-    const double wj = wc_out[grid_order ? grid_slot(j) : j];
-    const double t = __builtin_fma(wj, rec.ihw, rec.c);
-    const double s = __builtin_fma(t, t, 1.0);
-    real_out[idx] = yoff + __builtin_fma(rec.al, rcp64(s), rec.ag2 * exp2_neg(-s));
-    imag_out[idx] = dispersion(wj, rec);
 }
 
 // per-chunk (min, max) of the centred grid: one wave per chunk
@@ -342,17 +314,6 @@ int launch_objective(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *dX, do
     ctx->last.waves_per_workgroup = wpb;
     ctx->last.nseg = (int32_t)nseg;
     ctx->last.seg_len = seg_len;
-    return NMRFIT_OK;
-}
-
-int launch_contributions(nmrfit_ctx *ctx, int32_t P, const double *dx, int64_t Nout, const double *d_wc_out,
-                         double *d_real, double *d_imag, bool grid_order)
-{
-    const int64_t n = (int64_t)P * Nout;
-    if (n == 0) return NMRFIT_OK;
-    hipLaunchKernelGGL(contributions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_wc_out,
-                       Nout, dx, (int)P, ctx->w0, ctx->wspan, d_real, d_imag, grid_order ? 1 : 0);
-    NMRFIT_HIP(hipGetLastError());
     return NMRFIT_OK;
 }
 

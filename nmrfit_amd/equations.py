@@ -141,6 +141,24 @@ class Evaluator:
                                                    _cabi.ptr(real), _cabi.ptr(imag)))
         return real, imag
 
+    def generate_result(self, x, w=None):
+        """FitUtility.generate_result's arithmetic for one parameter vector in one launch (nmrfit/utils.py:226-295):
+        ``(real[P, Nout], imag[P, Nout], fit[4, Nout], data[2, N])`` -- the per-peak contributions, (V_fit, I_fit, u_fit,
+        v_fit) and the spectrum rotated by the fitted phase (V, I).  ``w`` None -> the context's grid."""
+        x = _cabi.f64(x)
+        if x.ndim != 1 or x.size < 4 or (x.size - 4) % 3:
+            raise ValueError("parameter vector must have 4 + 3P entries")
+        P = (x.size - 4) // 3
+        wout = None if w is None else _cabi.f64(w)
+        n = self.N if wout is None else wout.size
+        real = np.empty((P, n), dtype=np.float64)
+        imag = np.empty((P, n), dtype=np.float64)
+        fit = np.empty((4, n), dtype=np.float64)
+        data = np.empty((2, self.N), dtype=np.float64)
+        _cabi.check(self._lib.nmrfit_generate_result(self._ctx, P, _cabi.ptr(x), n, _cabi.ptr(wout), _cabi.ptr(real),
+                                                     _cabi.ptr(imag), _cabi.ptr(fit), _cabi.ptr(data)))
+        return real, imag, fit, data
+
     def residual_batch(self, X, return_f=False):
         X, P = self._as_batch(X)
         R = np.empty((X.shape[0], self.N), dtype=np.float64)

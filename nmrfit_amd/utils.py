@@ -224,9 +224,11 @@ class FitUtility:
         if self.summary is True:
             self._print_summary()
 
-    def fit(self):
-        """utils.py:164-189: weights, minimise, store params/error, optional summary."""
-        plan = self._plan()
+    def fit(self, plan=None):
+        """utils.py:164-189: weights, minimise, store params/error, optional summary.  (``plan``: what ``_plan()``
+        returned for this fit, when the caller -- core.fit_many -- has made it already.)"""
+        if plan is None:
+            plan = self._plan()
         opt = self.options
         kw, swarmsize, maxiter, seed = plan['kw'], plan['swarmsize'], plan['maxiter'], plan['seed']
         # Multi-GPU fits (one process per GPU, every rank makes the same fit() call):
@@ -284,45 +286,44 @@ class FitUtility:
     def generate_result(self, scale=1):
         """utils.py:226-295: per-peak real and imaginary contributions of the fitted parameters
         on the data grid (or a grid upsampled by ``scale``), their sums V, I, and the fit
-        rotated back to the (u, v) frame.  The imaginary contributions are the Kramers-Kronig
-        partners in closed form on the GPU (the reference integrates each point numerically)."""
+        rotated back to the (u, v) frame -- one launch of the reconstruction kernel (csrc/result.hip).
+        The imaginary contributions are the Kramers-Kronig partners in closed form (the reference
+        integrates each point numerically).  ``core.fit_many(jobs, generate=True)`` does this for all
+        the fits of a device batch in one launch."""
         if scale == 1.0:
             w = self.data.w
         else:
             w = np.linspace(self.data.w.min(), self.data.w.max(), int(scale * self.data.w.shape[0]))
-        p0, p1 = self.params[0], self.params[1]
-
-        # phase shift data by fit theta (containers.py:68-78 with method='manual')
-        if hasattr(self.data, 'shift_phase'):
-            self.data.shift_phase(method='manual', p0=p0, p1=p1)
-        else:
-            self.data.p0, self.data.p1 = p0, p1
-            self.data.V, self.data.I = proc_autophase.ps2(self.data.u, self.data.v, p0, p1)
-
         ev = equations.Evaluator(self.data.w, self.data.u, self.data.v, np.ones(len(self.data.w)),
                                  device=self._device())
         try:
-            real, imag = ev.contributions(self.params, None if scale == 1.0 else w)
+            real, imag, fit, rotated = ev.generate_result(self.params, None if scale == 1.0 else w)
         finally:
             ev.close()
-        real_contribs = [real[k] for k in range(real.shape[0])]
-        imag_contribs = [imag[k] for k in range(imag.shape[0])]
-        V_fit = np.zeros_like(w)
-        I_fit = np.zeros_like(w)
-        for k in range(len(real_contribs)):          # same accumulation order as utils.py:276-277
-            V_fit = V_fit + real_contribs[k]
-            I_fit = I_fit + imag_contribs[k]
+        self._store_result(w, real, imag, fit, rotated)
 
-        # transform the fits for V and I to get fits for u and v
-        u_fit, v_fit = proc_autophase.ps2(V_fit, I_fit, inv=True, p0=p0, p1=p1)
-
-        self.u = u_fit
-        self.v = v_fit
-        self.V = V_fit
-        self.I = I_fit
+    def _store_result(self, w, real, imag, fit, rotated, call_shift_phase=True):
+        """The attributes generate_result leaves behind (utils.py:251, 289-295), from the arrays the reconstruction
+        kernel returns (csrc/result.hip) -- for one fit (generate_result) or as views of a batch's arrays
+        (core.fit_many(generate=...))."""
+        p0, p1 = self.params[0], self.params[1]
+        # phase shift data by fit theta (utils.py:251; containers.py:68-78 with method='manual').  A data object that
+        # brings the reference's method gets it called; one that does not gets the same attributes set from the kernel's
+        # rotation of the spectrum.
+        if call_shift_phase and hasattr(self.data, 'shift_phase'):
+            self.data.shift_phase(method='manual', p0=p0, p1=p1)
+        else:
+            self.data.p0, self.data.p1 = p0, p1
+            self.data.V, self.data.I = rotated[0], rotated[1]
+        # (V_fit, I_fit: the contributions added peak after peak from zero, utils.py:276-277; u_fit, v_fit: the fit
+        # rotated back, utils.py:284 -- all four evaluated next to the contributions on the GPU)
+        self.u = fit[2]
+        self.v = fit[3]
+        self.V = fit[0]
+        self.I = fit[1]
         self.w = w
-        self.real_contribs = real_contribs
-        self.imag_contribs = imag_contribs
+        self.real_contribs = [real[k] for k in range(real.shape[0])]
+        self.imag_contribs = [imag[k] for k in range(imag.shape[0])]
 
     def get_areas(self):
         """utils.py:312-322."""

@@ -33,7 +33,7 @@ def client(tmp_path_factory):
 def test_c_client_builds_and_loads(client):
     out = subprocess.run([client, "--abi"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "ABI version 5 (header 5)" in out.stdout
+    assert "ABI version 6 (header 6)" in out.stdout
 
 
 @pytest.mark.gpu

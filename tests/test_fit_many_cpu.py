@@ -51,7 +51,7 @@ def test_jobs_with_a_communicator_run_one_after_another(monkeypatch):
     once from several host threads.  The fits run serially, in job order, on the calling thread."""
     calls = []
 
-    def fake_fit(self):
+    def fake_fit(self, plan=None):
         calls.append((threading.get_ident(), self.options.get("tag")))
         self.params, self.error = np.zeros(len(self.lower)), 0.0
     monkeypatch.setattr(utils.FitUtility, "fit", fake_fit)
@@ -68,33 +68,57 @@ def test_jobs_with_a_communicator_run_one_after_another(monkeypatch):
     assert sorted(t for _, t in calls) == [0, 1, 2, 3, 4] and [f.options["tag"] for f in out] == [0, 1, 2, 3, 4]
 
 
-def test_long_job_lists_go_through_spans_and_leftovers_find_partners(monkeypatch):
-    """The host side of the pipeline (no device: the batch's creation and run are replaced): a list longer than
-    BATCH_JOBS is cut into spans of equal size, every span's groups of equal key become batches made on the second
-    thread and run on the calling one in span order, a job without a partner inside its span is batched with the
-    leftovers of the other spans, and what stays alone goes through fit()."""
-    monkeypatch.setattr(core, "BATCH_JOBS", 4)
-    made, ran, lone = [], [], []
+class _FakeBatch:
+    """Stands in for batch.FitBatch where no device is: records which thread ran it."""
 
-    class FakeBatch:
-        def close(self):
-            pass
+    def __init__(self, log, tags):
+        self.log, self.tags, self.closed = log, tags, False
+
+    def run(self, maxiter, check_every):
+        self.log.append((threading.get_ident(), self.tags))
+
+    def close(self):
+        self.closed = True
+
+
+def _fake_pipeline(monkeypatch, refuse=()):
+    """core's device calls replaced: returns the logs (made, ran, collected, lone, batches)."""
+    made, ran, collected, lone, batches = [], [], [], [], []
 
     def fake_create(fits, plans, key):
-        made.append((threading.get_ident(), [f.options["tag"] for f in fits]))
-        return FakeBatch(), fits, plans, key
+        tags = [f.options["tag"] for f in fits]
+        if any(t in refuse for t in tags):
+            raise _cabi.NmrfitError(_cabi.E_UNSUPPORTED, "too many peaks for the kernel's LDS records in a batched launch")
+        made.append((threading.get_ident(), tags))
+        batches.append(_FakeBatch(ran, tags))
+        return batches[-1], fits, plans, key
 
-    def fake_finish(fb, fits, plans, key):
-        ran.append((threading.get_ident(), [f.options["tag"] for f in fits]))
+    def fake_collect(fb, fits, plans, key, scale=False):
+        collected.append((threading.get_ident(), fb.tags, scale))
         for f in fits:
             f.params, f.error = np.zeros(len(f.lower)), 0.0
+        fb.close()
 
-    def fake_fit(self):
-        lone.append(self.options["tag"])
+    def fake_fit(self, plan=None):
+        lone.append((self.options["tag"], plan is not None))
         self.params, self.error = np.zeros(len(self.lower)), 0.0
+
+    def fake_generate(self, scale=1):
+        self.generated = scale
     monkeypatch.setattr(core, "_batch_create", fake_create)
-    monkeypatch.setattr(core, "_batch_finish", fake_finish)
+    monkeypatch.setattr(core, "_batch_collect", fake_collect)
     monkeypatch.setattr(utils.FitUtility, "fit", fake_fit)
+    monkeypatch.setattr(utils.FitUtility, "generate_result", fake_generate)
+    return made, ran, collected, lone, batches
+
+
+def test_long_job_lists_go_through_spans_and_leftovers_find_partners(monkeypatch):
+    """The host side of the pipeline (no device: the batch's creation, run and read-back are replaced): a list longer
+    than BATCH_JOBS is cut into spans of equal size, every span's groups of equal key become batches made on the second
+    thread, run on the calling one in span order and read back on a third; a job without a partner inside its span is
+    batched with the leftovers of the other spans, and what stays alone goes through fit() with the plan made for it."""
+    monkeypatch.setattr(core, "BATCH_JOBS", 4)
+    made, ran, collected, lone, batches = _fake_pipeline(monkeypatch)
     # 10 jobs -> 3 spans of 4, 4, 2.  Grid lengths: span 0 = [A A A B], span 1 = [A A B C], span 2 = [A A]
     lengths = [1024, 1024, 1024, 2048, 1024, 1024, 2048, 4096, 1024, 1024]
     jobs = [_job(n, 2, 20 + k, options={"tag": k}) for k, n in enumerate(lengths)]
@@ -104,7 +128,93 @@ def test_long_job_lists_go_through_spans_and_leftovers_find_partners(monkeypatch
     assert [tags for _, tags in ran] == [[0, 1, 2], [4, 5], [8, 9], [3, 6]]      # spans in order, then the leftovers' batch
     assert all(tid == me for tid, _ in ran)                                      # the device is driven from the calling thread
     assert [tags for _, tags in made[:3]] == [[0, 1, 2], [4, 5], [8, 9]] and all(tid != me for tid, _ in made[:3])
-    assert lone == [7]                                                           # the only 4096-point job
+    assert [tags for _, tags, _ in collected] == [tags for _, tags in ran]       # read back in the order they ran ...
+    assert len({tid for tid, _, _ in collected}) == 1 and collected[0][0] not in (me, made[0][0])   # ... on a third thread
+    assert all(scale is False for _, _, scale in collected) and all(b.closed for b in batches)
+    assert lone == [(7, True)]                                                   # the only 4096-point job: its plan is reused
+    assert not hasattr(out[7], "generated")
+
+
+def test_generate_reaches_batches_and_lone_fits(monkeypatch):
+    """generate=True / a scale: the batches' read-back gets the scale, fits that ran alone get generate_result(scale)."""
+    monkeypatch.setattr(core, "BATCH_JOBS", 4)
+    made, ran, collected, lone, _ = _fake_pipeline(monkeypatch)
+    jobs = [_job(n, 2, 40 + k, options={"tag": k}) for k, n in enumerate([1024, 1024, 2048])]
+    out = core.fit_many(jobs, threads=1, generate=True)
+    assert [(tags, scale) for _, tags, scale in collected] == [([0, 1], 1)] and out[2].generated == 1
+    collected.clear()
+    out = core.fit_many(jobs, threads=2, generate=2.5)
+    assert [(tags, scale) for _, tags, scale in collected] == [([0, 1], 2.5)] and out[2].generated == 2.5
+
+
+def test_a_batch_the_device_refuses_runs_as_lone_fits(monkeypatch):
+    """NMRFIT_E_UNSUPPORTED (or an allocation failure) from the batch's creation must not abort fit_many: the
+    group's fits run one by one, the other groups stay batched."""
+    monkeypatch.setattr(core, "BATCH_JOBS", 8)
+    made, ran, collected, lone, batches = _fake_pipeline(monkeypatch, refuse={2})
+    lengths = [1024, 1024, 2048, 2048, 2048]
+    jobs = [_job(n, 2, 60 + k, options={"tag": k}) for k, n in enumerate(lengths)]
+    out = core.fit_many(jobs, threads=1)
+    assert [tags for _, tags in ran] == [[0, 1]]
+    assert sorted(t for t, _ in lone) == [2, 3, 4] and all(had_plan for _, had_plan in lone)
+    assert all(f.error == 0.0 for f in out) and all(b.closed for b in batches)
+
+
+def test_an_error_in_a_run_closes_every_batch(monkeypatch):
+    monkeypatch.setattr(core, "BATCH_JOBS", 2)
+    made, ran, collected, lone, batches = _fake_pipeline(monkeypatch)
+
+    def bad_run(self, maxiter, check_every):
+        if self.tags == [2, 3]:
+            raise _cabi.NmrfitError(_cabi.E_HIP, "injected")
+        ran.append((threading.get_ident(), self.tags))
+    monkeypatch.setattr(_FakeBatch, "run", bad_run)
+    jobs = [_job(1024, 2, 80 + k, options={"tag": k}) for k in range(6)]
+    with pytest.raises(_cabi.NmrfitError):
+        core.fit_many(jobs, threads=1)
+    assert [tags for _, tags in ran] == [[0, 1]] and all(b.closed for b in batches) and len(batches) >= 2
+
+
+def test_the_rank_device_reaches_jobs_that_bring_their_own_options(monkeypatch):
+    """a job's own `options` replaces the shared dict when the two are merged, so the device of a
+    sharded (or devices=[...]) call must be stamped into every job's options -- a seed per job is exactly what callers
+    pass."""
+    seen = []
+
+    def fake_local(jobs, threads, batch, kwargs, generate=False):
+        seen.append([dict(j.get("options") or {}) for j in jobs])
+        out = []
+        for j in jobs:
+            f = utils.FitUtility(j["data"], j["lower"], j["upper"], summary=False, options=j.get("options", {}))
+            f.params, f.error, f.seed = np.zeros(len(j["lower"])), 0.0, 1
+            out.append(f)
+        return out
+    monkeypatch.setattr(core, "_fit_many_local", fake_local)
+    monkeypatch.setattr(core, "_cabi_device_count", lambda: 8)
+    jobs = [_job(512, 2, 90 + k, options={"seed": k}) for k in range(4)] + [_job(512, 2, 99)]
+
+    class Chan:
+        def all_gather(self, blob):
+            return [blob]
+
+        def close(self):
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    core._fit_many_sharded(jobs, 1, True, dict(summary=False, options={"maxiter": 5}), 0, 1, channel=Chan())
+    assert [o["device"] for o in seen[-1]] == [3] * 5
+    assert [o.get("seed") for o in seen[-1]] == [0, 1, 2, 3, None] and all(o["maxiter"] == 5 for o in seen[-1])
+    # a device the job names itself wins in the sharded mode ...
+    core._fit_many_sharded([_job(512, 2, 1, options={"device": 6})], 1, True, dict(summary=False), 0, 1, channel=Chan())
+    assert seen[-1][0]["device"] == 6
+    # ... and devices=[...] assigns -- without a TypeError when the job's options already hold a device (ADVICE r5, low)
+    seen.clear()
+    core.fit_many([_job(512, 2, 2, options={"device": 0, "seed": 1}), _job(512, 2, 3)], devices=[4, 5])
+    got = sorted((o["device"], o.get("seed")) for share in seen for o in share)
+    assert got == [(4, 1), (5, None)]
 
 
 def test_small_shard_warning():

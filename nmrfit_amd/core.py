@@ -31,7 +31,7 @@ def fit(data, lower, upper, expon=0.5, dynamic_weighting=True, fit_im=False, pro
     return f
 
 
-def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, generate=False, **kwargs):
+def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, generate=False, channel=None, **kwargs):
     """Fit several spectra: ``jobs`` is a sequence of ``(data, lower, upper)`` triples (or dicts of ``fit``'s
     arguments); every job is fitted as ``fit`` would fit it with the same keyword arguments, and the list of
     FitUtility objects comes back in the order of ``jobs``.  Not in the reference (its users loop over
@@ -62,7 +62,8 @@ def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, generate=Fa
       the JOBS are divided over the ranks -- rank r takes jobs r, r + world, ... on its own GPU -- and the results are
       gathered so that every rank returns the full list (``params``, ``error``, ``seed``; the arrays of ``generate`` stay
       on the rank that made them).  Replicas: no collective touches the fits themselves.  This is the multi-GPU mode
-      for many small fits (sharding one 204-particle swarm over GPUs is slower than one GPU).
+      for many small fits (sharding one 204-particle swarm over GPUs is slower than one GPU).  ``channel``: an open
+      ``nmrfit_amd.rendezvous.Channel`` to gather over (a caller that already has one); else one is made.
     * ``devices=[0, 1, ...]`` (or ``"all"``): the same replicas WITHOUT a launcher -- this one process drives several
       GPUs, a host thread per device, job k on ``devices[k % len(devices)]``; each device runs its share as device
       batches of its own.  Nothing crosses devices.  (``shard`` and ``devices`` exclude each other.)"""
@@ -84,7 +85,7 @@ def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, generate=Fa
         from . import rendezvous
         rank, _, world = rendezvous.env_rank_world()
         if world > 1:
-            return _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, generate=generate)
+            return _fit_many_sharded(jobs, threads, batch, kwargs, rank, world, channel=channel, generate=generate)
     return _fit_many_local(jobs, threads, batch, kwargs, generate)
 
 

@@ -46,6 +46,12 @@ struct BatchPart {
     int64_t Psum = 0;
     // scratch of a reconstruction call in flight (nmrfit_batch_contributions): device block, and what goes where on the host
     void *d_result = nullptr;
+    struct ResultCopy {
+        void *host;
+        const void *dev;
+        size_t bytes;
+    };
+    std::vector<ResultCopy> result_copies;
     // launch geometry: [0] workgroup = particle, [1] wave = particle
     nmrfit::BatchLaunch geom[2];
     bool geom_ok[2] = {false, false};
@@ -682,8 +688,8 @@ static int part_best(BatchPart *b, double *x_best, double *f_best)
 
 
 // FitUtility.generate_result (nmrfit/utils.py:226-295) for every fit of the part at its best position: ONE launch of the
-// reconstruction kernel (result.hip) over the part's resident grids and best rows, enqueued on the part's stream with
-// the copies back to the host; part_contributions_finish waits for it.  The host pointers are this part's shares.
+// reconstruction kernel (result.hip) over the part's resident grids and best rows, enqueued on the part's stream;
+// part_contributions_finish brings the arrays to the host (staged_d2h).  The host pointers are this part's shares.
 static int part_contributions_enqueue(BatchPart *b, int64_t Nout, const double *w_out, double *real_out, double *imag_out,
                                       double *fit_out, double *data_out)
 {
@@ -736,12 +742,15 @@ static int part_contributions_enqueue(BatchPart *b, int64_t Nout, const double *
     if (n_w) NMRFIT_HIP(hipMemcpyAsync(d_w, w_out, (size_t)n_w * sizeof(double), hipMemcpyHostToDevice, st));
     if ((rc = launch_result_jobs(st, reinterpret_cast<const ResultJob *>(base), K, std::max(Nn, data_out ? N : 0), b->Pmax)) != NMRFIT_OK)
         return rc;
+    // what goes where on the host, for part_contributions_finish (the copies are staged and synchronous: they would
+    // serialise the parts' launches if they were made here)
+    b->result_copies.clear();
     if (n_contrib) {
-        NMRFIT_HIP(hipMemcpyAsync(real_out, d_real, (size_t)n_contrib * sizeof(double), hipMemcpyDeviceToHost, st));
-        NMRFIT_HIP(hipMemcpyAsync(imag_out, d_imag, (size_t)n_contrib * sizeof(double), hipMemcpyDeviceToHost, st));
+        b->result_copies.push_back({real_out, d_real, (size_t)n_contrib * sizeof(double)});
+        b->result_copies.push_back({imag_out, d_imag, (size_t)n_contrib * sizeof(double)});
     }
-    if (n_fit) NMRFIT_HIP(hipMemcpyAsync(fit_out, d_fit, (size_t)n_fit * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (n_data) NMRFIT_HIP(hipMemcpyAsync(data_out, d_data, (size_t)n_data * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (n_fit) b->result_copies.push_back({fit_out, d_fit, (size_t)n_fit * sizeof(double)});
+    if (n_data) b->result_copies.push_back({data_out, d_data, (size_t)n_data * sizeof(double)});
     return NMRFIT_OK;
 }
 
@@ -749,11 +758,15 @@ static int part_contributions_finish(BatchPart *b)
 {
     if (!b->d_result) return NMRFIT_OK;
     (void)hipSetDevice(b->device);
+    int rc = NMRFIT_OK;
+    for (const BatchPart::ResultCopy &c : b->result_copies)
+        if (rc == NMRFIT_OK) rc = staged_d2h(b->device, b->stream, c.host, c.dev, c.bytes);
+    b->result_copies.clear();
     const hipError_t e = hipStreamSynchronize(b->stream);
     (void)hipFree(b->d_result);
     b->d_result = nullptr;
-    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize(reconstruction)", __FILE__, __LINE__);
-    return NMRFIT_OK;
+    if (rc == NMRFIT_OK && e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize(reconstruction)", __FILE__, __LINE__);
+    return rc;
 }
 
 

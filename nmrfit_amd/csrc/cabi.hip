@@ -117,6 +117,65 @@ void give_stream(int device, hipStream_t s)
     (void)hipStreamDestroy(s);
 }
 
+// Large results to PAGEABLE host memory (numpy arrays the caller has just made): a plain hipMemcpy pins the destination's
+// pages on the fly, 13-26 ms for the 30 MB a batch of 50 reconstructed fits returns, 1 ms when the runtime happens to
+// know the pages (tools/generate_breakdown.py; profiles/r06/generate_breakdown.txt).  Here the copy goes through two
+// pinned buffers the process keeps per device: the DMA engine fills one while the CPU copies the other out, so the call
+// costs what the CPU copy into the caller's pages costs (~3 ms for 30 MB) whatever the runtime's pinning cache holds.
+// Synchronous: the data is in `dst` on return.  Small copies take the plain path.
+namespace {
+struct HostStage {
+    std::mutex lock;                 // one staged copy at a time per device (the buffers are the resource)
+    void *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+constexpr size_t kStageChunk = (size_t)4 << 20;
+constexpr size_t kStageMin = (size_t)256 << 10;
+HostStage *host_stage(int device)
+{
+    static std::mutex table_lock;
+    static std::vector<HostStage *> table;   // (never destroyed: pinned memory outlives every context, freed at process exit)
+    std::lock_guard<std::mutex> guard(table_lock);
+    if ((int)table.size() <= device) table.resize((size_t)device + 1, nullptr);
+    if (!table[(size_t)device]) table[(size_t)device] = new HostStage;
+    return table[(size_t)device];
+}
+}  // namespace
+
+int staged_d2h(int device, hipStream_t st, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (bytes == 0) return NMRFIT_OK;
+    static const bool off = getenv("NMRFIT_NO_STAGED_COPIES") != nullptr;   // A/B knob
+    if (bytes < kStageMin || off) {
+        NMRFIT_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        NMRFIT_HIP(hipStreamSynchronize(st));
+        return NMRFIT_OK;
+    }
+    HostStage *hs = host_stage(device);
+    std::lock_guard<std::mutex> guard(hs->lock);
+    for (int i = 0; i < 2; ++i)
+        if (!hs->buf[i]) {
+            NMRFIT_HIP(hipHostMalloc(&hs->buf[i], kStageChunk, hipHostMallocDefault));
+            NMRFIT_HIP(hipEventCreateWithFlags(&hs->ev[i], hipEventDisableTiming));
+        }
+    const unsigned char *src = static_cast<const unsigned char *>(src_dev);
+    unsigned char *dst = static_cast<unsigned char *>(dst_host);
+    const size_t n_chunks = (bytes + kStageChunk - 1) / kStageChunk;
+    for (size_t i = 0; i <= n_chunks; ++i) {
+        if (i < n_chunks) {   // (buffer i % 2 was copied out two rounds ago, before chunk i - 1 was waited for)
+            const size_t off_i = i * kStageChunk, n = std::min(kStageChunk, bytes - off_i);
+            NMRFIT_HIP(hipMemcpyAsync(hs->buf[i & 1], src + off_i, n, hipMemcpyDeviceToHost, st));
+            NMRFIT_HIP(hipEventRecord(hs->ev[i & 1], st));
+        }
+        if (i > 0) {
+            const size_t off_p = (i - 1) * kStageChunk, n = std::min(kStageChunk, bytes - off_p);
+            NMRFIT_HIP(hipEventSynchronize(hs->ev[(i - 1) & 1]));
+            memcpy(dst + off_p, hs->buf[(i - 1) & 1], n);
+        }
+    }
+    return NMRFIT_OK;
+}
+
 // (hipGetDeviceProperties costs about a millisecond: once per device and PROCESS -- a default fit is 30 ms, and
 // fit_many's worker threads come and go)
 int device_info_cached(int device, DeviceInfo *out)
@@ -472,9 +531,20 @@ int nmrfit_objective_batch(nmrfit_ctx *ctx, int64_t S, int32_t P, const double *
     const int64_t D = 4 + 3 * (int64_t)P;
     if ((rc = ensure(ctx, &ctx->d_X, &ctx->cap_X, S * D)) != NMRFIT_OK) return rc;
     if ((rc = ensure(ctx, &ctx->d_f, &ctx->cap_f, S)) != NMRFIT_OK) return rc;
-    NMRFIT_HIP(hipMemcpyAsync(ctx->d_X, X, (size_t)(S * D) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const int saved = ctx->fit_im;
     ctx->fit_im = fit_im;
+    // (Round 6, measured and rejected: the upload cut into slices through pinned memory, the kernel of a slice starting as
+    // soon as its rows have landed -- 1.52 ms per C3 call against 1.34 ms for this plain form, resident launch 1.20: four
+    // kernels each drain on their own, which costs more than the 0.1 ms of upload they hide;
+    // profiles/r06/host_pointer_pipelined_ab.txt.)
+    const int64_t x_bytes = S * D * (int64_t)sizeof(double);
+    {
+        hipError_t e = hipMemcpyAsync(ctx->d_X, X, (size_t)x_bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            ctx->fit_im = saved;
+            return hip_fail(e, "hipMemcpyAsync(X)", __FILE__, __LINE__);
+        }
+    }
     rc = launch_objective(ctx, S, P, ctx->d_X, ctx->d_f, nullptr);
     ctx->fit_im = saved;
     if (rc != NMRFIT_OK) return rc;

@@ -69,6 +69,9 @@ int device_info_cached(int device, DeviceInfo *out);      // cabi.hip: compute u
 hipError_t take_stream(int device, hipStream_t *out);     // cabi.hip: a recycled (or new) non-blocking stream
 void give_stream(int device, hipStream_t s);              // ... handed back idle (synchronised)
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
+// cabi.hip: device -> pageable host memory through the process's pinned double buffer (synchronous; stream-ordered after
+// what is queued on `st`)
+int staged_d2h(int device, hipStream_t st, void *dst_host, const void *src_dev, size_t bytes);
 
 #define NMRFIT_HIP(call)                                                        \
     do {                                                                        \

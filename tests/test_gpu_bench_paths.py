@@ -95,16 +95,35 @@ def test_bench_paths_agree():
     assert "rccl" not in plain
     # self-launching form: no launcher, no WORLD_SIZE in the environment
     two = _run([sys.executable, "bench.py", "--gpus", "2", "--swarm-per-gpu", "256"] + common,
-               {"NMRFIT_BENCH_BACKEND": "host"})
+               {"NMRFIT_BENCH_BACKEND": "host", "NMRFIT_BENCH_REPLICA_JOBS": "24"})
     assert two["n_gpus"] == 2 and two["config"]["swarm_total"] == 512
+    _check_replicas(two, 2, 24)
     assert two["rccl"] is None and "error" not in two          # the host-staged exchange was asked for explicitly
     assert two["config"]["swarm_best_f"] == plain["config"]["swarm_best_f"]
     assert two["config"]["generations_done"] == plain["config"]["generations_done"] == 7
     # the driver's form: torch.distributed.run as the launcher (torch is not imported by the ranks)
-    three = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                  "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
-                  "--swarm-per-gpu", "256"] + common, {"NMRFIT_BENCH_BACKEND": "host"})
-    assert three["config"]["swarm_best_f"] == plain["config"]["swarm_best_f"]
+    three = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                  "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "3",
+                  "--swarm-per-gpu", "256"] + common, {"NMRFIT_BENCH_BACKEND": "host", "NMRFIT_BENCH_REPLICA_JOBS": "12"})
+    assert three["n_gpus"] == 3 and three["config"]["swarm_total"] == 768 and "error" not in three
+    _check_replicas(three, 3, 12)
+
+
+def _check_replicas(line, world, jobs):
+    """the N > 1 line carries BOTH multi-GPU modes -- the swarm-sharded `value` (with `scaling_model`)
+    and the spectra-parallel replicas, every rank its own spectra through fit_many / fit_many(shard=True)."""
+    rp = line["replicas"]
+    assert "error" not in rp and rp["ranks"] == world and rp["jobs_per_rank"] == jobs
+    for key in ("stopping_rule_on", "stopping_rule_off"):
+        q = rp[key]
+        assert len(q["per_rank_fits_per_s"]) == world and min(q["per_rank_fits_per_s"]) > 0
+        assert q["aggregate_fits_per_s"] == pytest.approx(world * jobs / (jobs / q["per_rank_spread"]["min"]))
+        assert q["expected_aggregate_fits_per_s"] == pytest.approx(sum(q["per_rank_fits_per_s"]))
+        assert 0.0 < q["aggregate_over_expected"] <= 1.0 + 1e-9
+        sh = q["sharded_call"]
+        assert sh["results_gathered_on_every_rank"] and sh["own_share_equals_local_run"] and sh["aggregate_fits_per_s"] > 0
+    sm = line["scaling_model"]["replicas"]
+    assert sm["measured_aggregate_fits_per_s"] == rp["stopping_rule_on"]["aggregate_fits_per_s"]
 
 
 def test_bench_says_so_when_rccl_is_unavailable():
@@ -146,9 +165,13 @@ def test_c4_rehearsal_four_ranks_on_one_gpu():
     assert oc["C1"]["shape"] == {"rows": 50, "grid": 4096, "peaks": 6} and oc["C1"]["kernel_ms"] > 0
     assert oc["C2"]["shape"] == {"rows": 1024, "grid": 4096, "peaks": 6} and oc["C2"]["kernel_ms"] > 0
     assert oc["C5"]["shape"] == {"rows": 41, "grid": 16384, "peaks": 12} and "residual" in oc["C5"]["kind"]
-    for k in ("C2", "C5"):
+    for k in ("C1", "C2", "C5"):
+        # these launches are latency-bound; no machine-readable fraction above 1, the streaming-operand
+        # rate (an effective rate served from L2) stands beside it without one
         r = oc[k]["roofline"]
-        assert r["frac"] == pytest.approx(r["bytes_per_launch"] / (oc[k]["kernel_ms"] * 1e-3) / 1e9 / r["peak"])
+        assert r["bound"] == "latency" and 0.0 < r["frac"] < 1.0 and r["frac_kind"] == "estimate"
+        assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+        assert r["streaming_operand_GBps_effective"] == pytest.approx(r["bytes_per_launch"] / (oc[k]["kernel_ms"] * 1e-3) / 1e9)
     assert oc["C2"]["roofline"]["bytes_per_launch"] == 1024 * (4 * 4096 * 8) + 1024 * 22 * 8 + 1024 * 8
     # ... and so does the reference's default fit, end to end (204 particles, all 2000 generations)
     rf = one["reference_default_fit"]
@@ -163,6 +186,15 @@ def test_c4_rehearsal_four_ranks_on_one_gpu():
     e2e = bf["fit_many_end_to_end"]      # the user-level call on the same spectra (its own weights: FitUtility._compute_weights)
     assert 0.0 < e2e["stopping_rule_off"]["error_fit0"] < 0.05
     assert e2e["stopping_rule_on"]["fits_per_s"] > e2e["stopping_rule_off"]["fits_per_s"] > 2.0 * 1e3 / rf["wall_ms"]
+    # ... and the rest of the README script (round 6): fit -> generate_result -> area fractions, batched against the loop
+    rp = one["readme_pipeline"]
+    assert rp["shape"]["jobs"] == 200 and "error" not in rp
+    for key in ("stopping_rule_off", "stopping_rule_on"):
+        assert rp[key]["batched_equals_plain_loop_bit_for_bit"] is True
+        assert rp[key]["pipeline_fits_per_s"] > 2.0 * rp[key]["plain_loop_fits_per_s"]
+        assert rp[key]["result_bytes_per_fit"] == (2 * 6 + 6) * 4096 * 8
+    assert rp["stopping_rule_off"]["pipeline_over_fit_only"] > 0.8
+    assert "replicas" not in one and "replicas" not in four          # (--no-extras, N = 1)
     # the sharded run carries the model its step time is to be judged against
     sm = four["scaling_model"]
     assert len(sm["expected_ms_per_step"]) == 2 and sm["max_rank_kernel_ms"] > 0 and sm["measured_over_expected"] is not None

@@ -904,6 +904,30 @@ def main():
                                     "generations": {"min": min(gens), "max": max(gens), "mean": float(np.mean(gens))},
                                     "us_per_fit_generation": dtb * 1e6 / max(1.0, float(np.sum(gens))),
                                     "geometry": gm, "error_fit0": bestb[0][1]}
+            # ... and spectra of DIFFERENT lengths in one batch (round 6; every dataset is cropped to its own region,
+            # nmrfit/containers.py:112-130): lengths drawn from 3000 ... 6000 against equal lengths of the same mean
+            lens = [int(n) for n in np.random.default_rng(11).integers(3000, 6001, Kb)]
+            mean_len = int(round(float(np.mean(lens)) / 512.0)) * 512
+            rag = {"lengths": {"min": min(lens), "max": max(lens), "mean": float(np.mean(lens))}, "equal_length": mean_len}
+            for name, lengths in (("ragged", lens), ("equal", [mean_len] * Kb)):
+                sps = [synth.make_spectrum(n, 6, seed=100 + k % 8) for k, n in enumerate(lengths)]
+                best_dt = None
+                for _ in range(2):
+                    tb = time.perf_counter()
+                    with FitBatch([(q["w"], q["u"], q["v"], q["weights"]) for q in sps], [q["lower"] for q in sps],
+                                  [q["upper"] for q in sps], swarmsize=204, seeds=list(range(7, 7 + Kb)), device=device,
+                                  minstep=-1.0, minfunc=-1.0) as fb:
+                        fb.run(2000, 64)
+                        fb.status()
+                    dtb = time.perf_counter() - tb
+                    best_dt = dtb if best_dt is None else min(best_dt, dtb)
+                rag[name] = {"wall_ms": best_dt * 1e3, "fits_per_s": Kb / best_dt,
+                             "units_per_s": 204.0 * float(np.sum(lengths)) * 6 * 2001 / best_dt}
+            rag["ragged_over_equal_fits_per_s"] = rag["ragged"]["fits_per_s"] / rag["equal"]["fits_per_s"]
+            rag["note"] = ("%d default-size swarms, 2000 generations each (stopping rule off), best of two runs: spectra of "
+                           "different lengths share a batch in the wave = particle geometry (a wave reads its fit's length "
+                           "from the fit's record); against equal lengths at the 512-multiple next to the mean" % Kb)
+            batched_fit["ragged_lengths"] = rag
             # ... and the user-level call, host side included: nmrfit_amd.fit_many on the same 40 spectra (weights and plans on
             # the host, one device batch, results into FitUtility objects)
             import contextlib

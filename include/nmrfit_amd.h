@@ -251,20 +251,30 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
                         const double *weights, const int32_t *P, const double *lower, const double *upper,
                         int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im,
                         nmrfit_batch **out);
+/* The same for spectra of DIFFERENT lengths (ABI 6): the reference's users crop every dataset to its own region
+ * (Data.select_bounds, nmrfit/containers.py:112-130), so the spectra of one study rarely share N.  N: K grid lengths;
+ * w, u, v, weights: the K spectra one after the other (fit k's N[k] points at offset N[0] + ... + N[k-1]).  Fits of
+ * different lengths run in the launch geometry that gives every particle one wave (the wave reads its fit's length and
+ * block structure from the fit's record); results stay bit-identical to each fit run alone.  nmrfit_batch_create is this
+ * call with K equal lengths. */
+int nmrfit_batch_create_ragged(int device, int32_t K, const int64_t *N, const double *w, const double *u, const double *v,
+                               const double *weights, const int32_t *P, const double *lower, const double *upper,
+                               int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im,
+                               nmrfit_batch **out);
 int nmrfit_batch_destroy(nmrfit_batch *batch);
 int nmrfit_batch_run(nmrfit_batch *batch, int64_t maxiter, int32_t check_every);
 int nmrfit_batch_status(nmrfit_batch *batch, int64_t *iteration, int32_t *stop_code, double *fg);
 int nmrfit_batch_best(nmrfit_batch *batch, double *x_best, double *f_best);
 /* FitUtility.generate_result (nmrfit/utils.py:226-295; README.md:64-72: fit -> generate_result) for EVERY fit of the
  * batch at its best position, ONE launch over the batch's resident grids and best rows (ABI 6) -- no context, no upload
- * of spectra per fit.  Outputs as nmrfit_generate_result's, fit after fit:
- *   w_out     NULL: every fit on its own grid (Nout ignored, taken as N); else K x Nout, fit k's output grid (the
- *             reference's np.linspace(w.min(), w.max(), int(scale * N)), utils.py:236)
- *   real_out, imag_out   (sum_k P[k]) x Nout, the peaks of fit 0, then of fit 1, ... (both or neither)
- *   fit_out   K x 4 x Nout (V_fit, I_fit, u_fit, v_fit of each fit);  data_out  K x 2 x N (V, I of each spectrum)
+ * of spectra per fit.  Outputs as nmrfit_generate_result's, fit after fit; with n_k the output length of fit k:
+ *   Nout, w_out   both NULL: every fit on its own grid (n_k = N[k]); else K output lengths and the K output grids one
+ *             after the other (the reference's np.linspace(w.min(), w.max(), int(scale * N)), utils.py:236)
+ *   real_out, imag_out   for fit 0, then fit 1, ...: P[k] rows of n_k doubles (both or neither)
+ *   fit_out   for each fit 4 x n_k (V_fit, I_fit, u_fit, v_fit);  data_out  for each fit 2 x N[k] (V, I of its spectrum)
  * Every value is bit-identical to what nmrfit_generate_result returns for that fit alone. */
-int nmrfit_batch_contributions(nmrfit_batch *batch, int64_t Nout, const double *w_out, double *real_out, double *imag_out,
-                               double *fit_out, double *data_out);
+int nmrfit_batch_contributions(nmrfit_batch *batch, const int64_t *Nout, const double *w_out, double *real_out,
+                               double *imag_out, double *fit_out, double *data_out);
 
 #ifdef __cplusplus
 }

@@ -3,10 +3,11 @@ Device-batched fits: K independent spectra fitted together, one kernel launch pe
 (``nmrfit_batch_*`` of libnmrfit_amd.so, csrc/batch.hip).
 
 The reference's users call ``nmrfit.fit`` once per spectrum (nmrfit/core.py:64, README.md:64-66), each fit a
-204-particle swarm (nmrfit/utils.py:177) -- a fraction of an MI355X.  ``FitBatch`` holds K spectra of equal length and
-K swarms of equal size on the device; every fit has its own peak count, box, seed and stopping rule, follows exactly
-the trajectory a lone ``nmrfit_amd.fit`` gives it (bit-identical ``params`` / ``error`` for the same seed) and stops on
-its own.  ``nmrfit_amd.fit_many`` builds these batches from a list of jobs.
+204-particle swarm (nmrfit/utils.py:177) -- a fraction of an MI355X.  ``FitBatch`` holds K spectra -- of any lengths:
+every dataset is cropped to its own region, nmrfit/containers.py:112-130 -- and K swarms of equal size on the device;
+every fit has its own grid, peak count, box, seed and stopping rule, follows exactly the trajectory a lone
+``nmrfit_amd.fit`` gives it (bit-identical ``params`` / ``error`` for the same seed) and stops on its own.
+``nmrfit_amd.fit_many`` builds these batches from a list of jobs.
 """
 import ctypes
 
@@ -18,8 +19,8 @@ from . import _cabi, equations, pso
 class FitBatch:
     """K fits on one GPU.
 
-    spectra : K tuples ``(w, u, v, weights)`` of equal length N (what FitUtility.fit passes as ``args``,
-              nmrfit/utils.py:176)
+    spectra : K tuples ``(w, u, v, weights)`` (what FitUtility.fit passes as ``args``, nmrfit/utils.py:176); the K
+              spectra may differ in length
     lowers, uppers : K parameter boxes, 4 + 3 P_k floats each (nmrfit/containers.py:193-217)
     swarmsize : particles per fit (the same for every fit of a batch)
     seeds : K integers (the swarm's random stream, like options['seed'] of ``fit``)
@@ -37,14 +38,15 @@ class FitBatch:
         K = len(spectra)
         if K == 0 or len(lowers) != K or len(uppers) != K:
             raise ValueError("FitBatch: as many boxes as spectra, at least one")
-        N = len(spectra[0][0])
-        planes = [np.empty((K, N)) for _ in range(4)]
-        self._w_range = [(np.min(sp[0]), np.max(sp[0])) for sp in spectra]      # (generate: the upsampled grids' ends)
+        Ns = np.array([len(sp[0]) for sp in spectra], dtype=np.int64)
+        noff = np.concatenate(([0], np.cumsum(Ns)))
+        planes = [np.empty(int(noff[-1])) for _ in range(4)]
         for k, sp in enumerate(spectra):
-            if any(len(a) != N for a in sp):
-                raise ValueError("FitBatch: every spectrum of a batch has the same length (fit %d differs)" % k)
+            if len(sp) != 4 or any(len(a) != Ns[k] for a in sp) or Ns[k] == 0:
+                raise ValueError("FitBatch: w, u, v, weights of a spectrum have the same non-zero length (fit %d)" % k)
             for a, plane in zip(sp, planes):
-                plane[k] = a            # (contiguous float64 rows: the reference hands out reversed views, core.py:60)
+                plane[noff[k]:noff[k + 1]] = a      # (contiguous float64: the reference hands out reversed views, core.py:60)
+        self._w_range = [(np.min(sp[0]), np.max(sp[0])) for sp in spectra]      # (generate: the upsampled grids' ends)
         lbs = [_cabi.f64(lo) for lo in lowers]
         ubs = [_cabi.f64(up) for up in uppers]
         self.D = []
@@ -54,7 +56,9 @@ class FitBatch:
             if lo.size < 4 or (lo.size - 4) % 3:
                 raise ValueError("bounds must have 4 + 3P entries (fit %d)" % k)
             self.D.append(int(lo.size))
-        self.K, self.N, self.S = K, N, int(swarmsize)
+        # N: the common grid length, or None when the spectra differ in length (Ns, noff: per fit)
+        self.K, self.Ns, self.noff, self.S = K, Ns, noff, int(swarmsize)
+        self.N = int(Ns[0]) if np.all(Ns == Ns[0]) else None
         self.P = np.array([(d - 4) // 3 for d in self.D], dtype=np.int32)
         self.offsets = np.concatenate(([0], np.cumsum(self.D)))
         lower = np.concatenate(lbs)
@@ -71,11 +75,11 @@ class FitBatch:
         prm = (_cabi.PsoParams * K)()
         for k in range(K):
             prm[k] = _cabi.PsoParams(om[k], pp[k], pg[k], ms[k], mf[k], self.seeds[k])
-        _cabi.check(self._lib.nmrfit_batch_create(int(device), K, N, _cabi.ptr(planes[0]), _cabi.ptr(planes[1]),
-                                                  _cabi.ptr(planes[2]), _cabi.ptr(planes[3]), _cabi.ptr(self.P),
-                                                  _cabi.ptr(lower), _cabi.ptr(upper), self.S, prm,
-                                                  _cabi.variant_id(variant), equations.fit_im_mode(fit_im),
-                                                  ctypes.byref(self._h)))
+        _cabi.check(self._lib.nmrfit_batch_create_ragged(int(device), K, _cabi.ptr(Ns), _cabi.ptr(planes[0]),
+                                                         _cabi.ptr(planes[1]), _cabi.ptr(planes[2]), _cabi.ptr(planes[3]),
+                                                         _cabi.ptr(self.P), _cabi.ptr(lower), _cabi.ptr(upper), self.S, prm,
+                                                         _cabi.variant_id(variant), equations.fit_im_mode(fit_im),
+                                                         ctypes.byref(self._h)))
 
     # -- life cycle ----------------------------------------------------------------------------
     def close(self):
@@ -118,34 +122,41 @@ class FitBatch:
     def generate(self, scale=1, grids=None):
         """FitUtility.generate_result for every fit of the batch at its best position (nmrfit/utils.py:226-295), ONE launch
         from the batch's resident spectra.  ``scale`` == 1: on each fit's own grid; else on
-        ``np.linspace(w.min(), w.max(), int(scale * N))`` per fit (utils.py:236; ``grids``: the K output grids, K x Nout,
-        if the caller has them).  Returns per fit a dict with ``w`` (None when scale == 1: the fit's own grid), ``real``,
+        ``np.linspace(w.min(), w.max(), int(scale * N_k))`` per fit (utils.py:236; ``grids``: the K output grids, if the
+        caller has them).  Returns per fit a dict with ``w`` (None when scale == 1: the fit's own grid), ``real``,
         ``imag`` ([P_k, Nout] each), ``V, I, u, v`` (the fit: utils.py:276-284) and ``data_V, data_I`` (the spectrum rotated
         by the fitted phase, what data.shift_phase(method='manual') stores, utils.py:251) -- all views of four arrays."""
-        K, N = self.K, self.N
+        K, Ns = self.K, self.Ns
         if scale == 1.0 and grids is None:
-            wout, n = None, N
+            wout = nout = None
+            n = Ns
         else:
             if grids is None:
-                n = int(scale * N)
-                grids = np.stack([np.linspace(lo, hi, n) for lo, hi in self._w_range])
-            wout = _cabi.f64(grids)
-            if wout.ndim != 2 or wout.shape[0] != K:
-                raise ValueError("FitBatch.generate: grids must be K x Nout")
-            n = wout.shape[1]
-        rows = int(self.P.sum())
-        real = np.empty((rows, n))
-        imag = np.empty((rows, n))
-        fit = np.empty((K, 4, n))
-        data = np.empty((K, 2, N))
-        _cabi.check(self._lib.nmrfit_batch_contributions(self._h, n, _cabi.ptr(wout), _cabi.ptr(real), _cabi.ptr(imag),
-                                                         _cabi.ptr(fit), _cabi.ptr(data)))
-        out, row = [], 0
+                grids = [np.linspace(lo, hi, int(scale * Ns[k])) for k, (lo, hi) in enumerate(self._w_range)]
+            if len(grids) != K:
+                raise ValueError("FitBatch.generate: one output grid per fit")
+            n = np.array([len(g) for g in grids], dtype=np.int64)
+            nout = n
+            wout = np.concatenate([_cabi.f64(g) for g in grids]) if K else np.empty(0)
+        P = self.P.astype(np.int64)
+        roff = np.concatenate(([0], np.cumsum(P * n)))          # contributions: P_k rows of n_k per fit
+        foff = np.concatenate(([0], np.cumsum(4 * n)))
+        woff = np.concatenate(([0], np.cumsum(n)))
+        real = np.empty(int(roff[-1]))
+        imag = np.empty(int(roff[-1]))
+        fit = np.empty(int(foff[-1]))
+        data = np.empty(2 * int(self.noff[-1]))
+        _cabi.check(self._lib.nmrfit_batch_contributions(self._h, _cabi.ptr(nout), _cabi.ptr(wout), _cabi.ptr(real),
+                                                         _cabi.ptr(imag), _cabi.ptr(fit), _cabi.ptr(data)))
+        out = []
         for k in range(K):
-            p = int(self.P[k])
-            out.append(dict(w=None if wout is None else wout[k], real=real[row:row + p], imag=imag[row:row + p],
-                            V=fit[k, 0], I=fit[k, 1], u=fit[k, 2], v=fit[k, 3], data_V=data[k, 0], data_I=data[k, 1]))
-            row += p
+            nk, Nk = int(n[k]), int(Ns[k])
+            f4 = fit[foff[k]:foff[k + 1]].reshape(4, nk)
+            d2 = data[2 * self.noff[k]:2 * self.noff[k + 1]].reshape(2, Nk)
+            out.append(dict(w=None if wout is None else wout[woff[k]:woff[k + 1]],
+                            real=real[roff[k]:roff[k + 1]].reshape(int(P[k]), nk),
+                            imag=imag[roff[k]:roff[k + 1]].reshape(int(P[k]), nk),
+                            V=f4[0], I=f4[1], u=f4[2], v=f4[3], data_V=d2[0], data_I=d2[1]))
         return out
 
     # -- diagnostics (include/nmrfit_amd_diag.h) ----------------------------------------------------

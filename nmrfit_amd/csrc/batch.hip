@@ -31,7 +31,10 @@ struct BatchPart {
     int compute_units = 0;
     hipStream_t stream = nullptr;
     int32_t K = 0;
-    int64_t N = 0, S = 0, n_chunks = 0;
+    int64_t N = 0;                       // the fits' common grid length, or 0 when they differ (ragged: wave = particle form only)
+    int64_t S = 0, n_chunks = 0;         // particles per fit; chunks of the LONGEST grid
+    std::vector<int64_t> Nk, noff;       // per fit: grid length; offset of its first point in the concatenated arrays (+ total)
+    int64_t Nmax = 0;
     int variant = NMRFIT_VARIANT_DEFAULT;
     int fit_im = NMRFIT_FIT_IM_OFF;
     int32_t Pmax = 0;
@@ -69,42 +72,37 @@ namespace {
 #pragma clang fp contract(off)
 
 struct PrepareArgs {
-    int K;
-    int64_t N, n_chunks;
-    const double *raw;       // [4][K][N]: w, u, v, weights as uploaded
-    const BatchFit *fits;    // any table: wc, u, v, wt, chunk, w0
+    int64_t plane;           // doubles per uploaded array (the sum of the fits' lengths)
+    const double *raw;       // [4][plane]: w, u, v, weights as uploaded, fit after fit
+    const BatchFit *fits;    // any table: wc, u, v, wt, chunk, w0, N, raw_off
 };
 
 // centred grid + scatter of the four arrays into the pair-interleaved order the kernels read (nmrfit_internal.h,
-// grid_slot), for every fit of the batch at once; the padding up to whole chunks was zeroed before
+// grid_slot), for every fit of the batch at once (blockIdx.y = the fit); the padding up to whole chunks was zeroed before
 __global__ void batch_prepare_kernel(PrepareArgs a)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)a.K * a.N) return;
-    const int k = (int)(idx / a.N);
-    const int64_t j = idx - (int64_t)k * a.N;
-    const BatchFit &f = a.fits[k];
+    const BatchFit &f = a.fits[blockIdx.y];
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= f.N) return;
+    const int64_t idx = f.raw_off + j;
     const int64_t slot = grid_slot(j);
-    const int64_t plane = (int64_t)a.K * a.N;
     const_cast<double *>(f.wc)[slot] = a.raw[idx] - f.w0;
-    const_cast<double *>(f.u)[slot] = a.raw[plane + idx];
-    const_cast<double *>(f.v)[slot] = a.raw[2 * plane + idx];
-    const_cast<double *>(f.wt)[slot] = a.raw[3 * plane + idx];
+    const_cast<double *>(f.u)[slot] = a.raw[a.plane + idx];
+    const_cast<double *>(f.v)[slot] = a.raw[2 * a.plane + idx];
+    const_cast<double *>(f.wt)[slot] = a.raw[3 * a.plane + idx];
 }
 
 // per-chunk (min, max) of every fit's centred grid: one wave per (fit, chunk)
 __global__ void batch_chunk_minmax_kernel(PrepareArgs a)
 {
+    const BatchFit &f = a.fits[blockIdx.y];
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t gc = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
-    if (gc >= (int64_t)a.K * a.n_chunks) return;
-    const int k = (int)(gc / a.n_chunks);
-    const int64_t c = gc - (int64_t)k * a.n_chunks;
-    const BatchFit &f = a.fits[k];
+    const int64_t c = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
+    if (c * kChunk >= f.N) return;
     double lo = INFINITY, hi = -INFINITY;
     for (int q = 0; q < kPointsPerLane; ++q) {
         const int64_t j = c * kChunk + q * kWave + lane;
-        if (j < a.N) {
+        if (j < f.N) {
             const double x = f.wc[grid_slot(j)];
             lo = fmin(lo, x);
             hi = fmax(hi, x);
@@ -225,7 +223,9 @@ int flush_fold(BatchPart *b)
 // the two launch geometries of a batch (objective.hip's launch_objective picks among the same forms for a lone swarm)
 void plan_geometry(BatchPart *b)
 {
-    const int64_t N = b->N;
+    // (ragged batches: the wave = particle form takes every fit's grid from its record; the launch record then carries
+    // the longest grid's figures, which that kernel does not read)
+    const int64_t N = b->N ? b->N : b->Nmax;
     const int64_t n_chunks = (N + kChunk - 1) / kChunk;
     const int blk_chunks = (int)((n_chunks + kMaxBlocks - 1) / kMaxBlocks);
     const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
@@ -252,6 +252,7 @@ void plan_geometry(BatchPart *b)
             int64_t seg_len = 0;
             for (int w : {kWideWaves, kWavesPerBlock}) {
                 if (b->fit_im != NMRFIT_FIT_IM_OFF) continue;   // (the imaginary channel: wave = particle only)
+                if (b->N == 0) continue;                        // (fits of different lengths: wave = particle only)
                 if (n_blocks < w) continue;
                 const int64_t sl = ((n_blocks + w - 1) / w) * blk_len;
                 if ((N + sl - 1) / sl != w) continue;
@@ -335,7 +336,8 @@ struct Carver {
 
 static int part_destroy(BatchPart *b);
 
-static int part_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
+// (w, u, v, weights: the part's fits one after the other, fit k's Nk[k] points at offset sum_{i<k} Nk[i])
+static int part_create(int device, int32_t K, const int64_t *Nk, const double *w, const double *u, const double *v,
                        const double *weights, const int32_t *P, const double *lower, const double *upper,
                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im, BatchPart **out)
 {
@@ -344,10 +346,15 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
         return NMRFIT_E_INVALID;
     }
     *out = nullptr;
-    if (K <= 0 || N <= 0 || swarmsize <= 0 || !w || !u || !v || !weights || !P || !lower || !upper || !params) {
+    if (K <= 0 || !Nk || swarmsize <= 0 || !w || !u || !v || !weights || !P || !lower || !upper || !params) {
         set_error("nmrfit_batch_create: K, N, swarmsize must be > 0 and every array non-null");
         return NMRFIT_E_INVALID;
     }
+    for (int32_t k = 0; k < K; ++k)
+        if (Nk[k] <= 0) {
+            set_error("nmrfit_batch_create: every grid length must be > 0");
+            return NMRFIT_E_INVALID;
+        }
     if (variant != NMRFIT_VARIANT_DEFAULT && variant != NMRFIT_VARIANT_FARFIELD) {
         set_error("nmrfit_batch_create: device-batched fits run the DEFAULT and FARFIELD kernels");
         return NMRFIT_E_UNSUPPORTED;
@@ -360,8 +367,8 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
         set_error("nmrfit_batch_create: the all-peak imaginary model runs the DEFAULT kernel (what nmrfit_amd.fit selects)");
         return NMRFIT_E_UNSUPPORTED;
     }
-    if (swarmsize > 0x7fffffffLL / 8) {
-        set_error("nmrfit_batch_create: swarm too large");
+    if (swarmsize > 0x7fffffffLL / 8 || K > 65535) {
+        set_error("nmrfit_batch_create: swarm too large, or more than 65535 fits in one part");
         return NMRFIT_E_INVALID;
     }
     int n = 0;
@@ -390,9 +397,17 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
     b->device = device;
     b->compute_units = prop.cus;
     b->K = K;
-    b->N = N;
+    b->Nk.assign(Nk, Nk + K);
+    b->noff.resize((size_t)K + 1);
+    b->noff[0] = 0;
+    b->N = Nk[0];
+    for (int32_t k = 0; k < K; ++k) {
+        b->noff[(size_t)k + 1] = b->noff[(size_t)k] + Nk[k];
+        b->Nmax = std::max(b->Nmax, Nk[k]);
+        if (Nk[k] != Nk[0]) b->N = 0;   // ragged
+    }
     b->S = swarmsize;
-    b->n_chunks = (N + kChunk - 1) / kChunk;
+    b->n_chunks = (b->Nmax + kChunk - 1) / kChunk;
     b->variant = variant;
     b->fit_im = fit_im;
     b->P.assign(P, P + K);
@@ -428,22 +443,27 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
     BATCH_HIP(take_stream(device, &b->stream));
     plan_geometry(b);
     if (!b->geom_ok[0] && !b->geom_ok[1]) {
-        set_error("nmrfit_batch_create: too many peaks for the kernel's LDS records in a batched launch");
+        set_error(b->N == 0 && b->fit_im == NMRFIT_FIT_IM_OFF
+                      ? "nmrfit_batch_create: fits of different grid lengths run in the wave = particle geometry, and these peak "
+                        "counts leave its LDS records no room"
+                      : "nmrfit_batch_create: too many peaks for the kernel's LDS records in a batched launch");
         part_destroy(b);
         return NMRFIT_E_UNSUPPORTED;
     }
     // ---- one allocation: per fit the four padded grid arrays + chunk table + swarm state; then the summary, the best
     // rows (+ their offsets), the descriptor tables, and the landing buffer of the upload
     const int64_t S = b->S;
-    const size_t padded = (size_t)b->n_chunks * kChunk * sizeof(double);
+    const int64_t Nsum = b->noff[(size_t)K];
+    auto chunks_of = [&](int32_t k) { return (b->Nk[(size_t)k] + kChunk - 1) / kChunk; };
+    auto padded_of = [&](int32_t k) { return (((size_t)chunks_of(k) * kChunk * sizeof(double)) + 255) & ~(size_t)255; };
     Carver c;
     std::vector<size_t> o_grid((size_t)K), o_chunk((size_t)K), o_lb((size_t)K), o_x((size_t)K), o_p((size_t)K), o_fx((size_t)K),
         o_cand((size_t)K), o_state((size_t)K);
     std::vector<size_t> state_bytes((size_t)K);
     for (int32_t k = 0; k < K; ++k) {
         const size_t D = (size_t)b->D[(size_t)k];
-        o_grid[(size_t)k] = c.take(4 * ((padded + 255) & ~(size_t)255));
-        o_chunk[(size_t)k] = c.take((size_t)b->n_chunks * sizeof(double2));
+        o_grid[(size_t)k] = c.take(4 * padded_of(k));
+        o_chunk[(size_t)k] = c.take((size_t)chunks_of(k) * sizeof(double2));
         o_lb[(size_t)k] = c.take(2 * ((D * sizeof(double) + 255) & ~(size_t)255));
         o_x[(size_t)k] = c.take(4 * (((size_t)S * D * sizeof(double) + 255) & ~(size_t)255));
         o_p[(size_t)k] = c.take(2 * ((((size_t)S * D + (size_t)S) * sizeof(double) + 255) & ~(size_t)255));
@@ -457,7 +477,7 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
     const size_t o_summary = c.take((size_t)K * 4 * sizeof(double));
     const size_t o_bestx = c.take((size_t)b->Dsum * sizeof(double) + (size_t)K * sizeof(int64_t));
     const size_t o_tables = c.take((size_t)9 * (size_t)K * sizeof(BatchFit));
-    const size_t o_raw = c.take((size_t)4 * (size_t)K * (size_t)N * sizeof(double));
+    const size_t o_raw = c.take((size_t)4 * (size_t)Nsum * sizeof(double));
     BATCH_HIP(hipMalloc(&b->d_block, c.total));
     unsigned char *base = reinterpret_cast<unsigned char *>(b->d_block);
     BATCH_HIP(hipMemsetAsync(base, 0, grid_state_end, b->stream));   // padding of the grid arrays (weight 0), state blocks
@@ -471,7 +491,7 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
     for (int32_t k = 0; k < K; ++k) {
         const size_t D = (size_t)b->D[(size_t)k];
         FitMem &m = mem[(size_t)k];
-        const size_t pad_al = (padded + 255) & ~(size_t)255;
+        const size_t pad_al = padded_of(k);
         m.wc = reinterpret_cast<double *>(base + o_grid[(size_t)k]);
         m.u = reinterpret_cast<double *>(base + o_grid[(size_t)k] + pad_al);
         m.v = reinterpret_cast<double *>(base + o_grid[(size_t)k] + 2 * pad_al);
@@ -499,8 +519,20 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
         f.wt = m.wt;
         f.chunk = m.chunk;
         double grid_dev = 0.0;
-        analyse_grid(w + (size_t)k * (size_t)N, N, &f.w0, &f.wspan, &f.lane_step, &grid_dev);
+        const int64_t N = b->Nk[(size_t)k];
+        analyse_grid(w + b->noff[(size_t)k], N, &f.w0, &f.wspan, &f.lane_step, &grid_dev);
         f.rec_devk = grid_dev * 11.0e10;   // (as launch_variant passes it: objective_kernel.h)
+        {
+            // the fit's own block structure: a function of its N only (objective.hip, launch_objective), one segment
+            const int64_t n_chunks = chunks_of(k);
+            const int blk_chunks = (int)((n_chunks + kMaxBlocks - 1) / kMaxBlocks);
+            const int64_t n_blocks = (n_chunks + blk_chunks - 1) / blk_chunks;
+            f.N = N;
+            f.blk_chunks = blk_chunks;
+            f.n_blocks = (int32_t)n_blocks;
+            f.seg_len = n_blocks * (int64_t)blk_chunks * kChunk;
+            f.raw_off = b->noff[(size_t)k];
+        }
         f.fx = m.fx;
         f.P = b->P[(size_t)k];
         const nmrfit_pso_params &prm = params[k];
@@ -557,7 +589,7 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
     BATCH_HIP(hipMemcpyAsync(b->d_tables, tabs.data(), tabs.size() * sizeof(BatchFit), hipMemcpyHostToDevice, b->stream));
     BATCH_HIP(hipMemcpyAsync(b->d_bestx + b->Dsum, b->boff.data(), (size_t)K * sizeof(int64_t), hipMemcpyHostToDevice, b->stream));
     // ---- spectra: four uploads, one scatter kernel, one chunk-table kernel
-    const size_t plane = (size_t)K * (size_t)N * sizeof(double);
+    const size_t plane = (size_t)Nsum * sizeof(double);
     const double *host_arrays[] = {w, u, v, weights};
     for (int a = 0; a < 4; ++a)
         BATCH_HIP(hipMemcpyAsync(reinterpret_cast<unsigned char *>(d_raw) + (size_t)a * plane, host_arrays[a], plane,
@@ -569,16 +601,12 @@ static int part_create(int device, int32_t K, int64_t N, const double *w, const 
     }
     {
         PrepareArgs a{};
-        a.K = K;
-        a.N = N;
-        a.n_chunks = b->n_chunks;
+        a.plane = Nsum;
         a.raw = d_raw;
         a.fits = b->d_tables;
-        const int64_t n = (int64_t)K * N;
-        hipLaunchKernelGGL(batch_prepare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, a);
+        hipLaunchKernelGGL(batch_prepare_kernel, dim3((unsigned)((b->Nmax + 255) / 256), (unsigned)K), dim3(256), 0, b->stream, a);
         BATCH_HIP(hipGetLastError());
-        const int64_t nc = (int64_t)K * b->n_chunks;
-        hipLaunchKernelGGL(batch_chunk_minmax_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(kWave * 4), 0, b->stream, a);
+        hipLaunchKernelGGL(batch_chunk_minmax_kernel, dim3((unsigned)((b->n_chunks + 3) / 4), (unsigned)K), dim3(kWave * 4), 0, b->stream, a);
         BATCH_HIP(hipGetLastError());
     }
     BATCH_HIP(hipStreamSynchronize(b->stream));   // (the host vectors go out of scope)
@@ -690,7 +718,7 @@ static int part_best(BatchPart *b, double *x_best, double *f_best)
 // FitUtility.generate_result (nmrfit/utils.py:226-295) for every fit of the part at its best position: ONE launch of the
 // reconstruction kernel (result.hip) over the part's resident grids and best rows, enqueued on the part's stream;
 // part_contributions_finish brings the arrays to the host (staged_d2h).  The host pointers are this part's shares.
-static int part_contributions_enqueue(BatchPart *b, int64_t Nout, const double *w_out, double *real_out, double *imag_out,
+static int part_contributions_enqueue(BatchPart *b, const int64_t *Nout, const double *w_out, double *real_out, double *imag_out,
                                       double *fit_out, double *data_out)
 {
     int rc = bind_batch(b);
@@ -705,9 +733,22 @@ static int part_contributions_enqueue(BatchPart *b, int64_t Nout, const double *
     }
     if ((rc = flush_fold(b)) != NMRFIT_OK) return rc;   // (the tail launch leaves every fit's best row in d_bestx)
     const int32_t K = b->K;
-    const int64_t N = b->N, Nn = w_out ? Nout : N;
-    const int64_t n_contrib = real_out ? b->Psum * Nn : 0, n_fit = fit_out ? (int64_t)K * 4 * Nn : 0,
-                  n_data = data_out ? (int64_t)K * 2 * N : 0, n_w = w_out ? (int64_t)K * Nout : 0;
+    // per fit: output length n_k (its own grid's, or Nout[k]); rows of contributions P_k x n_k; 4 x n_k; 2 x N_k
+    int64_t n_contrib = 0, n_fit = 0, n_w = 0, n_max = 0;
+    for (int32_t k = 0; k < K; ++k) {
+        const int64_t nk = w_out ? Nout[k] : b->Nk[(size_t)k];
+        if (nk < 0) {
+            set_error("nmrfit_batch_contributions: negative output length");
+            return NMRFIT_E_INVALID;
+        }
+        n_contrib += (int64_t)b->P[(size_t)k] * nk;
+        n_fit += 4 * nk;
+        n_w += w_out ? nk : 0;
+        n_max = std::max(n_max, nk);
+    }
+    if (!real_out) n_contrib = 0;
+    if (!fit_out) n_fit = 0;
+    const int64_t n_data = data_out ? 2 * b->noff[(size_t)K] : 0;
     if (2 * n_contrib + n_fit + n_data == 0) return NMRFIT_OK;
     const size_t jobs_bytes = ((size_t)K * sizeof(ResultJob) + 255) & ~(size_t)255;
     NMRFIT_HIP(hipMalloc(&b->d_result, jobs_bytes + (size_t)(n_w + 2 * n_contrib + n_fit + n_data) * sizeof(double)));
@@ -715,32 +756,35 @@ static int part_contributions_enqueue(BatchPart *b, int64_t Nout, const double *
     double *d_w = reinterpret_cast<double *>(base + jobs_bytes);
     double *d_real = d_w + n_w, *d_imag = d_real + n_contrib, *d_fit = d_imag + n_contrib, *d_data = d_fit + n_fit;
     std::vector<ResultJob> jobs((size_t)K);
-    int64_t prow = 0;
+    int64_t at_contrib = 0, at_fit = 0, at_w = 0;
     for (int32_t k = 0; k < K; ++k) {
         const BatchFit &f = b->h_fits[(size_t)k];
+        const int64_t nk = w_out ? Nout[k] : f.N;
         ResultJob &j = jobs[(size_t)k];
         j = ResultJob{};
         j.wc = f.wc;
-        j.w_plain = w_out ? d_w + (int64_t)k * Nout : nullptr;
+        j.w_plain = w_out ? d_w + at_w : nullptr;
         j.x = b->d_bestx + b->boff[(size_t)k];
         j.u = f.u;
         j.v = f.v;
         j.w0 = f.w0;
         j.wspan = f.wspan;
-        j.Nout = Nn;
-        j.N = N;
+        j.Nout = nk;
+        j.N = f.N;
         j.P = f.P;
-        j.real = real_out ? d_real + prow * Nn : nullptr;
-        j.imag = real_out ? d_imag + prow * Nn : nullptr;
-        j.fit = fit_out ? d_fit + (int64_t)k * 4 * Nn : nullptr;
-        j.data = data_out ? d_data + (int64_t)k * 2 * N : nullptr;
-        prow += f.P;
+        j.real = real_out ? d_real + at_contrib : nullptr;
+        j.imag = real_out ? d_imag + at_contrib : nullptr;
+        j.fit = fit_out ? d_fit + at_fit : nullptr;
+        j.data = data_out ? d_data + 2 * b->noff[(size_t)k] : nullptr;
+        at_contrib += (int64_t)f.P * nk;
+        at_fit += 4 * nk;
+        at_w += w_out ? nk : 0;
     }
     hipStream_t st = b->stream;
     // (pageable host memory: the copy has left `jobs` when hipMemcpyAsync returns)
     NMRFIT_HIP(hipMemcpyAsync(base, jobs.data(), (size_t)K * sizeof(ResultJob), hipMemcpyHostToDevice, st));
     if (n_w) NMRFIT_HIP(hipMemcpyAsync(d_w, w_out, (size_t)n_w * sizeof(double), hipMemcpyHostToDevice, st));
-    if ((rc = launch_result_jobs(st, reinterpret_cast<const ResultJob *>(base), K, std::max(Nn, data_out ? N : 0), b->Pmax)) != NMRFIT_OK)
+    if ((rc = launch_result_jobs(st, reinterpret_cast<const ResultJob *>(base), K, std::max(n_max, data_out ? b->Nmax : 0), b->Pmax)) != NMRFIT_OK)
         return rc;
     // what goes where on the host, for part_contributions_finish (the copies are staged and synchronous: they would
     // serialise the parts' launches if they were made here)
@@ -847,6 +891,8 @@ struct nmrfit_batch {
     std::vector<BatchPart *> parts;
     std::vector<int32_t> first;      // first fit of each part (+ K at the end)
     std::vector<int64_t> boff;       // offset of each fit's row in the concatenated bounds / best arrays (+ total)
+    std::vector<int64_t> noff;       // offset of each fit's first grid point in the concatenated spectra (+ total)
+    std::vector<int64_t> prow;       // peaks before each fit (+ total)
     int32_t K = 0;
     int device = -1;
 };
@@ -875,16 +921,16 @@ static int part_of(const nmrfit_batch *b, int32_t k)
 #pragma GCC visibility push(default)   // the C-ABI: the only symbols the library exports (build.sh: -fvisibility=hidden)
 extern "C" {
 
-int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
-                        const double *weights, const int32_t *P, const double *lower, const double *upper,
-                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im, nmrfit_batch **out)
+int nmrfit_batch_create_ragged(int device, int32_t K, const int64_t *N, const double *w, const double *u, const double *v,
+                               const double *weights, const int32_t *P, const double *lower, const double *upper,
+                               int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im, nmrfit_batch **out)
 {
     if (!out) {
         set_error("null out pointer");
         return NMRFIT_E_INVALID;
     }
     *out = nullptr;
-    if (K <= 0 || N <= 0 || swarmsize <= 0 || !w || !u || !v || !weights || !P || !lower || !upper || !params) {
+    if (K <= 0 || !N || swarmsize <= 0 || !w || !u || !v || !weights || !P || !lower || !upper || !params) {
         set_error("nmrfit_batch_create: K, N, swarmsize must be > 0 and every array non-null");
         return NMRFIT_E_INVALID;
     }
@@ -896,16 +942,22 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
     b->K = K;
     b->device = device;
     b->boff.resize((size_t)K + 1);
-    b->boff[0] = 0;
-    for (int32_t k = 0; k < K; ++k) b->boff[(size_t)k + 1] = b->boff[(size_t)k] + 4 + 3 * (int64_t)std::max(P[k], 0);
+    b->noff.resize((size_t)K + 1);
+    b->prow.resize((size_t)K + 1);
+    b->boff[0] = b->noff[0] = b->prow[0] = 0;
+    for (int32_t k = 0; k < K; ++k) {
+        b->boff[(size_t)k + 1] = b->boff[(size_t)k] + 4 + 3 * (int64_t)std::max(P[k], 0);
+        b->noff[(size_t)k + 1] = b->noff[(size_t)k] + std::max<int64_t>(N[k], 0);
+        b->prow[(size_t)k + 1] = b->prow[(size_t)k] + std::max(P[k], 0);
+    }
     int nparts = (K >= 6) ? 2 : 1;
     if (const char *e = getenv("NMRFIT_BATCH_STREAMS")) nparts = std::max(1, std::min(atoi(e), (int)std::min<int32_t>(K, 8)));
     for (int p = 0; p <= nparts; ++p) b->first.push_back((int32_t)((int64_t)K * p / nparts));
     for (int p = 0; p < nparts; ++p) {
         const int32_t f0 = b->first[(size_t)p], f1 = b->first[(size_t)p + 1];
+        const int64_t n0 = b->noff[(size_t)f0];
         BatchPart *part = nullptr;
-        const int rc = part_create(device, f1 - f0, N, w + (size_t)f0 * (size_t)N, u + (size_t)f0 * (size_t)N,
-                                   v + (size_t)f0 * (size_t)N, weights + (size_t)f0 * (size_t)N, P + f0,
+        const int rc = part_create(device, f1 - f0, N + f0, w + n0, u + n0, v + n0, weights + n0, P + f0,
                                    lower + b->boff[(size_t)f0], upper + b->boff[(size_t)f0], swarmsize, params + f0, variant,
                                    fit_im, &part);
         if (rc != NMRFIT_OK) {
@@ -916,6 +968,20 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
     }
     *out = b;
     return NMRFIT_OK;
+}
+
+int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const double *u, const double *v,
+                        const double *weights, const int32_t *P, const double *lower, const double *upper,
+                        int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im, nmrfit_batch **out)
+{
+    if (K <= 0 || N <= 0) {
+        if (out) *out = nullptr;
+        set_error("nmrfit_batch_create: K, N, swarmsize must be > 0 and every array non-null");
+        return NMRFIT_E_INVALID;
+    }
+    const std::vector<int64_t> lengths((size_t)K, N);
+    return nmrfit_batch_create_ragged(device, K, lengths.data(), w, u, v, weights, P, lower, upper, swarmsize, params, variant,
+                                      fit_im, out);
 }
 
 int nmrfit_batch_destroy(nmrfit_batch *b)
@@ -990,25 +1056,30 @@ int nmrfit_batch_best(nmrfit_batch *b, double *x_best, double *f_best)
     return rc;
 }
 
-int nmrfit_batch_contributions(nmrfit_batch *b, int64_t Nout, const double *w_out, double *real_out, double *imag_out,
+int nmrfit_batch_contributions(nmrfit_batch *b, const int64_t *Nout, const double *w_out, double *real_out, double *imag_out,
                                double *fit_out, double *data_out)
 {
     int rc = check_batch_handle(b);
     if (rc != NMRFIT_OK) return rc;
-    if ((w_out && Nout <= 0) || (!real_out != !imag_out)) {
-        set_error("nmrfit_batch_contributions: Nout > 0 with an output grid; real_out and imag_out together or not at all");
+    if ((w_out != nullptr) != (Nout != nullptr) || (!real_out != !imag_out)) {
+        set_error("nmrfit_batch_contributions: Nout and w_out together or not at all; real_out and imag_out likewise");
         return NMRFIT_E_INVALID;
     }
-    // every part enqueues its launch and copies on its own stream, then all are waited for
-    int64_t prow = 0;
+    // every part enqueues its launch on its own stream, then the copies back are made part after part.  A part's share of
+    // each output starts where the fits before it end.
+    int64_t at_contrib = 0, at_fit = 0, at_w = 0;
     for (size_t p = 0; p < b->parts.size() && rc == NMRFIT_OK; ++p) {
         BatchPart *q = b->parts[p];
-        const int32_t f0 = b->first[p];
-        const int64_t Nn = w_out ? Nout : q->N;
-        rc = part_contributions_enqueue(q, Nout, w_out ? w_out + (int64_t)f0 * Nout : nullptr, real_out ? real_out + prow * Nn : nullptr,
-                                        imag_out ? imag_out + prow * Nn : nullptr, fit_out ? fit_out + (int64_t)f0 * 4 * Nn : nullptr,
-                                        data_out ? data_out + (int64_t)f0 * 2 * q->N : nullptr);
-        prow += q->Psum;
+        const int32_t f0 = b->first[p], f1 = b->first[p + 1];
+        rc = part_contributions_enqueue(q, Nout ? Nout + f0 : nullptr, w_out ? w_out + at_w : nullptr,
+                                        real_out ? real_out + at_contrib : nullptr, imag_out ? imag_out + at_contrib : nullptr,
+                                        fit_out ? fit_out + at_fit : nullptr, data_out ? data_out + 2 * b->noff[(size_t)f0] : nullptr);
+        for (int32_t k = f0; k < f1; ++k) {
+            const int64_t nk = Nout ? std::max<int64_t>(Nout[k], 0) : b->noff[(size_t)k + 1] - b->noff[(size_t)k];
+            at_contrib += (b->prow[(size_t)k + 1] - b->prow[(size_t)k]) * nk;
+            at_fit += 4 * nk;
+            at_w += Nout ? nk : 0;
+        }
     }
     for (BatchPart *q : b->parts) {
         const int rc2 = part_contributions_finish(q);

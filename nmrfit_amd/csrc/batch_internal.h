@@ -15,6 +15,13 @@ struct BatchFit {
     const double *X;     // positions to evaluate when the launch does not move the swarm (generation 0)
     double *fx;          // objective values of this launch [S]
     int32_t P, pad;
+    // the fit's own grid (round 6: the fits of a batch may differ in length -- spectra cropped per dataset,
+    // nmrfit/containers.py:112-130 -- in the wave = particle geometry, whose kernel reads these instead of its launch
+    // arguments): length, the one segment's length (whole blocks), chunks per block, blocks per grid; and where the fit's
+    // points start in the planes of the upload
+    int64_t N, seg_len;
+    int32_t blk_chunks, n_blocks;
+    int64_t raw_off;
     PsoFused upd;        // x_in == null: plain evaluation of X
 };
 
@@ -23,7 +30,7 @@ struct BatchLaunch {
     const BatchFit *fits;   // device, K records
     int32_t K;
     int64_t S;              // particles per fit
-    int64_t N;
+    int64_t N;              // (the workgroup = particle form: equal for every fit; the wave form reads BatchFit::N)
     int nseg;
     int64_t seg_len;
     int blk_chunks;

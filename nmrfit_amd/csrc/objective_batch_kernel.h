@@ -41,9 +41,17 @@ __global__ __launch_bounds__(kWave *WPB, (WPB != kWavesPerBlock) ? 2 : (FIT_IM =
         }
     }
     const int64_t g = lblock * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    objective_body<VARIANT, false, FIT_IM, WPB, WAVE_SWARM>(lds_raw, g, lblock, d.wc, d.u, d.v, d.wt, d.chunk, d.X, S, P, N, d.w0,
-                                                      d.wspan, nseg, seg_len, blk_chunks, seg_blocks, n_blocks, d.lane_step, d.rec_devk, d.fx,
-                                                      nullptr, nullptr, d.upd, aux_off, wsums);
+    if constexpr (WAVE_SWARM) {
+        // one particle per wave, one segment: the grid's length and block structure are the FIT's (scalar loads from its
+        // record) -- the fits of a batch may differ in length
+        objective_body<VARIANT, false, FIT_IM, WPB, true>(lds_raw, g, lblock, d.wc, d.u, d.v, d.wt, d.chunk, d.X, S, P, d.N, d.w0,
+                                                          d.wspan, 1, d.seg_len, d.blk_chunks, d.n_blocks, d.n_blocks, d.lane_step,
+                                                          d.rec_devk, d.fx, nullptr, nullptr, d.upd, aux_off, wsums);
+    } else {
+        objective_body<VARIANT, false, FIT_IM, WPB, false>(lds_raw, g, lblock, d.wc, d.u, d.v, d.wt, d.chunk, d.X, S, P, N, d.w0,
+                                                           d.wspan, nseg, seg_len, blk_chunks, seg_blocks, n_blocks, d.lane_step,
+                                                           d.rec_devk, d.fx, nullptr, nullptr, d.upd, aux_off, wsums);
+    }
 }
 
 }  // namespace

@@ -206,7 +206,8 @@ class FitUtility:
 
     def _batch_key(self, plan):
         """The key under which core.fit_many may put this fit into a device batch with others (csrc/batch.hip: equal
-        grid length, swarm size, kernel variant and imaginary-channel mode) -- or None when it must run on its own."""
+        swarm size, kernel variant and imaginary-channel mode; the grids may differ in length) -- or None when it must
+        run on its own."""
         opt = self.options
         mode = equations.fit_im_mode(self.fit_im)
         if opt.get('exchange') is not None or opt.get('polish', False):
@@ -215,7 +216,7 @@ class FitUtility:
             return None
         if mode == _cabi.FIT_IM_SUM and plan['variant'] != _cabi.VARIANT_DEFAULT:
             return None
-        return (self._device(), len(self.data.w), int(plan['swarmsize']), plan['variant'], int(plan['maxiter']),
+        return (self._device(), None, int(plan['swarmsize']), plan['variant'], int(plan['maxiter']),
                 int(plan['check_every']), mode)
 
     def _finish(self, xopt, fopt):

@@ -36,7 +36,7 @@ def test_batch_key_groups_equal_shapes_only():
     a, b, c = _job(4096, 6, 1), _job(4096, 4, 2), _job(8192, 6, 3)
     big = _job(32768, 12, 4)
     ka, kb, kc = key(a), key(b), key(c)
-    assert ka is not None and ka == kb and kc != ka                 # peak counts may differ, grid lengths may not
+    assert ka is not None and ka == kb == kc                        # peak counts and (round 6) grid lengths may differ
     assert key(a, options={"swarmsize": 100}) != ka
     assert key(a, fit_im=True) not in (None, ka) and key(a, fit_im="sum") not in (None, ka, key(a, fit_im=True))
     assert key(big, fit_im="sum")[3] == _cabi.VARIANT_DEFAULT          # (every peak's imaginary line: the direct kernel)
@@ -119,9 +119,9 @@ def test_long_job_lists_go_through_spans_and_leftovers_find_partners(monkeypatch
     batched with the leftovers of the other spans, and what stays alone goes through fit() with the plan made for it."""
     monkeypatch.setattr(core, "BATCH_JOBS", 4)
     made, ran, collected, lone, batches = _fake_pipeline(monkeypatch)
-    # 10 jobs -> 3 spans of 4, 4, 2.  Grid lengths: span 0 = [A A A B], span 1 = [A A B C], span 2 = [A A]
-    lengths = [1024, 1024, 1024, 2048, 1024, 1024, 2048, 4096, 1024, 1024]
-    jobs = [_job(n, 2, 20 + k, options={"tag": k}) for k, n in enumerate(lengths)]
+    # 10 jobs -> 3 spans of 4, 4, 2.  Swarm sizes (a batch's fits share one): span 0 = [A A A B], span 1 = [A A B C], span 2 = [A A]
+    sizes = [100, 100, 100, 50, 100, 100, 50, 25, 100, 100]
+    jobs = [_job(1024, 2, 20 + k, options={"tag": k, "swarmsize": n}) for k, n in enumerate(sizes)]
     out = core.fit_many(jobs, threads=1)
     assert [f.options["tag"] for f in out] == list(range(10)) and all(f.error == 0.0 for f in out)
     me = threading.get_ident()
@@ -131,7 +131,7 @@ def test_long_job_lists_go_through_spans_and_leftovers_find_partners(monkeypatch
     assert [tags for _, tags, _ in collected] == [tags for _, tags in ran]       # read back in the order they ran ...
     assert len({tid for tid, _, _ in collected}) == 1 and collected[0][0] not in (me, made[0][0])   # ... on a third thread
     assert all(scale is False for _, _, scale in collected) and all(b.closed for b in batches)
-    assert lone == [(7, True)]                                                   # the only 4096-point job: its plan is reused
+    assert lone == [(7, True)]                                                   # the only 25-particle job: its plan is reused
     assert not hasattr(out[7], "generated")
 
 
@@ -139,7 +139,7 @@ def test_generate_reaches_batches_and_lone_fits(monkeypatch):
     """generate=True / a scale: the batches' read-back gets the scale, fits that ran alone get generate_result(scale)."""
     monkeypatch.setattr(core, "BATCH_JOBS", 4)
     made, ran, collected, lone, _ = _fake_pipeline(monkeypatch)
-    jobs = [_job(n, 2, 40 + k, options={"tag": k}) for k, n in enumerate([1024, 1024, 2048])]
+    jobs = [_job(1024, 2, 40 + k, options={"tag": k, "swarmsize": n}) for k, n in enumerate([100, 100, 50])]
     out = core.fit_many(jobs, threads=1, generate=True)
     assert [(tags, scale) for _, tags, scale in collected] == [([0, 1], 1)] and out[2].generated == 1
     collected.clear()
@@ -152,8 +152,8 @@ def test_a_batch_the_device_refuses_runs_as_lone_fits(monkeypatch):
     group's fits run one by one, the other groups stay batched."""
     monkeypatch.setattr(core, "BATCH_JOBS", 8)
     made, ran, collected, lone, batches = _fake_pipeline(monkeypatch, refuse={2})
-    lengths = [1024, 1024, 2048, 2048, 2048]
-    jobs = [_job(n, 2, 60 + k, options={"tag": k}) for k, n in enumerate(lengths)]
+    sizes = [100, 100, 50, 50, 50]
+    jobs = [_job(1024, 2, 60 + k, options={"tag": k, "swarmsize": n}) for k, n in enumerate(sizes)]
     out = core.fit_many(jobs, threads=1)
     assert [tags for _, tags in ran] == [[0, 1]]
     assert sorted(t for t, _ in lone) == [2, 3, 4] and all(had_plan for _, had_plan in lone)

@@ -341,13 +341,83 @@ def test_fit_many_over_the_devices_of_one_process():
         nmrfit_amd.fit_many(jobs, devices=[])
 
 
+@pytest.mark.parametrize("fit_im,variant", [(False, "default"), (False, "farfield"), (True, "default"), ("sum", "default")])
+def test_ragged_batch_trajectories_equal_lone_swarms_bit_for_bit(fit_im, variant):
+    """Round 6: the fits of a batch may differ in grid length (spectra cropped per dataset,
+    nmrfit/containers.py:112-130).  Lengths from one chunk to 13 (full and ragged last chunks, 1 to 4 chunks per block),
+    mixed peak counts, two parts: every fit's state after 0, 1, 2 and 25 generations equals the lone swarm's."""
+    lengths = [3000, 6000, 4096, 512, 700, 5555, 3333, 6144, 4500]
+    K, S = len(lengths), 33
+    problems = [synth.make_spectrum(n, 1 + (3 * k) % 7, seed=70 + k, physical=bool(fit_im)) for k, n in enumerate(lengths)]
+    seeds = [2000 + 3 * k for k in range(K)]
+    kw = dict(minstep=-1.0, minfunc=-1.0)
+    evs, sws = _lone_swarms(problems, S, seeds, variant, **kw)
+    try:
+        for ev in evs:
+            ev.set_fit_im(fit_im)
+        with _batch(problems, S, seeds, variant=variant, fit_im=fit_im, **kw) as fb:
+            assert fb.N is None and fb.geometry()["mode"] == "wave"
+            with pytest.raises(_cabi.NmrfitError):
+                fb.set_geometry("workgroup")          # (one launch geometry for all fits: the workgroup form needs equal lengths)
+            fb.step()
+            for sw in sws:
+                sw.init()
+                sw.step()
+            done = 0
+            for upto in (0, 1, 2, 25):
+                while done < upto:
+                    fb.step()
+                    for sw in sws:
+                        sw.step()
+                    done += 1
+                for k, sw in enumerate(sws):
+                    a, b = fb.state(k), sw.state()
+                    for name in ("x", "v", "p", "fp", "fx"):
+                        np.testing.assert_array_equal(a[name], b[name], err_msg="fit %d (N = %d) %s after %d" % (k, lengths[k], name, upto))
+            for k, ((x, f), sw) in enumerate(zip(fb.best(), sws)):
+                xb, fb_ = sw.best()
+                np.testing.assert_array_equal(x, xb)
+                assert f == fb_
+    finally:
+        _close(evs, sws)
+
+
+def test_fit_many_batches_spectra_of_different_lengths():
+    """fit_many: jobs whose spectra differ in length share a device batch (the key no longer holds N); results equal the
+    plain loop's bit for bit, with and without the reconstruction."""
+    import nmrfit_amd
+    rng = np.random.default_rng(3)
+    lengths = [int(n) for n in rng.integers(3000, 6001, 14)]
+    specs = [synth.make_spectrum(n, 2 + k % 5, seed=700 + k, physical=True) for k, n in enumerate(lengths)]
+
+    def jobs():
+        return [dict(data=synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"]), lower=list(sp["lower"]), upper=list(sp["upper"]),
+                     options={"seed": 40 + k, "swarmsize": 60, "maxiter": 90}) for k, sp in enumerate(specs)]
+    from nmrfit_amd import utils
+    keys = set()
+    for j in jobs():
+        f = utils.FitUtility(j["data"], j["lower"], j["upper"], options=j["options"])
+        keys.add(f._batch_key(f._plan()))
+    assert len(keys) == 1
+    many = nmrfit_amd.fit_many(jobs(), generate=1.25)
+    for k, job in enumerate(jobs()):
+        one = nmrfit_amd.fit(job["data"], job["lower"], job["upper"], summary=False, options=job["options"])
+        one.generate_result(1.25)
+        assert np.array_equal(many[k].params, one.params) and many[k].error == one.error, k
+        for name in ("u", "v", "V", "I", "w"):
+            np.testing.assert_array_equal(getattr(many[k], name), getattr(one, name), err_msg="%d %s" % (k, name))
+        np.testing.assert_array_equal(np.stack(many[k].imag_contribs), np.stack(one.imag_contribs))
+        np.testing.assert_array_equal(many[k].data.V, one.data.V)
+        assert many[k].w.shape == (int(1.25 * lengths[k]),)
+
+
 def test_batch_argument_validation():
     sp = synth.make_spectrum(4096, 3, seed=1)
     spec = (sp["w"], sp["u"], sp["v"], sp["weights"])
     with pytest.raises(AssertionError):
         FitBatch([spec], [sp["upper"]], [sp["lower"]])
-    with pytest.raises(ValueError):
-        FitBatch([spec, (sp["w"][:100], sp["u"][:100], sp["v"][:100], sp["weights"][:100])], [sp["lower"]] * 2, [sp["upper"]] * 2)
+    with pytest.raises(ValueError):      # the four arrays of ONE spectrum differ in length (spectra may differ from each other)
+        FitBatch([spec, (sp["w"][:100], sp["u"][:100], sp["v"][:99], sp["weights"][:100])], [sp["lower"]] * 2, [sp["upper"]] * 2)
     with pytest.raises(_cabi.NmrfitError) as ei:
         FitBatch([spec], [sp["lower"]], [sp["upper"]], variant="norec")
     assert ei.value.code == _cabi.E_UNSUPPORTED

@@ -183,6 +183,8 @@ def test_c4_rehearsal_four_ranks_on_one_gpu():
     assert bf["stopping_rule_off"]["fits_per_s"] > 2.0 * 1e3 / rf["wall_ms"]      # at least twice a loop of lone fits
     assert bf["stopping_rule_on"]["generations"]["max"] <= 2000 and bf["stopping_rule_on"]["fits_per_s"] > bf["stopping_rule_off"]["fits_per_s"]
     assert bf["stopping_rule_off"]["geometry"]["mode"] == "wave"
+    rg = bf["ragged_lengths"]            # round 6: spectra of different lengths in one batch
+    assert 3000 <= rg["lengths"]["min"] < rg["lengths"]["max"] <= 6000 and rg["ragged_over_equal_fits_per_s"] > 0.8
     e2e = bf["fit_many_end_to_end"]      # the user-level call on the same spectra (its own weights: FitUtility._compute_weights)
     assert 0.0 < e2e["stopping_rule_off"]["error_fit0"] < 0.05
     assert e2e["stopping_rule_on"]["fits_per_s"] > e2e["stopping_rule_off"]["fits_per_s"] > 2.0 * 1e3 / rf["wall_ms"]

@@ -158,6 +158,56 @@ def build(verbose=False, ab=False):
     return AB_LIB_PATH if ab else LIB_PATH
 
 
+STAMP_PATH = os.path.join(_HERE, "lib", "BUILD_STAMP.json")
+
+
+def source_digest():
+    """sha256 over the sources the library is built from (nmrfit_amd/csrc/*, include/*.h), names and contents, sorted."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    files = []
+    for d in (os.path.join(_HERE, "csrc"), os.path.join(root, "include")):
+        files += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".h", ".sh"))]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, root).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def file_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for block in iter(lambda: fh.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
+def write_stamp():
+    """What build() leaves next to the libraries it has just made: the digest of the sources and of each library file
+    (the build is deterministic -- fixed compilation-unit ids, csrc/build.sh -- so the same sources give the same
+    bytes).  __graft_entry__.smoke() checks the library it LOADED against this on the GPU box."""
+    import json
+    import time
+    stamp = {"source_sha256": source_digest(), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+             "libraries": {os.path.basename(p): {"sha256": file_sha256(p), "bytes": os.path.getsize(p)}
+                           for p in (LIB_PATH, AB_LIB_PATH) if os.path.exists(p)}}
+    with open(STAMP_PATH, "w") as fh:
+        json.dump(stamp, fh, indent=1)
+    return stamp
+
+
+def read_stamp():
+    import json
+    if not os.path.exists(STAMP_PATH):
+        return None
+    with open(STAMP_PATH) as fh:
+        return json.load(fh)
+
+
 def lib_path():
     """The library this process loads: NMRFIT_LIB if set (e.g. the A/B library), else the product library."""
     return os.environ.get("NMRFIT_LIB") or LIB_PATH

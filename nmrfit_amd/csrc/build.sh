@@ -27,11 +27,15 @@ for arg in "$@"; do
 done
 OBJ="$(mktemp -d "${TMPDIR:-/tmp}/nmrfit_build.XXXXXX")"
 trap 'rm -rf "$OBJ"' EXIT
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=on -fno-fast-math -I"$ROOT/include" -I"$HERE")
+# (-ffile-prefix-map: __FILE__ in the error messages is relative to the repository, so the library's bytes do not depend
+# on where the repository lies -- it is built here and checked against a rebuild on the GPU box)
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=on -fno-fast-math -ffile-prefix-map="$ROOT"=. -I"$ROOT/include" -I"$HERE")
 pids=()
 for u in "${UNITS[@]}"; do
     [ -f "$HERE/$u.hip" ] || continue
-    "$HIPCC" "${FLAGS[@]}" "${EXTRA[@]}" -c "$HERE/$u.hip" -o "$OBJ/$u.o" &
+    # (-cuid: the compilation-unit id hipcc otherwise hashes from the command line, temporary directory included; fixed, the
+    # same sources give the same device code bytes -- what __graft_entry__.smoke() compares on the GPU box)
+    "$HIPCC" "${FLAGS[@]}" "${EXTRA[@]}" -cuid="nmrfit_$u" -c "$HERE/$u.hip" -o "$OBJ/$u.o" &
     pids+=($!)
 done
 fail=0

@@ -153,3 +153,18 @@ def test_variant_names():
         _cabi.variant_id("fastest")
     with pytest.raises(ValueError):
         _cabi.variant_id(9)
+
+
+def test_build_stamp_names_the_sources_and_the_library(tmp_path, monkeypatch):
+    """build() leaves the digests of the sources and of the libraries next to them; smoke() checks the
+    library it loads against them on the GPU box (and rebuilds: the build is deterministic).  Here: the digest follows
+    the sources, and the stamp of the library on disk matches it."""
+    d0 = _cabi.source_digest()
+    assert len(d0) == 64 and d0 == _cabi.source_digest()
+    stamp = _cabi.read_stamp()
+    if stamp is not None and stamp["source_sha256"] == d0:      # (a library built by __graft_entry__.build() from these sources)
+        rec = stamp["libraries"]["libnmrfit_amd.so"]
+        assert rec["sha256"] == _cabi.file_sha256(_cabi.LIB_PATH) and rec["bytes"] == os.path.getsize(_cabi.LIB_PATH)
+    # the build script pins what would make two builds of the same sources differ
+    script = open(_cabi.BUILD_SCRIPT).read()
+    assert "-cuid=" in script and "-ffile-prefix-map=" in script

@@ -339,11 +339,19 @@ class FitUtility:
         return sats / (peaks + sats)
 
     def _print_summary(self):
-        """What FitUtility._print_summary reports (nmrfit/utils.py:324-339): the four global parameters, one row
-        per peak, the error.  Plain text tables; no pandas needed."""
+        """What FitUtility._print_summary reports (nmrfit/utils.py:324-339): the four global parameters, one row per
+        peak, the error -- through pandas' DataFrame.to_string(index=False) like the reference, so that whoever parses
+        the reference's summary parses this one; a plain-text table of the same columns only where pandas is missing."""
         values = np.asarray(self.params, dtype=float)
+        head, peak = ['p0', 'p1', 'r', 'y-off'], ['width', 'location', 'area']
+        try:
+            import pandas as pd
+        except ImportError:
+            pd = None
 
         def table(header, rows):
+            if pd is not None:
+                return pd.DataFrame(np.asarray(rows, dtype=float).reshape(-1, len(header)), columns=header).to_string(index=False)
             cells = [["%.6g" % x for x in row] for row in rows]
             widths = [max(len(h), *(len(c[k]) for c in cells)) for k, h in enumerate(header)]
             lines = [" ".join(h.rjust(n) for h, n in zip(header, widths))]
@@ -352,7 +360,7 @@ class FitUtility:
         print("\nFit Summary:")
         print("------------")
         print("Global parameters")
-        print(table(["p0", "p1", "r", "y-off"], [values[:4]]))
+        print(table(head, [values[:4]]))
         print("\nPeak parameters")
-        print(table(["width", "location", "area"], values[4:].reshape(-1, 3)))
+        print(table(peak, values[4:].reshape(-1, 3)))
         print("Error:\t", self.error)

@@ -131,3 +131,19 @@ def test_dense_swarm_generator_is_the_opposite_of_the_sparse_workload():
     sp = synth.make_spectrum(4096, 24, seed=1)
     assert sp["x_true"][4::3].max() < 0.01          # the headline workload's lines: 0.4-0.6 % of the span
     np.testing.assert_array_equal(X, synth.make_dense_swarm(64, 24, seed=5))      # seeded
+
+
+def test_summary_is_printed_through_pandas_like_the_reference(capsys):
+    """nmrfit/utils.py:324-339 prints DataFrame.to_string(index=False) tables; users who parse the
+    reference's stdout must find the same text."""
+    pd = pytest.importorskip("pandas")
+    from nmrfit_amd import utils
+    f = utils.FitUtility(None, [0] * 10, [1] * 10)
+    f.params = np.array([0.3123456789, -0.2, 0.6, 0.002, 0.004, 3.1, 0.005, 0.0051, 3.5, 0.0071])
+    f.error = 0.0123
+    f._print_summary()
+    out = capsys.readouterr().out
+    res = np.array(f.params)
+    want_globals = pd.DataFrame(res[:4].reshape((1, -1)), columns=['p0', 'p1', 'r', 'y-off']).to_string(index=False)
+    want_peaks = pd.DataFrame(res[4:].reshape((-1, 3)), columns=['width', 'location', 'area']).to_string(index=False)
+    assert out == "\nFit Summary:\n------------\nGlobal parameters\n%s\n\nPeak parameters\n%s\nError:\t 0.0123\n" % (want_globals, want_peaks)

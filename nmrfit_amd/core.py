@@ -55,7 +55,9 @@ def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, generate=Fa
       the values are bit-identical to the lone call's.  The data objects get ``p0, p1, V, I`` set to what
       ``data.shift_phase(method='manual', p0, p1)`` computes (nmrfit/containers.py:68-78) from the same launch; the
       method itself is called only on the lone path.
-    * whatever cannot be batched (``polish``, a lone shape, more than 132 peaks, a batch the device refuses) runs
+    * ``options['polish']``: the swarm runs in the batch, the least-squares refinement that follows it per fit on
+      ``threads`` host threads (scipy's trust-region iterations, a context per fit) -- the answers are the lone call's.
+    * whatever cannot be batched (a lone shape, more than 132 peaks, a batch the device refuses) runs
       through ``fit`` on ``threads`` host threads, each fit with its own context and HIP stream -- serially when
       ``options['exchange']`` is given: a communicator serves one swarm at a time.
     * ``shard=True`` in a multi-GPU launch (one process per GPU, RANK / WORLD_SIZE / LOCAL_RANK set by the launcher):
@@ -229,7 +231,7 @@ def _fit_many_local(jobs, threads, batch, kwargs, generate=False):
                     made.extend(r[0] for r in ready)
                     for fb, bfits, bplans, key, idx in ready:
                         fb.run(key[4], key[5])           # (maxiter, check_every): the device's generations, this thread
-                        posted.append(post.submit(_batch_collect, fb, bfits, bplans, key, scale))
+                        posted.append(post.submit(_batch_collect, fb, bfits, bplans, key, scale, threads))
                         batched.update(idx)
                 for c in range(len(spans)):
                     ready, single = pending.result()
@@ -296,15 +298,29 @@ def _fit_batch(fits, plans, key, generate=False):
     _batch_collect(fb, fits, plans, key, 1 if generate is True else generate)
 
 
-def _batch_collect(fb, fits, plans, key, scale=False):
+def _batch_collect(fb, fits, plans, key, scale=False, threads=1):
     """What follows a batch's generations: stop codes, best positions and -- ``scale`` not False -- the reconstruction
-    of every fit in one launch (FitBatch.generate), stored into the FitUtility objects; closes the batch."""
+    of every fit in one launch (FitBatch.generate), stored into the FitUtility objects; closes the batch.  Fits with
+    options['polish'] are refined first (FitUtility._polish, ``threads`` at a time) and reconstructed from the refined
+    parameters."""
     from .pso import STOP_MESSAGES
     maxiter = key[4]
+    polished = [k for k, f in enumerate(fits) if f.options.get('polish', False)]
     with fb:
         status = fb.status()
         best = fb.best()
-        results = fb.generate(scale) if scale is not False else None
+        results = fb.generate(scale) if scale is not False and len(polished) < len(fits) else None
+    if polished:
+        def refine(k):
+            return fits[k]._polish(best[k][0], best[k][1], plans[k])
+        if threads > 1 and len(polished) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=int(threads)) as pool:
+                refined = list(pool.map(refine, polished))
+        else:
+            refined = [refine(k) for k in polished]
+        for k, xf in zip(polished, refined):
+            best[k] = xf
     for k, (f, p, st, (x, fx)) in enumerate(zip(fits, plans, status, best)):
         # (pyswarm's closing line, once per fit like the plain loop prints it)
         if st["stop"]:
@@ -312,7 +328,10 @@ def _batch_collect(fb, fits, plans, key, scale=False):
         else:
             print('Stopping search: maximum iterations reached --> {:}'.format(maxiter))
         f._finish(x, fx)
-        if results is not None:
+        if k in polished:
+            if scale is not False:
+                f.generate_result(scale)      # (from the refined parameters: the batch's launch used the swarm's)
+        elif results is not None:
             r = results[k]
             f._store_result(f.data.w if r["w"] is None else r["w"], r["real"], r["imag"],
                             (r["V"], r["I"], r["u"], r["v"]), (r["data_V"], r["data_I"]), call_shift_phase=False)

@@ -66,16 +66,18 @@ namespace {
 // FIT_IM: 0 real part only (reference default); 1 reference-compatible fit_im=True -- the
 // imaginary model is the LAST peak's dispersion only, because equations.py:199 assigns
 // instead of accumulating; 2 the imaginary model is the sum over all peaks.
-// The 8-peak group keeps 24 per-peak constants live next to the 8-point register block:
-// ~152 VGPRs, i.e. 3 waves per SIMD (measured faster than 4 peaks per reciprocal at 4 waves).
-// FIT_IM == 1 evaluates the last peak's dispersion line at the chunk's points in the epilogue
-// (dispersion_points, Dawson coefficients from LDS): the direct kernels keep three waves per SIMD, the
-// far-field one takes two rather than spilling; FIT_IM == 2 holds eight more accumulators and the
-// far-field sums: two waves.
-// launch bounds (waves per SIMD the compiler must leave room for), by variant and imaginary-channel mode.  The direct
-// kernels with the imaginary sum fit in 168 VGPRs, i.e. run at THREE waves per SIMD, with the bound left at two: asked
-// for three the compiler stops at 160 registers and schedules worse (2.86 against 2.57 ms at C3, round 4); the far-field
-// kernels with the imaginary channel take two rather than spilling.
+// Registers and occupancy of the selectable kernels (tools/kernel_resources.py, checked by
+// tests/test_kernel_resources_cpu.py; figures of the round-6 build): the headline objective kernel <DEFAULT, real part
+// only, four waves per workgroup> 127 VGPRs -- FOUR waves per SIMD, no scratch -- with the 8-peak group's 24 constants,
+// the 8-point register block and the batch inversion's intermediates live together; FARFIELD 119.
+// FIT_IM == 1 evaluates the last peak's dispersion line at the chunk's points in the epilogue (dispersion_points, Dawson
+// coefficients from LDS): three waves per SIMD (DEFAULT 131 VGPRs, FARFIELD 142).  FIT_IM == 2 holds eight more
+// accumulators and the imaginary far-field sums: the direct kernel 156 VGPRs (three waves), the far-field one 190 (two
+// waves, which is why fit() never selects it for the all-peak imaginary model: utils.default_variant).
+// Launch bounds (waves per SIMD the compiler must leave room for), by variant and imaginary-channel mode: the direct
+// kernels with the imaginary sum run at three waves per SIMD with the bound left at two -- asked for three the compiler
+// stops at 160 registers and schedules worse (2.86 against 2.57 ms at C3, round 4); the far-field kernels with the
+// imaginary channel take two rather than spilling.
 constexpr int objective_min_waves(int variant, int fit_im)
 {
     const bool tuned = variant == NMRFIT_VARIANT_DEFAULT || variant == NMRFIT_VARIANT_NOSKIP || variant == NMRFIT_VARIANT_STAGED ||

@@ -210,7 +210,7 @@ class FitUtility:
         run on its own."""
         opt = self.options
         mode = equations.fit_im_mode(self.fit_im)
-        if opt.get('exchange') is not None or opt.get('polish', False):
+        if opt.get('exchange') is not None:
             return None
         if plan['variant'] not in (_cabi.VARIANT_DEFAULT, _cabi.VARIANT_FARFIELD) or len(self.lower) > 400:
             return None
@@ -283,6 +283,21 @@ class FitUtility:
                 exchange.close()
             ev.close()
         self._finish(xopt, fopt)
+
+    def _polish(self, xopt, fopt, plan):
+        """options['polish'] for a fit whose swarm ran in a device batch (core.fit_many): the same least-squares
+        refinement fit() applies, on a context made like fit()'s (weights, kernel variant, imaginary-channel mode), so
+        the polished answer is the lone call's bit for bit.  The trust-region iterations are scipy's, one fit at a time
+        on the host (each Jacobian is one launch of D + 1 residual rows): they do not run in lock step across fits."""
+        from . import lsq
+        ev = equations.Evaluator(self.data.w, self.data.u, self.data.v, self.weights, device=self._device())
+        try:
+            ev.set_fit_im(self.fit_im)
+            ev.set_variant(plan['variant'])
+            xopt, fopt, _ = lsq.polish(ev, xopt, self.lower, self.upper, fit_im=self.fit_im)
+        finally:
+            ev.close()
+        return xopt, fopt
 
     def generate_result(self, scale=1):
         """utils.py:226-295: per-peak real and imaginary contributions of the fitted parameters

@@ -40,7 +40,7 @@ def test_batch_key_groups_equal_shapes_only():
     assert key(a, options={"swarmsize": 100}) != ka
     assert key(a, fit_im=True) not in (None, ka) and key(a, fit_im="sum") not in (None, ka, key(a, fit_im=True))
     assert key(big, fit_im="sum")[3] == _cabi.VARIANT_DEFAULT          # (every peak's imaginary line: the direct kernel)
-    assert key(a, options={"polish": True}) is None
+    assert key(a, options={"polish": True}) == ka                     # (round 6: the swarm of a polished fit runs in the batch)
     assert key(a, options={"exchange": object()}) is None
     assert key(a, options={"variant": "norec"}) is None
     assert key(big)[3] == _cabi.VARIANT_FARFIELD and key(a)[3] == _cabi.VARIANT_DEFAULT
@@ -63,7 +63,7 @@ def test_jobs_with_a_communicator_run_one_after_another(monkeypatch):
     assert len(out) == 5
     # without a communicator the same call may use the pool (order of completion is free, results keep job order)
     calls.clear()
-    jobs = [_job(1024, 2, 10 + k, options={"tag": k, "polish": True}) for k in range(5)]      # (polish: not batchable)
+    jobs = [_job(1024, 2, 10 + k, options={"tag": k, "variant": "norec"}) for k in range(5)]      # (NOREC: not batchable)
     out = core.fit_many(jobs, threads=4)
     assert sorted(t for _, t in calls) == [0, 1, 2, 3, 4] and [f.options["tag"] for f in out] == [0, 1, 2, 3, 4]
 
@@ -93,8 +93,9 @@ def _fake_pipeline(monkeypatch, refuse=()):
         batches.append(_FakeBatch(ran, tags))
         return batches[-1], fits, plans, key
 
-    def fake_collect(fb, fits, plans, key, scale=False):
+    def fake_collect(fb, fits, plans, key, scale=False, threads=1):
         collected.append((threading.get_ident(), fb.tags, scale))
+        assert threads >= 1
         for f in fits:
             f.params, f.error = np.zeros(len(f.lower)), 0.0
         fb.close()

@@ -83,3 +83,23 @@ def test_fit_with_polish_option():
     b = nmrfit_amd.fit(data, list(sp["lower"]), list(sp["upper"]), summary=False,
                        options={"swarmsize": 64, "maxiter": 100, "seed": 3, "polish": True})
     assert b.error <= a.error
+
+
+def test_fit_many_with_polish_equals_the_lone_fits():
+    """options['polish'] in fit_many: the swarms run as one device batch, the refinement per fit on host threads with a
+    context made like fit()'s -- params and error equal the lone fit(polish=True) bit for bit; with generate=True the
+    reconstruction is made from the REFINED parameters."""
+    import nmrfit_amd
+    specs = [synth.make_spectrum(2048, 2 + k % 2, seed=30 + k, physical=True) for k in range(5)]
+
+    def jobs():
+        return [dict(data=synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"]), lower=list(sp["lower"]), upper=list(sp["upper"]),
+                     options={"swarmsize": 64, "maxiter": 100, "seed": 3 + k, "polish": k != 1}) for k, sp in enumerate(specs)]
+    many = nmrfit_amd.fit_many(jobs(), generate=True, threads=3)
+    for k, job in enumerate(jobs()):
+        one = nmrfit_amd.fit(job["data"], job["lower"], job["upper"], summary=False, options=job["options"])
+        one.generate_result()
+        np.testing.assert_array_equal(many[k].params, one.params, err_msg=str(k))
+        assert many[k].error == one.error
+        np.testing.assert_array_equal(many[k].V, one.V)
+        np.testing.assert_array_equal(many[k].u, one.u)

@@ -104,7 +104,7 @@ size_t objective_lds(int variant, int32_t P, bool residual, int fit_im, int *var
                             (size_t)wpb * kMaxBlocks * sizeof(double2) + kSharedPrologueBytes +
                             (slices == 1 ? 0 : (size_t)wpb * 2 * kWave * sizeof(double));   // per-wave lane phase seeds
     const size_t lds_stage = (size_t)wpb * 3 * kChunk * sizeof(double);
-    const size_t lds_far = (size_t)wpb * kFarTerms * kFarPad * sizeof(double);
+    const size_t lds_far = (size_t)wpb * far_stride(fit_im) * sizeof(double);
     // Gaussian recurrence constants (d, C) per peak: objective launches of DEFAULT / FARFIELD
     const size_t lds_rec = residual ? 0 : (size_t)slices * np * sizeof(double2);
     const size_t lds_fast = (size_t)slices * np * sizeof(PeakFast);   // scaled records of the two-operation pair form (DEFAULT)

@@ -78,11 +78,14 @@ namespace {
 // kernels with the imaginary sum run at three waves per SIMD with the bound left at two -- asked for three the compiler
 // stops at 160 registers and schedules worse (2.86 against 2.57 ms at C3, round 4); the far-field kernels with the
 // imaginary channel take two rather than spilling.
+#ifndef NMRFIT_IM2_FAR_WAVES
+#define NMRFIT_IM2_FAR_WAVES 2   // (A/B knob)
+#endif
 constexpr int objective_min_waves(int variant, int fit_im)
 {
     const bool tuned = variant == NMRFIT_VARIANT_DEFAULT || variant == NMRFIT_VARIANT_NOSKIP || variant == NMRFIT_VARIANT_STAGED ||
                        is_farfield(variant) || variant == NMRFIT_VARIANT_NOREC;
-    return (fit_im != 0 && is_farfield(variant)) ? 2 : (fit_im == 2) ? 2 : tuned ? kMinWaves : 4;
+    return (fit_im == 2 && is_farfield(variant)) ? NMRFIT_IM2_FAR_WAVES : (fit_im != 0 && is_farfield(variant)) ? 2 : (fit_im == 2) ? 2 : tuned ? kMinWaves : 4;
 }
 // WAVE_SWARM (device-batched fits, objective_batch.hip): every WAVE holds a whole particle (one segment) and does
 // the particle's whole swarm step by itself -- deferred fold, update, evaluation, personal best (swarm_prologue.h).
@@ -146,14 +149,18 @@ __device__ __forceinline__ void objective_body(
     double *stage = reinterpret_cast<double *>(lds_tail2) + (size_t)wave * (3 * kChunk);
     // FARFIELD: per-wave scratch [kFarTerms][kFarPad] for the cross-peak coefficient sums
     // (shares the offset of `stage`; the two variants are exclusive)
-    double *ffs = reinterpret_cast<double *>(lds_tail2) + (size_t)wave * (kFarTerms * kFarPad);
+    double *ffs = reinterpret_cast<double *>(lds_tail2) + (size_t)wave * far_stride(FIT_IM);
+    // FIT_IM == 2: where the even chunk of a pair parks the odd chunk's 16 coefficient sums (expand_sums).  Without the
+    // imaginary sum they wait in slots 16..31 of the scratch's first row; the all-peak imaginary pass uses every row of
+    // the scratch for its own expansions, so there they wait in a row of their own behind it.
+    // (at ffs + kFarTerms * kFarPad)
 
     // objective launches of DEFAULT / FARFIELD: per-peak (d, C) of the Gaussian recurrence, after
     // everything else (residual rows are evaluated point by point: they feed finite differences)
     constexpr bool kRec = !WRITE_R && (VARIANT == NMRFIT_VARIANT_DEFAULT || is_farfield(VARIANT));
     unsigned char *grec_base = lds_tail2 +
                         (kStage ? (size_t)WPB * 3 * kChunk * sizeof(double)
-                                : (is_farfield(VARIANT) || FIT_IM == 2) ? (size_t)WPB * kFarTerms * kFarPad * sizeof(double) : 0);
+                                : (is_farfield(VARIANT) || FIT_IM == 2) ? (size_t)WPB * far_stride(FIT_IM) * sizeof(double) : 0);
     double2 *grec = reinterpret_cast<double2 *>(grec_base) + (size_t)slice * P;
 
     // DEFAULT: scaled Lorentzian constants for the two-operation pair form, after grec
@@ -161,10 +168,10 @@ __device__ __forceinline__ void objective_body(
     PeakFast *lorf = reinterpret_cast<PeakFast *>(grec_base + (kRec ? (size_t)nslices * P * sizeof(double2) : 0)) +
                      (size_t)slice * P;
 
-    // FIT_IM != 0: Dawson table (16 intervals x 19 coefficients for the gathered evaluation, then the 12 of the
+    // FIT_IM != 0: Dawson table (64 quarter intervals x 11 coefficients for the gathered evaluation, then the 12 of the
     // asymptotic series), one copy per workgroup; the barrier after the staging below makes it visible
     double *dtab = reinterpret_cast<double *>(lds_raw + aux_off);
-    if constexpr (FIT_IM != 0)   // kTab[16][19], then kFar[12]
+    if constexpr (FIT_IM != 0)   // kTab[64][11], then kFar[12]
         for (int i = threadIdx.x; i < kDawTabCount; i += WPB * kWave)
             dtab[i] = (i < kDawTabFar) ? (&dawson::kTab[0][0])[i] : dawson::kFar[i - kDawTabFar];
     phase_stamp(clk, 0);
@@ -450,7 +457,11 @@ __device__ __forceinline__ void objective_body(
         for (int j = 0; j < 16; ++j) part += row[j];
         part += __shfl_xor(part, 1, kWave);
         wave_lds_fence();   // reads issued before the sums overwrite row 0
-        if ((lane & 1) == 0) ffs[((lane & 2) << 3) + (lane >> 2)] = part;
+        if constexpr (FIT_IM == 2) {
+            if ((lane & 1) == 0) ffs[((lane & 2) ? kFarTerms * kFarPad : 0) + (lane >> 2)] = part;
+        } else {
+            if ((lane & 1) == 0) ffs[((lane & 2) << 3) + (lane >> 2)] = part;
+        }
         wave_lds_fence();
     };
     auto chunk = [&](const int64_t jb, auto full_tag, auto odd_tag) {
@@ -536,7 +547,7 @@ __device__ __forceinline__ void objective_body(
                 const double hw = wave_uniform(0.5 * (mm.y - mm.x));
                 double cf[kFarTerms];
                 bool horner_done = false;
-                if (P <= 32 && FIT_IM != 2) {   // (the all-peak imaginary pass below reuses the scratch that parks the odd chunk's sums)
+                if (P <= 32) {
                     // Half a wave of peaks: the even chunks of a segment work out the expansions
                     // of TWO chunks at once -- lanes 0..31 for this chunk, lanes 32..63 for the
                     // next -- and park the second set (sums in LDS, masks in SGPRs) for the odd
@@ -549,7 +560,7 @@ __device__ __forceinline__ void objective_body(
                     const unsigned near_c = ff_odd ? pend_near : even_near;
                     const unsigned hits_c = ff_odd ? pend_hits : even_hits;
                     wave_lds_fence();
-                    const double *src = ffs + (ff_odd ? kFarTerms : 0);
+                    const double *src = ffs + (ff_odd ? (FIT_IM == 2 ? kFarTerms * kFarPad : kFarTerms) : 0);
 #pragma unroll
                     for (int n = 0; n < kFarTerms; ++n) cf[n] = src[n];
                     {

@@ -36,6 +36,9 @@ constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coeff
                                    // (DEFAULT: 5e4) all the same: 12 cycles per chunk PAIR, from the per-lane reads of the
                                    // 32-byte peak records (lanes i and i + 8 of a ds_read_b128 group share banks) -- 0.3 % of a
                                    // pair's ~4500 cycles, not worth a padded record (profiles/r04/farfield_c3_pmc_summary.json)
+// doubles of far-field scratch per wave: the rows -- and, with the all-peak imaginary model, one more row where the even chunk
+// of a pair parks the odd chunk's coefficient sums (the imaginary pass uses every row of the scratch itself)
+constexpr int far_stride(int fit_im) { return kFarTerms * kFarPad + (fit_im == 2 ? kFarTerms : 0); }
 constexpr size_t kSharedPrologueBytes = ((2 + 2 * kWave) * sizeof(double) + 16 * sizeof(int) + 15) & ~(size_t)15;
 constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
 
@@ -295,21 +298,22 @@ __device__ __forceinline__ double dispersion(double wcj, const PeakLor &r)
     return __builtin_fma(r.al * t, rcp64(s), (r.ag2 * kInvSqrtPi) * dawson(kSqrtLn2 * t));
 }
 
-// Dawson's integral for the objective's imaginary channel: the same piecewise fits, but one
-// degree-18 polynomial for EVERY unit interval [k, k+1), k = 0..15, gathered from a 2.4 KiB table
-// in LDS by a per-lane index -- no divergent branches (the lanes of a wave sit in two or three
-// different intervals), 19 FMAs + 19 broadcast-friendly LDS reads.  Beyond 16 the asymptotic form
-// (a branch almost no wave takes: such peaks are summed through the far-field expansion).
-constexpr int kDawTabFar = 16 * 19, kDawTabCount = 16 * 19 + 12;   // kTab[16][19], then kFar[12]
+// Dawson's integral for the objective's imaginary channel: the same kind of piecewise fits, but one polynomial for
+// EVERY quarter interval [k/4, (k+1)/4) of |x| < 16, gathered from a 5.6 KiB table in LDS by a per-lane index -- no
+// divergent branches (the lanes of a wave sit in a few different intervals).  Round 6: quarter intervals of degree 10
+// (11 FMAs + 11 LDS reads per point, |error| <= 3.3e-16 absolute) instead of unit intervals of degree 18 (19 + 19):
+// these evaluations are the largest item of the all-peak imaginary model's cost.  Beyond 16 the asymptotic form (a
+// branch almost no wave takes: such peaks are summed through the far-field expansion).
+constexpr int kDawTabFar = dawson::kTabIntervals * dawson::kTabCoeffs, kDawTabCount = kDawTabFar + 12;   // kTab[64][11], then kFar[12]
 __device__ __forceinline__ double dawson_tab(double x, const double *tab)
 {
     const double ax = fabs(x);
-    const int k = (int)fmin(ax, 15.0);                 // NaN -> 15
-    const double t = __builtin_fma(2.0, ax - (double)k, -1.0);
-    const double *q = tab + k * 19;
-    double p = q[18];
+    const int k = (int)fmin(4.0 * ax, (double)(dawson::kTabIntervals - 1));   // NaN -> the last interval
+    const double t = __builtin_fma(8.0, ax, -(double)(2 * k + 1));
+    const double *q = tab + k * dawson::kTabCoeffs;
+    double p = q[dawson::kTabCoeffs - 1];
 #pragma unroll
-    for (int i = 17; i >= 0; --i) p = __builtin_fma(p, t, q[i]);
+    for (int i = dawson::kTabCoeffs - 2; i >= 0; --i) p = __builtin_fma(p, t, q[i]);
     if (!(ax < 16.0)) {
         const double inv = rcp64(ax);                  // NaN/inf propagate: D(inf) = 0
         const double s2 = 49.0 * inv * inv;

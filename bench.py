@@ -68,8 +68,8 @@ PEAK_CLOCK_MHZ = 2400.0        # MI355X_MICROARCH.md
 LAUNCHER_GRACE_S = 15.0        # self-launcher: how much later than the ranks' own watchdogs its deadline falls
 FP64_ISSUE_CYCLES = 4.0        # one wave64 fp64 VALU instruction occupies a SIMD's issue port for 4 cycles
 VALU_PER_UNIT_C3 = 5.76        # fp64 VALU instructions per (particle, point, peak) of the headline kernel at C3 (profiles/r05/bench_c3_pmc_summary.json)
-PMC_SUMMARIES = [os.path.join("profiles", r, "bench_c3_pmc_summary.json") for r in ("r05", "r04", "r03", "r02", "r01")]
-FARFIELD_PMC_SUMMARIES = [os.path.join("profiles", r, "farfield_c3_pmc_summary.json") for r in ("r05", "r04", "r03")]
+PMC_SUMMARIES = [os.path.join("profiles", r, "bench_c3_pmc_summary.json") for r in ("r06", "r05", "r04", "r03", "r02", "r01")]
+FARFIELD_PMC_SUMMARIES = [os.path.join("profiles", r, "farfield_c3_pmc_summary.json") for r in ("r06", "r05", "r04", "r03")]
 
 
 def parse():

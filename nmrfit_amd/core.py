@@ -227,20 +227,25 @@ def _fit_many_local(jobs, threads, batch, kwargs, generate=False):
             pending = host.submit(prepare, spans[0])
             posted = []
             try:
-                def run(ready):
+                def run(ready, last=False):
                     made.extend(r[0] for r in ready)
-                    for fb, bfits, bplans, key, idx in ready:
+                    for n, (fb, bfits, bplans, key, idx) in enumerate(ready):
                         fb.run(key[4], key[5])           # (maxiter, check_every): the device's generations, this thread
-                        posted.append(post.submit(_batch_collect, fb, bfits, bplans, key, scale, threads))
+                        if last and n == len(ready) - 1 and not posted:
+                            # the only batch of the call: nothing to overlap its read-back with -- here, without a
+                            # thread's first HIP call in the way (a 40-job list is 30 ms in all)
+                            _batch_collect(fb, bfits, bplans, key, scale, threads)
+                        else:
+                            posted.append(post.submit(_batch_collect, fb, bfits, bplans, key, scale, threads))
                         batched.update(idx)
                 for c in range(len(spans)):
                     ready, single = pending.result()
                     pending = host.submit(prepare, spans[c + 1]) if c + 1 < len(spans) else None
                     leftover.extend(single)
-                    run(ready)
+                    run(ready, last=(c + 1 == len(spans) and not any(key is not None for _, key in leftover)))
                 # what found no partner inside its span may have one in another
                 ready, _ = group([(i, key) for i, key in leftover if key is not None])
-                run(ready)
+                run(ready, last=True)
                 for p in posted:
                     p.result()
             except BaseException:

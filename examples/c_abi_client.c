@@ -9,7 +9,8 @@
  * It builds a three-line spectrum, evaluates a small swarm through nmrfit_objective_batch and
  * nmrfit_residual_batch, checks them against the textbook formulas written out below
  * (reference: nmrfit/equations.py:115-149 voigt, :152-212 objective; nmrfit/proc_autophase.py:9-37
- * ps2), then lets the device-resident swarm (nmrfit_pso_run) fit the spectrum.
+ * ps2), then lets the device-resident swarm (nmrfit_pso_run) fit the spectrum, fits three spectra as one device batch,
+ * reconstructs the three fits in one launch (nmrfit_batch_contributions) and runs a batch of spectra of different lengths.
  */
 #include <math.h>
 #include <stdio.h>
@@ -232,8 +233,64 @@ int main(int argc, char **argv)
         CHECK(nmrfit_batch_best(batch, xK, fK));
         printf("batch of %d fits: %lld generations each, best f = %.3e %.3e %.3e\n", K, (long long)itK[0], fK[0], fK[1], fK[2]);
         if (fK[0] != fb || memcmp(xK, xb, sizeof xb) != 0) return 10;
+
+        /* The reconstruction that follows a fit (FitUtility.generate_result, nmrfit/utils.py:226-295) for all three fits
+         * in ONE launch from the batch's resident spectra: per-peak lines, their sums, the fit rotated back to (u, v) and
+         * the spectrum rotated by the fitted phase -- against the formulas above and against the one-fit call. */
+        static double realK[K * P * N], imagK[K * P * N], fitK[K * 4 * N], dataK[K * 2 * N];
+        static double real1[P * N], imag1[P * N], fit1[4 * N], data1[2 * N];
+        CHECK(nmrfit_batch_contributions(batch, NULL, NULL, realK, imagK, fitK, dataK));
+        CHECK(nmrfit_generate_result(ctx, P, xK, 0, NULL, real1, imag1, fit1, data1));
+        if (memcmp(realK, real1, sizeof real1) || memcmp(imagK, imag1, sizeof imag1) || memcmp(fitK, fit1, sizeof fit1) ||
+            memcmp(dataK, data1, sizeof data1)) {
+            fprintf(stderr, "batched reconstruction differs from the one-fit call\n");
+            return 11;
+        }
+        double worst_r = 0.0, scale = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double *xk = xK + k * D;
+            for (int j = 0; j < N; j += 7) {
+                double vsum = 0.0;
+                for (int q = 0; q < P; ++q) {
+                    const double want = voigt(w[j], xk[2], xk[3], xk[4 + 3 * q], xk[5 + 3 * q], xk[6 + 3 * q]);
+                    worst_r = fmax(worst_r, fabs(realK[((size_t)k * P + q) * N + j] - want));
+                    scale = fmax(scale, fabs(want));
+                    vsum += realK[((size_t)k * P + q) * N + j];
+                }
+                if (vsum != fitK[(size_t)k * 4 * N + j]) return 11;                      /* V_fit: the same additions */
+                const double phi = xk[0] + xk[1] * (double)j / (double)N;
+                const double vd = u[j] * cos(phi) - v[j] * sin(phi);
+                worst_r = fmax(worst_r, fabs(dataK[(size_t)k * 2 * N + j] - vd));
+                const double vf = fitK[(size_t)k * 4 * N + j], iif = fitK[(size_t)k * 4 * N + N + j];
+                worst_r = fmax(worst_r, fabs(fitK[(size_t)k * 4 * N + 2 * N + j] - (vf * cos(phi) + iif * sin(phi))));
+            }
+        }
+        printf("reconstruction of %d fits in one launch: max abs deviation from the formulas %.2e (scale %.2e)\n", K, worst_r, scale);
+        if (!(worst_r < 1e-12 * scale)) return 11;
+        if (nmrfit_batch_contributions(batch, NULL, w, realK, imagK, NULL, NULL) != NMRFIT_E_INVALID) return 11;   /* grids without lengths */
         CHECK(nmrfit_batch_destroy(batch));
         if (nmrfit_batch_run(NULL, 1, 1) != NMRFIT_E_INVALID) return 10;
+
+        /* Spectra of DIFFERENT lengths in one batch (every dataset is cropped to its own region,
+         * nmrfit/containers.py:112-130): the first 3000, 2200 and 1000 points of the spectrum, concatenated.  Fit 0 is
+         * again the lone swarm. */
+        const int64_t NK[K] = {N, 2200, 1000};
+        int64_t at = 0;
+        for (int k = 0; k < K; ++k) {
+            memcpy(wK + at, w, (size_t)NK[k] * sizeof(double));
+            memcpy(uK + at, u, (size_t)NK[k] * sizeof(double));
+            memcpy(vK + at, v, (size_t)NK[k] * sizeof(double));
+            memcpy(wtK + at, wt, (size_t)NK[k] * sizeof(double));
+            at += NK[k];
+        }
+        CHECK(nmrfit_batch_create_ragged(0, K, NK, wK, uK, vK, wtK, PK, loK, hiK, 204, prmK, NMRFIT_VARIANT_DEFAULT,
+                                         NMRFIT_FIT_IM_OFF, &batch));
+        CHECK(nmrfit_batch_run(batch, 1000, 100));
+        CHECK(nmrfit_batch_best(batch, xK, fK));
+        printf("ragged batch (%lld, %lld, %lld points): best f = %.3e %.3e %.3e\n", (long long)NK[0], (long long)NK[1],
+               (long long)NK[2], fK[0], fK[1], fK[2]);
+        if (fK[0] != fb || memcmp(xK, xb, sizeof xb) != 0) return 12;
+        CHECK(nmrfit_batch_destroy(batch));
     }
 
     /* errors come back as codes, never as crashes */

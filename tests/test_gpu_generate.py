@@ -125,6 +125,38 @@ def test_batch_generate_equals_the_lone_generate_result_bit_for_bit(K, N, S, sca
         np.testing.assert_array_equal(r["data_I"], data.I)
 
 
+def test_batch_generate_edge_shapes():
+    """Spectra of 1, 64, 513 and 700 points in one batch, peak counts 0, 1, 2, 3 (a fit without peaks: V = I = 0, u = v = 0),
+    own grids and upsampled ones (int(2.5 * 1) = 2 points): against the lone call, bit for bit."""
+    lengths, peaks = [1, 64, 513, 700], [0, 1, 2, 3]
+    problems = []
+    for k, (n, p) in enumerate(zip(lengths, peaks)):
+        sp = synth.make_spectrum(max(n, 8), p, seed=800 + k, physical=True)
+        for name in ("w", "u", "v", "weights"):
+            sp[name] = sp[name][:n]
+        problems.append(sp)
+    with FitBatch([(sp["w"], sp["u"], sp["v"], sp["weights"]) for sp in problems], [sp["lower"] for sp in problems],
+                  [sp["upper"] for sp in problems], swarmsize=16, seeds=[5, 6, 7, 8]) as fb:
+        fb.run(10, 5)
+        best = fb.best()
+        for scale in (1, 2.5):
+            res = fb.generate(scale)
+            for k, (sp, (x, _)) in enumerate(zip(problems, best)):
+                fu, data = _lone_result(sp, x, scale)
+                r = res[k]
+                n = lengths[k] if scale == 1 else int(scale * lengths[k])
+                assert r["real"].shape == (peaks[k], n) and r["V"].shape == (n,) and r["data_V"].shape == (lengths[k],)
+                for name in ("V", "I", "u", "v"):
+                    np.testing.assert_array_equal(r[name], getattr(fu, name), err_msg="%d %s %r" % (k, name, scale))
+                if peaks[k]:
+                    np.testing.assert_array_equal(r["real"], np.stack(fu.real_contribs))
+                    np.testing.assert_array_equal(r["imag"], np.stack(fu.imag_contribs))
+                else:
+                    assert not fu.real_contribs and not np.any(r["V"]) and not np.any(r["u"])
+                np.testing.assert_array_equal(r["data_V"], data.V)
+                np.testing.assert_array_equal(r["data_I"], data.I)
+
+
 def test_batch_generate_before_the_first_generation_is_a_state_error():
     from nmrfit_amd import _cabi
     problems = _problems(2, 1024)

@@ -43,10 +43,10 @@ def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, generate=Fa
     * ``batch=True`` (default): jobs of equal grid length, swarm size, kernel variant and ``fit_im`` are fitted as
       ONE device batch -- one kernel launch per swarm generation for all of them (nmrfit_amd.batch.FitBatch,
       csrc/batch.hip).  A 204-particle swarm fills a fraction of an MI355X; a batch fills it.  Each fit's ``params`` and
-      ``error`` are bit-identical to what ``fit`` returns for it alone with the same ``options['seed']``.  Long job
-      lists go through batches of about ``nmrfit_amd.core.BATCH_JOBS`` (64) jobs, three stages in flight: a second host
-      thread prepares the next batch (error weights, plans, device state) while the device runs the current one and a
-      third reads back the one before.
+      ``error`` are bit-identical to what ``fit`` returns for it alone with the same ``options['seed']``.  Job lists go
+      through batches of a quarter of the list, between 40 and 200 jobs (``nmrfit_amd.core.BATCH_JOBS`` overrides),
+      three stages in flight: a second host thread prepares the next batch (error weights, plans, device state) while
+      the device runs the current one and a third reads back the one before.
     * ``generate=True`` (or a number: the ``scale`` of ``FitUtility.generate_result``): the rest of the reference's
       per-spectrum script, README.md:64-72 -- every returned fit has had ``generate_result(scale)`` called on it
       (nmrfit/utils.py:226-295: ``u, v, V, I, w, real_contribs, imag_contribs``; ``calculate_area_fraction()`` then
@@ -175,11 +175,20 @@ def _cabi_device_count():
     return _cabi.device_count()
 
 
-# Jobs per device batch in fit_many.  From ~40 default-size fits on a batch holds the MI355X's issue rate
-# (DESIGN.md 4.5), so longer job lists are cut into batches of about this many: the host prepares batch c + 1
-# (error weights, plans, the batch's device state) on a second thread while the device runs batch c and a third thread
-# reads back batch c - 1 (status, best positions, the reconstruction of generate=...).
-BATCH_JOBS = 64
+# Jobs per device batch in fit_many.  From ~40 default-size fits on a batch holds the MI355X's issue rate (DESIGN.md
+# 4.5), and a long list wants large batches (1000 default jobs with pyswarm's rule: 2050 fits/s in batches of 64, 2270 in
+# batches of 200) while a short one wants at least four of them, so that the three stages overlap -- the host prepares
+# batch c + 1 (error weights, plans, device state) on a second thread while the device runs batch c and a third thread
+# reads back batch c - 1 (200 jobs: 1970 fits/s in batches of 50, 1740 as one batch; profiles/r06/fit_many_span_sweep.txt).
+# BATCH_JOBS = None: that rule (a quarter of the list, between 40 and 200); a number: batches of about that many.
+BATCH_JOBS = None
+BATCH_JOBS_MIN, BATCH_JOBS_MAX, PIPELINE_BATCHES = 40, 200, 4
+
+
+def _batch_jobs(n):
+    if BATCH_JOBS is not None:
+        return max(1, int(BATCH_JOBS))
+    return min(BATCH_JOBS_MAX, max(BATCH_JOBS_MIN, -(-n // PIPELINE_BATCHES)))
 
 
 def _fit_many_local(jobs, threads, batch, kwargs, generate=False):
@@ -194,7 +203,7 @@ def _fit_many_local(jobs, threads, batch, kwargs, generate=False):
     alone = list(range(len(fits)))
     if batch and len(fits) > 1:
         n = len(fits)
-        nspans = -(-n // BATCH_JOBS)
+        nspans = -(-n // _batch_jobs(n))
         size = -(-n // nspans)
         spans = [range(a, min(a + size, n)) for a in range(0, n, size)]
 

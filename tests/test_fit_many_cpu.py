@@ -220,6 +220,18 @@ def test_the_rank_device_reaches_jobs_that_bring_their_own_options(monkeypatch):
     assert got == [(4, 1), (5, None)]
 
 
+def test_batch_size_rule():
+    """Jobs per device batch: a quarter of the list, between 40 and 200 (profiles/r06/fit_many_span_sweep.txt); a number in
+    core.BATCH_JOBS overrides."""
+    assert core.BATCH_JOBS is None
+    assert [core._batch_jobs(n) for n in (2, 40, 100, 200, 400, 1000, 5000)] == [40, 40, 40, 50, 100, 200, 200]
+    try:
+        core.BATCH_JOBS = 64
+        assert core._batch_jobs(1000) == 64
+    finally:
+        core.BATCH_JOBS = None
+
+
 def test_small_shard_warning():
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")

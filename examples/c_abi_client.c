@@ -227,7 +227,12 @@ int main(int argc, char **argv)
             prmK[k].seed = prm.seed + (uint64_t)k;
         }
         nmrfit_batch *batch = NULL;
-        CHECK(nmrfit_batch_create(0, K, N, wK, uK, vK, wtK, PK, loK, hiK, 204, prmK, NMRFIT_VARIANT_DEFAULT, NMRFIT_FIT_IM_OFF, &batch));
+        /* the kernel variant of the lone swarm above: DEFAULT, unless the test knob NMRFIT_DEFAULT_VARIANT makes the
+         * far-field kernel every context's default (the batch names its variant itself) */
+        int variant = NMRFIT_VARIANT_DEFAULT;
+        const char *knob = getenv("NMRFIT_DEFAULT_VARIANT");
+        if (knob && atoi(knob) == NMRFIT_VARIANT_FARFIELD) variant = NMRFIT_VARIANT_FARFIELD;
+        CHECK(nmrfit_batch_create(0, K, N, wK, uK, vK, wtK, PK, loK, hiK, 204, prmK, variant, NMRFIT_FIT_IM_OFF, &batch));
         CHECK(nmrfit_batch_run(batch, 1000, 100));
         CHECK(nmrfit_batch_status(batch, itK, stopK, NULL));
         CHECK(nmrfit_batch_best(batch, xK, fK));
@@ -283,8 +288,7 @@ int main(int argc, char **argv)
             memcpy(wtK + at, wt, (size_t)NK[k] * sizeof(double));
             at += NK[k];
         }
-        CHECK(nmrfit_batch_create_ragged(0, K, NK, wK, uK, vK, wtK, PK, loK, hiK, 204, prmK, NMRFIT_VARIANT_DEFAULT,
-                                         NMRFIT_FIT_IM_OFF, &batch));
+        CHECK(nmrfit_batch_create_ragged(0, K, NK, wK, uK, vK, wtK, PK, loK, hiK, 204, prmK, variant, NMRFIT_FIT_IM_OFF, &batch));
         CHECK(nmrfit_batch_run(batch, 1000, 100));
         CHECK(nmrfit_batch_best(batch, xK, fK));
         printf("ragged batch (%lld, %lld, %lld points): best f = %.3e %.3e %.3e\n", (long long)NK[0], (long long)NK[1],

@@ -457,14 +457,13 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
     auto chunks_of = [&](int32_t k) { return (b->Nk[(size_t)k] + kChunk - 1) / kChunk; };
     auto padded_of = [&](int32_t k) { return (((size_t)chunks_of(k) * kChunk * sizeof(double)) + 255) & ~(size_t)255; };
     Carver c;
-    std::vector<size_t> o_grid((size_t)K), o_chunk((size_t)K), o_lb((size_t)K), o_x((size_t)K), o_p((size_t)K), o_fx((size_t)K),
+    std::vector<size_t> o_grid((size_t)K), o_chunk((size_t)K), o_x((size_t)K), o_p((size_t)K), o_fx((size_t)K),
         o_cand((size_t)K), o_state((size_t)K);
     std::vector<size_t> state_bytes((size_t)K);
     for (int32_t k = 0; k < K; ++k) {
         const size_t D = (size_t)b->D[(size_t)k];
         o_grid[(size_t)k] = c.take(4 * padded_of(k));
         o_chunk[(size_t)k] = c.take((size_t)chunks_of(k) * sizeof(double2));
-        o_lb[(size_t)k] = c.take(2 * ((D * sizeof(double) + 255) & ~(size_t)255));
         o_x[(size_t)k] = c.take(4 * (((size_t)S * D * sizeof(double) + 255) & ~(size_t)255));
         o_p[(size_t)k] = c.take(2 * ((((size_t)S * D + (size_t)S) * sizeof(double) + 255) & ~(size_t)255));
         o_fx[(size_t)k] = c.take((size_t)S * sizeof(double));
@@ -473,6 +472,8 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
         state_bytes[(size_t)k] = (((2 + 2 * D) * sizeof(double) + 2 * sizeof(long long)) + 255) & ~(size_t)255;
         o_state[(size_t)k] = c.take(2 * state_bytes[(size_t)k]);
     }
+    // the K boxes, concatenated like the caller's arrays: two uploads for the whole part (they were 2 K small ones, ~8 us each)
+    const size_t o_lball = c.take((size_t)b->Dsum * sizeof(double)), o_uball = c.take((size_t)b->Dsum * sizeof(double));
     const size_t grid_state_end = c.total;
     const size_t o_summary = c.take((size_t)K * 4 * sizeof(double));
     const size_t o_bestx = c.take((size_t)b->Dsum * sizeof(double) + (size_t)K * sizeof(int64_t));
@@ -497,9 +498,8 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
         m.v = reinterpret_cast<double *>(base + o_grid[(size_t)k] + 2 * pad_al);
         m.wt = reinterpret_cast<double *>(base + o_grid[(size_t)k] + 3 * pad_al);
         m.chunk = reinterpret_cast<double2 *>(base + o_chunk[(size_t)k]);
-        const size_t d_al = (D * sizeof(double) + 255) & ~(size_t)255;
-        m.lb = reinterpret_cast<double *>(base + o_lb[(size_t)k]);
-        m.ub = reinterpret_cast<double *>(base + o_lb[(size_t)k] + d_al);
+        m.lb = reinterpret_cast<double *>(base + o_lball) + b->boff[(size_t)k];
+        m.ub = reinterpret_cast<double *>(base + o_uball) + b->boff[(size_t)k];
         const size_t sd_al = ((size_t)S * D * sizeof(double) + 255) & ~(size_t)255;
         m.x = reinterpret_cast<double *>(base + o_x[(size_t)k]);
         m.vel = reinterpret_cast<double *>(base + o_x[(size_t)k] + sd_al);
@@ -594,11 +594,8 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
     for (int a = 0; a < 4; ++a)
         BATCH_HIP(hipMemcpyAsync(reinterpret_cast<unsigned char *>(d_raw) + (size_t)a * plane, host_arrays[a], plane,
                                  hipMemcpyHostToDevice, b->stream));
-    for (int32_t k = 0; k < K; ++k) {
-        const FitMem &m = mem[(size_t)k];
-        BATCH_HIP(hipMemcpyAsync(m.lb, lower + b->boff[(size_t)k], (size_t)b->D[(size_t)k] * sizeof(double), hipMemcpyHostToDevice, b->stream));
-        BATCH_HIP(hipMemcpyAsync(m.ub, upper + b->boff[(size_t)k], (size_t)b->D[(size_t)k] * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    }
+    BATCH_HIP(hipMemcpyAsync(base + o_lball, lower, (size_t)b->Dsum * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    BATCH_HIP(hipMemcpyAsync(base + o_uball, upper, (size_t)b->Dsum * sizeof(double), hipMemcpyHostToDevice, b->stream));
     {
         PrepareArgs a{};
         a.plane = Nsum;

@@ -386,6 +386,7 @@ __device__ __forceinline__ void objective_body(
 
     unsigned even_near = 0, even_hits = 0;     // FARFIELD, P <= 32: near-peak and Gaussian-window masks of the even ...
     unsigned pend_near = 0, pend_hits = 0;     // ... and of the odd chunk of the current pair (expand_pair)
+    unsigned even_near_im = 0, pend_near_im = 0, pair_far_im = 0;   // FIT_IM == 2, P <= 32: the same for the imaginary model (expand_pair_im)
 
     // The chunk loop exists twice, once per Lorentzian group form, chosen ONCE per wave: inside one
     // copy the accumulators never meet the other form's registers (a merge of the two forms per
@@ -450,7 +451,7 @@ __device__ __forceinline__ void objective_body(
     };
     // ... second half: lane l sums order l>>2 over 16 peaks (quarter rows padded to 17 doubles), lanes l, l^1 hold
     // the halves of one chunk; sums of the pair's first chunk -> slots 0..15, of its second -> slots 16..31
-    auto expand_sums = [&]() {
+    auto expand_sums = [&](const int park) {   // park: where the second chunk's sums go (doubles from ffs; FIT_IM == 2 only)
         const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
         double part = 0.0;
 #pragma unroll
@@ -458,11 +459,85 @@ __device__ __forceinline__ void objective_body(
         part += __shfl_xor(part, 1, kWave);
         wave_lds_fence();   // reads issued before the sums overwrite row 0
         if constexpr (FIT_IM == 2) {
-            if ((lane & 1) == 0) ffs[((lane & 2) ? kFarTerms * kFarPad : 0) + (lane >> 2)] = part;
+            if ((lane & 1) == 0) ffs[((lane & 2) ? park : 0) + (lane >> 2)] = part;
         } else {
             if ((lane & 1) == 0) ffs[((lane & 2) << 3) + (lane >> 2)] = part;
         }
         wave_lds_fence();
+    };
+    // FIT_IM == 2: one lane's 16 coefficients of the far-field form of ITS peak's imaginary line about a chunk centre --
+    // al Re(q m^n) by the real two-term recurrence + the Gaussian's asymptotic series expanded binomially (see the
+    // imaginary block of the chunk below) -- written to the lane's column of the wave's scratch.  Lanes without a far
+    // peak write exact zeros.
+    auto im_rows = [&](const bool farim, const double tc, const double hk, const double rq, const double al, const double agd) {
+        const double qr = tc * rq, qi = rq;
+        const double mr = -hk * qr, mi = -hk * qi;
+        const double a2 = farim ? mr + mr : 0.0;
+        const double b2 = farim ? -__builtin_fma(mr, mr, mi * mi) : 0.0;
+        double y0 = farim ? al * qr : 0.0;
+        double y1 = farim ? al * __builtin_fma(qr, mr, -(qi * mi)) : 0.0;
+        // Gaussian dispersion: agd * sum_j A_j x^-(2j+1), x = xc (1 - eps u), eps = -hk/tc:
+        // coefficient of u^n = agd eps^n sum_j B_j binom(2j + n, n), B_j = A_j xc^-(2j+1)
+        double B[kDawFarTerms];
+        {
+            const double xc = farim ? kSqrtLn2 * tc : 1.0;
+            const double inv = rcp64(xc), inv2 = inv * inv;
+            double pw = farim ? agd * inv : 0.0;
+#pragma unroll
+            for (int j = 0; j < kDawFarTerms; ++j) {
+                B[j] = (dawson::kFar[j] * pow49_half(j)) * pw;
+                pw *= inv2;
+            }
+        }
+        const double eps = farim ? -hk * rcp64(tc) : 0.0;
+        double en = 1.0;
+        double *dst = ffs + lane + (lane >> 4);
+#pragma unroll
+        for (int n = 0; n < kFarTerms; ++n) {
+            double sg = 0.0;
+#pragma unroll
+            for (int j = kDawFarTerms - 1; j >= 0; --j) sg = __builtin_fma(B[j], binom_d(2 * j + n, n), sg);
+            dst[n * kFarPad] = __builtin_fma(sg, en, y0);
+            en *= eps;
+            const double y2 = __builtin_fma(a2, y1, b2 * y0);
+            y0 = y1;
+            y1 = y2;
+        }
+    };
+    // ... and, far-field kernel with P <= 32, for a PAIR of chunks at once like expand_pair: lanes 0..31 the peaks against
+    // chunk jbE, lanes 32..63 against the chunk after it; the sums of the first chunk land in slots 0..15 of the scratch,
+    // those of the second in a parking row of their own (behind the real part's), the near-peak masks in scalar registers.
+    auto expand_pair_im = [&](const int64_t jbE) {
+        const double2 mm = global_table(chunk_minmax, jbE / kChunk);
+        const bool has_next = jbE + kChunk < j1;                  // wave-uniform
+        double2 mn = mm;
+        if (has_next) mn = global_table(chunk_minmax, jbE / kChunk + 1);
+        const bool upper = lane >= 32;
+        const int k = lane & 31;
+        const double lo_w = upper ? mn.x : mm.x, hi_w = upper ? mn.y : mm.y;
+        const bool act = (k < P) && (!upper || has_next);
+        bool farim = false;
+        double tc = 0.0, hk = 0.0, rq = 0.0, al = 0.0, agd = 0.0;
+        if (act) {
+            const PeakLor rec = lor[k];
+            tc = __builtin_fma(0.5 * (lo_w + hi_w), rec.ihw, rec.c);
+            hk = (0.5 * (hi_w - lo_w)) * rec.ihw;
+            const double den = __builtin_fma(tc, tc, 1.0);
+            farim = (den >= 100.0 * hk * hk) && ((fabs(tc) - fabs(hk)) * kSqrtLn2 >= kDawFarX);   // false for NaN
+            rq = rcp64(den);
+            al = rec.al;
+            agd = rec.ag2 * kInvSqrtPi;
+        }
+        const unsigned long long farmask = __ballot(farim);
+        const unsigned long long nearmask = __ballot(act && !farim);
+        even_near_im = (unsigned)nearmask;
+        pend_near_im = (unsigned)(nearmask >> 32);
+        pair_far_im = ((unsigned)farmask != 0u ? 1u : 0u) | ((unsigned)(farmask >> 32) != 0u ? 2u : 0u);
+        if (farmask) {   // wave-uniform
+            im_rows(farim, tc, hk, rq, al, agd);
+            wave_lds_fence();   // same-wave LDS write -> read
+            expand_sums(kFarTerms * kFarPad + kFarTerms);
+        }
     };
     auto chunk = [&](const int64_t jb, auto full_tag, auto odd_tag) {
         // FARFIELD, P <= 32: an odd chunk's expansion was made by the even chunk before it
@@ -555,7 +630,7 @@ __device__ __forceinline__ void objective_body(
                     // order, so a chunk's coefficients do not depend on which half made them.
                     if (!ff_odd) {
                         expand_pair(jb);
-                        expand_sums();
+                        expand_sums(kFarTerms * kFarPad);
                     }
                     const unsigned near_c = ff_odd ? pend_near : even_near;
                     const unsigned hits_c = ff_odd ? pend_hits : even_hits;
@@ -744,6 +819,17 @@ __device__ __forceinline__ void objective_body(
             const double ihalf = wave_uniform(0.5 * (mi2.y - mi2.x));
             double isum = 0.0;     // lane l: coefficient of order l >> 2 (all 4 lanes of a quad)
             bool anyfar = false;
+            const bool pair_im = kFar && P <= 32;   // (wave-uniform; a compile-time false outside the far-field kernel)
+            if (pair_im) {
+                // the expansions of this chunk and the next were made together by the even chunk (expand_pair_im)
+                if (!ff_odd) expand_pair_im(jb);
+                anyfar = (pair_far_im & (ff_odd ? 2u : 1u)) != 0u;
+                for (unsigned m = ff_odd ? pend_near_im : even_near_im; m; m &= m - 1) {
+                    const PeakLor rec = lor[__builtin_ctz(m)];
+#pragma unroll
+                    for (int q = 0; q < kPointsPerLane; ++q) iacc[q] += dispersion_tab(wv[q], rec, dtab);
+                }
+            } else
             for (int kb = 0; kb < P; kb += kWave) {
                 const int k = kb + lane;
                 const bool act = k < P;
@@ -763,41 +849,7 @@ __device__ __forceinline__ void objective_body(
                 const unsigned long long nearmask = __ballot(act && !farim);
                 if (farmask) {
                     anyfar = true;
-                    // Lorentzian dispersion: al * Re(q m^n), q = (tc + i)/(tc^2 + 1), m = -hk q, by the
-                    // real two-term recurrence (both roots of modulus |m|)
-                    const double qr = tc * rq, qi = rq;
-                    const double mr = -hk * qr, mi = -hk * qi;
-                    const double a2 = farim ? mr + mr : 0.0;
-                    const double b2 = farim ? -__builtin_fma(mr, mr, mi * mi) : 0.0;
-                    double y0 = farim ? al * qr : 0.0;
-                    double y1 = farim ? al * __builtin_fma(qr, mr, -(qi * mi)) : 0.0;
-                    // Gaussian dispersion: agd * sum_j A_j x^-(2j+1), x = xc (1 - eps u), eps = -hk/tc:
-                    // coefficient of u^n = agd eps^n sum_j B_j binom(2j + n, n), B_j = A_j xc^-(2j+1)
-                    double B[kDawFarTerms];
-                    {
-                        const double xc = farim ? kSqrtLn2 * tc : 1.0;
-                        const double inv = rcp64(xc), inv2 = inv * inv;
-                        double pw = farim ? agd * inv : 0.0;
-#pragma unroll
-                        for (int j = 0; j < kDawFarTerms; ++j) {
-                            B[j] = (dawson::kFar[j] * pow49_half(j)) * pw;
-                            pw *= inv2;
-                        }
-                    }
-                    const double eps = farim ? -hk * rcp64(tc) : 0.0;
-                    double en = 1.0;
-                    double *dst = ffs + lane + (lane >> 4);
-#pragma unroll
-                    for (int n = 0; n < kFarTerms; ++n) {
-                        double sg = 0.0;
-#pragma unroll
-                        for (int j = kDawFarTerms - 1; j >= 0; --j) sg = __builtin_fma(B[j], binom_d(2 * j + n, n), sg);
-                        dst[n * kFarPad] = __builtin_fma(sg, en, y0);
-                        en *= eps;
-                        const double y2 = __builtin_fma(a2, y1, b2 * y0);
-                        y0 = y1;
-                        y1 = y2;
-                    }
+                    im_rows(farim, tc, hk, rq, al, agd);
                     wave_lds_fence();   // same-wave LDS write -> read
                     double part = 0.0;
                     const double *row = ffs + (lane >> 2) * kFarPad + (lane & 3) * 17;
@@ -815,11 +867,14 @@ __device__ __forceinline__ void objective_body(
                 }
             }
             if (anyfar) {   // wave-uniform
-                if ((lane & 3) == 0) ffs[lane >> 2] = isum;
-                wave_lds_fence();
+                if (!pair_im) {
+                    if ((lane & 3) == 0) ffs[lane >> 2] = isum;
+                    wave_lds_fence();
+                }
+                const double *srci = ffs + ((pair_im && ff_odd) ? kFarTerms * kFarPad + kFarTerms : 0);
                 double cfi[kFarTerms];
 #pragma unroll
-                for (int n = 0; n < kFarTerms; ++n) cfi[n] = ffs[n];
+                for (int n = 0; n < kFarTerms; ++n) cfi[n] = srci[n];
                 const double ihc = (ihalf > 0.0) ? rcp64(ihalf) : 0.0;
 #pragma unroll
                 for (int q = 0; q < kPointsPerLane; ++q) {

@@ -36,9 +36,9 @@ constexpr int kFarPad = 68;        // row stride (doubles) of the per-wave coeff
                                    // (DEFAULT: 5e4) all the same: 12 cycles per chunk PAIR, from the per-lane reads of the
                                    // 32-byte peak records (lanes i and i + 8 of a ds_read_b128 group share banks) -- 0.3 % of a
                                    // pair's ~4500 cycles, not worth a padded record (profiles/r04/farfield_c3_pmc_summary.json)
-// doubles of far-field scratch per wave: the rows -- and, with the all-peak imaginary model, one more row where the even chunk
-// of a pair parks the odd chunk's coefficient sums (the imaginary pass uses every row of the scratch itself)
-constexpr int far_stride(int fit_im) { return kFarTerms * kFarPad + (fit_im == 2 ? kFarTerms : 0); }
+// doubles of far-field scratch per wave: the rows -- and, with the all-peak imaginary model, two more rows where the even chunk
+// of a pair parks the odd chunk's coefficient sums, real and imaginary (the imaginary pass uses every row of the scratch itself)
+constexpr int far_stride(int fit_im) { return kFarTerms * kFarPad + (fit_im == 2 ? 2 * kFarTerms : 0); }
 constexpr size_t kSharedPrologueBytes = ((2 + 2 * kWave) * sizeof(double) + 16 * sizeof(int) + 15) & ~(size_t)15;
 constexpr double kGaussWindow = 3.9686269665968861;          // 0.5*sqrt(63): 2^-(1+t^2) < 2^-64 beyond
 

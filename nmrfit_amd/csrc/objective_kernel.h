@@ -72,12 +72,14 @@ namespace {
 // the 8-point register block and the batch inversion's intermediates live together; FARFIELD 119.
 // FIT_IM == 1 evaluates the last peak's dispersion line at the chunk's points in the epilogue (dispersion_points, Dawson
 // coefficients from LDS): three waves per SIMD (DEFAULT 131 VGPRs, FARFIELD 142).  FIT_IM == 2 holds eight more
-// accumulators and the imaginary far-field sums: the direct kernel 156 VGPRs (three waves), the far-field one 190 (two
-// waves, which is why fit() never selects it for the all-peak imaginary model: utils.default_variant).
+// accumulators and the imaginary far-field sums: the direct kernel 156 VGPRs, the far-field one 162 -- three waves per
+// SIMD both, no scratch (round 6: up to round 5 the far-field kernel took the general expansion path with the imaginary
+// sum, 190 VGPRs and two waves; it now makes the expansions of two chunks at once there too, real and imaginary).
 // Launch bounds (waves per SIMD the compiler must leave room for), by variant and imaginary-channel mode: the direct
 // kernels with the imaginary sum run at three waves per SIMD with the bound left at two -- asked for three the compiler
 // stops at 160 registers and schedules worse (2.86 against 2.57 ms at C3, round 4); the far-field kernels with the
-// imaginary channel take two rather than spilling.
+// imaginary channel keep the bound at two as well (they reach three by themselves: asked for three, the all-peak form
+// is 2.32 instead of 2.04 ms).
 #ifndef NMRFIT_IM2_FAR_WAVES
 #define NMRFIT_IM2_FAR_WAVES 2   // (A/B knob)
 #endif

@@ -83,14 +83,12 @@ def default_variant(N, P, fit_im=False):
     covers the spectra where no peak is far.  bench.py's headline is always measured on the direct
     kernel; its `fit_default` entry reports this one.
 
-    ``fit_im="sum"`` (every peak's imaginary line): the far-field kernel from grid x peaks = 3e5 on.  Up to round 5 it
-    needed 190 VGPRs with the imaginary sums (two waves per SIMD: 3.0 ms at 4096 x 65536 x 24 against the direct
-    kernel's 2.6) and was never selected; round 6 gave it the pair expansions with the imaginary model and a
-    quarter-interval Dawson table (162 VGPRs, three waves, no scratch): 1.63 ms against 2.38 there, and per swarm
-    generation far-field / direct (tools/variant_threshold_im.py, profiles/r06/variant_threshold_im.txt) 1.01-1.03 up to
-    grid x peaks = 1e5, 0.98-1.01 at 2e5, 0.92-0.97 at 3.9e5, 0.76-0.80 at 65536 x 24."""
-    if equations.fit_im_mode(fit_im) == _cabi.FIT_IM_SUM:
-        return "farfield" if int(N) * int(P) >= 300000 else "default"
+    ``fit_im="sum"`` (every peak's imaginary line): the same rule.  Up to round 5 the far-field kernel needed 190 VGPRs with
+    the imaginary sums (two waves per SIMD: 3.0 ms at 4096 x 65536 x 24 against the direct kernel's 2.6) and was never
+    selected; round 6 gave it the pair expansions with the imaginary model -- for the real and for the imaginary series --
+    and a quarter-interval Dawson table (162 VGPRs, three waves, no scratch): 1.63 ms against 2.38 there, and per swarm
+    generation far-field / direct (tools/variant_threshold_im.py, profiles/r06/variant_threshold_im.txt) 1.00-1.03 below
+    grid x peaks = 1e5, 0.95-1.00 at 1e5, 0.94-0.99 at 2e5, 0.85-0.94 at 3.9e5, 0.70-0.74 at 65536 x 24."""
     return "farfield" if int(N) * int(P) >= 100000 else "default"
 
 

@@ -89,8 +89,8 @@ def test_default_variant_rule():
     assert utils.default_variant(16384, 12) == "farfield"
     assert utils.default_variant(65536, 24) == "farfield"
     assert utils.default_variant(65536, 24, fit_im=True) == "farfield"      # the reference's fit_im=True
-    assert utils.default_variant(65536, 24, fit_im="sum") == "farfield"     # every peak's imaginary line: far-field from 3e5 on (round 6)
-    assert utils.default_variant(16384, 12, fit_im="sum") == "default" and utils.default_variant(16384, 24, fit_im="sum") == "farfield"
+    assert utils.default_variant(65536, 24, fit_im="sum") == "farfield"     # every peak's imaginary line: the same rule (round 6)
+    assert utils.default_variant(4096, 24, fit_im="sum") == "default" and utils.default_variant(16384, 12, fit_im="sum") == "farfield"
 
 
 def test_fit_device_follows_local_rank(monkeypatch):

@@ -242,7 +242,7 @@ int nmrfit_pso_step(nmrfit_pso *pso);
  *   P                  K peak counts; lower / upper: the K boxes concatenated, sum_k (4 + 3 P[k]) doubles each
  *   params             K records (omega, phip, phig, minstep, minfunc, seed)
  *   variant, fit_im    NMRFIT_VARIANT_DEFAULT or NMRFIT_VARIANT_FARFIELD and NMRFIT_FIT_IM_* for the whole batch (the
- *                      all-peak imaginary model, NMRFIT_FIT_IM_SUM, with DEFAULT: the kernels nmrfit_amd.fit selects)
+ *                      kernels nmrfit_amd.fit selects)
  * nmrfit_batch_run: generation 0 (if needed) + up to maxiter generations, polling the K stop flags every
  * `check_every`; returns when every fit has stopped or maxiter is reached.  nmrfit_batch_status / _best: K values
  * each (any pointer may be NULL); x_best receives the K best positions concatenated like `lower`. */

@@ -363,10 +363,6 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
         set_error("fit_im must be 0 (real part), 1 (reference fit_im=True) or 2 (all-peak imaginary model)");
         return NMRFIT_E_INVALID;
     }
-    if (fit_im == NMRFIT_FIT_IM_SUM && variant != NMRFIT_VARIANT_DEFAULT) {
-        set_error("nmrfit_batch_create: the all-peak imaginary model runs the DEFAULT kernel (what nmrfit_amd.fit selects)");
-        return NMRFIT_E_UNSUPPORTED;
-    }
     if (swarmsize > 0x7fffffffLL / 8 || K > 65535) {
         set_error("nmrfit_batch_create: swarm too large, or more than 65535 fits in one part");
         return NMRFIT_E_INVALID;

@@ -47,5 +47,6 @@ struct BatchLaunch {
 int launch_objective_batch(const BatchLaunch &a);      // objective_batch.hip (fit_im = 0)
 int launch_objective_batch_im(const BatchLaunch &a);   // objective_batch_im.hip (fit_im = 1; forwards 2)
 int launch_objective_batch_im2(const BatchLaunch &a);  // objective_batch_im2.hip (fit_im = 2, DEFAULT)
+int launch_objective_batch_im2f(const BatchLaunch &a); // objective_batch_im2f.hip (fit_im = 2, FARFIELD)
 
 }  // namespace nmrfit

@@ -15,7 +15,7 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 EXTRA=()
 LIBNAME="${NMRFIT_LIBNAME:-libnmrfit_amd.so}"
-UNITS=(objective objective_default objective_farfield objective_farfield32 objective_norec objective_batch objective_batch_im objective_batch_im2 pso batch result cabi comm)
+UNITS=(objective objective_default objective_farfield objective_farfield32 objective_norec objective_batch objective_batch_im objective_batch_im2 objective_batch_im2f pso batch result cabi comm)
 for arg in "$@"; do
     if [ "$arg" = "--ab" ]; then
         EXTRA+=(-DNMRFIT_AB_BUILD)

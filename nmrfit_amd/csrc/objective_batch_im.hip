@@ -1,6 +1,6 @@
 // objective_batch_im.hip -- the batched objective kernel with the imaginary channel (fit_im = True: the reference's
 // last-peak-only term, nmrfit/equations.py:197-209; "sum": every peak), in the wave = particle geometry (a batch is
-// worth making from two fits on, and from three on that form is the faster one anyway).  DEFAULT and FARFIELD for fit_im = 1, DEFAULT for fit_im = 2
+// worth making from two fits on, and from three on that form is the faster one anyway).  DEFAULT and FARFIELD for both modes
 // (what nmrfit_amd.fit selects: utils.default_variant).  A translation unit of its own: these are the slowest kernels
 // to compile (the all-peak sum has a unit of its own, objective_batch_im2.hip).
 #include "objective_batch_kernel.h"
@@ -31,7 +31,8 @@ int launch_objective_batch_im(const BatchLaunch &a)
     if (a.variant == NMRFIT_VARIANT_DEFAULT && a.fit_im == NMRFIT_FIT_IM_REFERENCE) return launch_batch_im<NMRFIT_VARIANT_DEFAULT, 1>(a);
     if (a.variant == NMRFIT_VARIANT_DEFAULT && a.fit_im == NMRFIT_FIT_IM_SUM) return launch_objective_batch_im2(a);   // objective_batch_im2.hip
     if (a.variant == NMRFIT_VARIANT_FARFIELD && a.fit_im == NMRFIT_FIT_IM_REFERENCE) return launch_batch_im<NMRFIT_VARIANT_FARFIELD, 1>(a);
-    set_error("device-batched fits with the imaginary channel: DEFAULT (fit_im 1, 2) and FARFIELD (fit_im 1) -- what nmrfit_amd.fit selects");
+    if (a.variant == NMRFIT_VARIANT_FARFIELD && a.fit_im == NMRFIT_FIT_IM_SUM) return launch_objective_batch_im2f(a);   // objective_batch_im2f.hip
+    set_error("device-batched fits with the imaginary channel: DEFAULT and FARFIELD -- what nmrfit_amd.fit selects");
     return NMRFIT_E_UNSUPPORTED;
 }
 

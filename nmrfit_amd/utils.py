@@ -215,8 +215,6 @@ class FitUtility:
             return None
         if plan['variant'] not in (_cabi.VARIANT_DEFAULT, _cabi.VARIANT_FARFIELD) or len(self.lower) > 400:
             return None
-        if mode == _cabi.FIT_IM_SUM and plan['variant'] != _cabi.VARIANT_DEFAULT:
-            return None
         return (self._device(), None, int(plan['swarmsize']), plan['variant'], int(plan['maxiter']),
                 int(plan['check_every']), mode)
 

@@ -39,8 +39,8 @@ def test_batch_key_groups_equal_shapes_only():
     assert ka is not None and ka == kb == kc                        # peak counts and (round 6) grid lengths may differ
     assert key(a, options={"swarmsize": 100}) != ka
     assert key(a, fit_im=True) not in (None, ka) and key(a, fit_im="sum") not in (None, ka, key(a, fit_im=True))
-    assert key(big, fit_im="sum") is None                              # (every peak's imaginary line on a large grid: the far-field
-                                                                       # kernel, which has no batched form with it -- a lone fit)
+    assert key(big, fit_im="sum")[3] == _cabi.VARIANT_FARFIELD         # (every peak's imaginary line on a large grid: the far-field
+                                                                       # kernel, batched too since round 6)
     assert key(_job(8192, 6, 5), fit_im="sum")[3] == _cabi.VARIANT_DEFAULT
     assert key(a, options={"polish": True}) == ka                     # (round 6: the swarm of a polished fit runs in the batch)
     assert key(a, options={"exchange": object()}) is None

@@ -152,7 +152,7 @@ def test_batch_farfield_variant_and_per_fit_constants():
 
 
 @pytest.mark.parametrize("fit_im,variant,N,P", [(True, "default", 4096, (6, 3, 5)), ("sum", "default", 4096, (4, 6, 2)),
-                                                  (True, "farfield", 16384, (12, 9, 10))])
+                                                  (True, "farfield", 16384, (12, 9, 10)), ("sum", "farfield", 16384, (12, 7, 33))])
 def test_batch_with_the_imaginary_channel(fit_im, variant, N, P):
     """fit_im=True (the reference's last-peak-only imaginary term, nmrfit/equations.py:197-209) and "sum" in a device
     batch: still the lone swarms' trajectories, bit for bit, with pyswarm's rule on."""
@@ -183,9 +183,9 @@ def test_batch_with_the_imaginary_channel(fit_im, variant, N, P):
                 xb, fbest = sw.best()
                 np.testing.assert_array_equal(best[k][0], xb)
                 assert best[k][1] == fbest
-        with pytest.raises(_cabi.NmrfitError) as ei:
+        with pytest.raises(_cabi.NmrfitError) as ei:      # (NOREC has no batched form)
             FitBatch([(sp["w"], sp["u"], sp["v"], sp["weights"]) for sp in problems], [sp["lower"] for sp in problems],
-                     [sp["upper"] for sp in problems], swarmsize=S, seeds=seeds, variant="farfield", fit_im="sum")
+                     [sp["upper"] for sp in problems], swarmsize=S, seeds=seeds, variant="norec", fit_im="sum")
         assert ei.value.code == _cabi.E_UNSUPPORTED
     finally:
         _close(evs, sws)

@@ -43,12 +43,15 @@ def test_selectable_kernels_use_no_scratch_and_the_hot_two_fit_four_waves():
         m = re.match(r"(objective_batch_kernel<[^>]+>)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)", line)
         if m:
             out2[m.group(1)] = dict(vgpr=int(m.group(2)), scratch=int(m.group(4)), waves=int(m.group(5)))
-    assert len(out2) == 9, out.stdout[-2000:]      # six real-part forms, three with the imaginary channel
+    assert len(out2) == 10, out.stdout[-2000:]     # six real-part forms, four with the imaginary channel
     assert all(v["scratch"] <= 24 for v in out2.values()), out2
     for name in ("objective_batch_kernel<DEFAULT,wave=particle>", "objective_batch_kernel<FARFIELD,wave=particle>"):
         assert out2[name]["waves"] >= 4 and out2[name]["scratch"] <= 24, (name, out2[name])
     # the imaginary channel: the reference's fit_im=True on the far-field kernel and the all-peak sum on the direct one
     # (what fit() selects) run three waves per SIMD
     for name in ("objective_kernel<FARFIELD,objective,fit_im=1>", "objective_kernel<DEFAULT,objective,fit_im=2>",
-                 "objective_kernel<DEFAULT,objective,fit_im=1>"):
+                 "objective_kernel<DEFAULT,objective,fit_im=1>", "objective_kernel<FARFIELD,objective,fit_im=2>"):
         assert rows[name]["scratch"] == 0 and rows[name]["vgpr"] <= 168, (name, rows[name])
+    # (round 6: the far-field kernel with the all-peak sum -- 190 VGPRs and two waves per SIMD up to round 5 -- lone and batched)
+    assert out2["objective_batch_kernel<FARFIELD,wave=particle,fit_im=2>"]["vgpr"] <= 168
+    assert out2["objective_batch_kernel<FARFIELD,wave=particle,fit_im=2>"]["scratch"] == 0

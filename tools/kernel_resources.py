@@ -27,7 +27,7 @@ def demangle(names):
 def resources(extra):
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
-        for src in ("objective_default.hip", "objective_farfield.hip", "objective_farfield32.hip", "objective_norec.hip", "objective_batch.hip", "objective_batch_im.hip", "objective_batch_im2.hip", "objective.hip", "pso.hip", "batch.hip"):
+        for src in ("objective_default.hip", "objective_farfield.hip", "objective_farfield32.hip", "objective_norec.hip", "objective_batch.hip", "objective_batch_im.hip", "objective_batch_im2.hip", "objective_batch_im2f.hip", "objective.hip", "pso.hip", "batch.hip"):
             if not os.path.exists(os.path.join(CSRC, src)):
                 continue
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",

@@ -288,7 +288,8 @@ int main(int argc, char **argv)
             memcpy(wtK + at, wt, (size_t)NK[k] * sizeof(double));
             at += NK[k];
         }
-        CHECK(nmrfit_batch_create_ragged(0, K, NK, wK, uK, vK, wtK, PK, loK, hiK, 204, prmK, variant, NMRFIT_FIT_IM_OFF, &batch));
+        const int64_t SK[K] = {204, 96, 51};   /* ... and swarms of different sizes (options['swarmsize'], nmrfit/utils.py:177) */
+        CHECK(nmrfit_batch_create_ragged(0, K, NK, wK, uK, vK, wtK, PK, loK, hiK, SK, prmK, variant, NMRFIT_FIT_IM_OFF, &batch));
         CHECK(nmrfit_batch_run(batch, 1000, 100));
         CHECK(nmrfit_batch_best(batch, xK, fK));
         printf("ragged batch (%lld, %lld, %lld points): best f = %.3e %.3e %.3e\n", (long long)NK[0], (long long)NK[1],

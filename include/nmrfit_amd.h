@@ -233,8 +233,9 @@ int nmrfit_pso_step(nmrfit_pso *pso);
 /* ---- device-batched fits: K independent fits, ONE launch per swarm generation for all of them (ABI 5) ---------
  * The reference's users fit spectrum after spectrum -- `nmrfit.fit(data, lb, ub)` per spectrum (nmrfit/core.py:64,
  * README.md:64-66), each a 204-particle swarm (nmrfit/utils.py:177-178) -- and a lone swarm of that size fills a
- * fraction of an MI355X.  A batch holds K spectra of EQUAL length N (each one the `args=(w, u, v, weights)` tuple of
- * nmrfit/utils.py:176) and K swarms of EQUAL size; peak counts, bounds, seeds and swarm constants are per fit.  Every
+ * fraction of an MI355X.  A batch holds K spectra (each one the `args=(w, u, v, weights)` tuple of nmrfit/utils.py:176;
+ * nmrfit_batch_create: of equal length N, nmrfit_batch_create_ragged: of any lengths) and K swarms (of one size, or of
+ * any sizes); peak counts, bounds, seeds and swarm constants are per fit.  Every
  * generation of every swarm that has not stopped is one launch of the objective kernel whose workgroups look their
  * fit up by blockIdx; each fit follows exactly the trajectory nmrfit_pso_run gives it alone (bit-identical params and
  * error for the same seed) and stops by its own pyswarm rule.
@@ -251,15 +252,17 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
                         const double *weights, const int32_t *P, const double *lower, const double *upper,
                         int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im,
                         nmrfit_batch **out);
-/* The same for spectra of DIFFERENT lengths (ABI 6): the reference's users crop every dataset to its own region
- * (Data.select_bounds, nmrfit/containers.py:112-130), so the spectra of one study rarely share N.  N: K grid lengths;
- * w, u, v, weights: the K spectra one after the other (fit k's N[k] points at offset N[0] + ... + N[k-1]).  Fits of
- * different lengths run in the launch geometry that gives every particle one wave (the wave reads its fit's length and
- * block structure from the fit's record); results stay bit-identical to each fit run alone.  nmrfit_batch_create is this
- * call with K equal lengths. */
+/* The same for spectra of DIFFERENT lengths and swarms of different sizes (ABI 6): the reference's users crop every dataset
+ * to its own region (Data.select_bounds, nmrfit/containers.py:112-130), so the spectra of one study rarely share N; and
+ * `swarmsize` is an option of every fit (nmrfit/utils.py:177).  N: K grid lengths; w, u, v, weights: the K spectra one
+ * after the other (fit k's N[k] points at offset N[0] + ... + N[k-1]); swarmsize: K swarm sizes.  Fits that differ in
+ * length or swarm size run in the launch geometry that gives every particle one wave (the wave reads its fit's length,
+ * block structure and swarm size from the fit's record; a launch has room for the largest swarm, smaller ones leave
+ * their spare workgroups idle); results stay bit-identical to each fit run alone.  nmrfit_batch_create is this call with
+ * K equal lengths and sizes. */
 int nmrfit_batch_create_ragged(int device, int32_t K, const int64_t *N, const double *w, const double *u, const double *v,
                                const double *weights, const int32_t *P, const double *lower, const double *upper,
-                               int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im,
+                               const int64_t *swarmsize, const nmrfit_pso_params *params, int variant, int fit_im,
                                nmrfit_batch **out);
 int nmrfit_batch_destroy(nmrfit_batch *batch);
 int nmrfit_batch_run(nmrfit_batch *batch, int64_t maxiter, int32_t check_every);

@@ -119,7 +119,7 @@ ALL_SIGNATURES = {
     "nmrfit_prof_read": [_VP, _VP, _I64, ctypes.POINTER(_I64), _VP, _I64, ctypes.POINTER(_I64), _c_double_p],
     "nmrfit_diag_ab_build": [],
     "nmrfit_batch_create": [_INT, _I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _INT, _INT, _c_void_pp],
-    "nmrfit_batch_create_ragged": [_INT, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP, _INT, _INT, _c_void_pp],
+    "nmrfit_batch_create_ragged": [_INT, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _INT, _INT, _c_void_pp],
     "nmrfit_batch_destroy": [_VP],
     "nmrfit_batch_run": [_VP, _I64, _I32],
     "nmrfit_batch_status": [_VP, _VP, _VP, _VP],

@@ -4,7 +4,7 @@ Device-batched fits: K independent spectra fitted together, one kernel launch pe
 
 The reference's users call ``nmrfit.fit`` once per spectrum (nmrfit/core.py:64, README.md:64-66), each fit a
 204-particle swarm (nmrfit/utils.py:177) -- a fraction of an MI355X.  ``FitBatch`` holds K spectra -- of any lengths:
-every dataset is cropped to its own region, nmrfit/containers.py:112-130 -- and K swarms of equal size on the device;
+every dataset is cropped to its own region, nmrfit/containers.py:112-130 -- and K swarms (of any sizes) on the device;
 every fit has its own grid, peak count, box, seed and stopping rule, follows exactly the trajectory a lone
 ``nmrfit_amd.fit`` gives it (bit-identical ``params`` / ``error`` for the same seed) and stops on its own.
 ``nmrfit_amd.fit_many`` builds these batches from a list of jobs.
@@ -22,7 +22,7 @@ class FitBatch:
     spectra : K tuples ``(w, u, v, weights)`` (what FitUtility.fit passes as ``args``, nmrfit/utils.py:176); the K
               spectra may differ in length
     lowers, uppers : K parameter boxes, 4 + 3 P_k floats each (nmrfit/containers.py:193-217)
-    swarmsize : particles per fit (the same for every fit of a batch)
+    swarmsize : particles per fit: one number, or K of them (``options['swarmsize']`` of each fit, nmrfit/utils.py:177)
     seeds : K integers (the swarm's random stream, like options['seed'] of ``fit``)
     omega, phip, phig, minstep, minfunc : scalars or length-K sequences
     variant : "default" or "farfield" (what ``fit`` would select for these shapes)
@@ -57,8 +57,11 @@ class FitBatch:
                 raise ValueError("bounds must have 4 + 3P entries (fit %d)" % k)
             self.D.append(int(lo.size))
         # N: the common grid length, or None when the spectra differ in length (Ns, noff: per fit)
-        self.K, self.Ns, self.noff, self.S = K, Ns, noff, int(swarmsize)
+        # S: the common swarm size, or None when the swarms differ in size (Ss: per fit)
+        self.Ss = np.ascontiguousarray(np.broadcast_to(np.asarray(swarmsize, dtype=np.int64), (K,)))
+        self.K, self.Ns, self.noff = K, Ns, noff
         self.N = int(Ns[0]) if np.all(Ns == Ns[0]) else None
+        self.S = int(self.Ss[0]) if np.all(self.Ss == self.Ss[0]) else None
         self.P = np.array([(d - 4) // 3 for d in self.D], dtype=np.int32)
         self.offsets = np.concatenate(([0], np.cumsum(self.D)))
         lower = np.concatenate(lbs)
@@ -77,7 +80,7 @@ class FitBatch:
             prm[k] = _cabi.PsoParams(om[k], pp[k], pg[k], ms[k], mf[k], self.seeds[k])
         _cabi.check(self._lib.nmrfit_batch_create_ragged(int(device), K, _cabi.ptr(Ns), _cabi.ptr(planes[0]),
                                                          _cabi.ptr(planes[1]), _cabi.ptr(planes[2]), _cabi.ptr(planes[3]),
-                                                         _cabi.ptr(self.P), _cabi.ptr(lower), _cabi.ptr(upper), self.S, prm,
+                                                         _cabi.ptr(self.P), _cabi.ptr(lower), _cabi.ptr(upper), _cabi.ptr(self.Ss), prm,
                                                          _cabi.variant_id(variant), equations.fit_im_mode(fit_im),
                                                          ctypes.byref(self._h)))
 
@@ -182,9 +185,9 @@ class FitBatch:
                     workgroups=n.value)
 
     def state(self, k):
-        D = self.D[k]
-        x = np.empty((self.S, D)); v = np.empty_like(x); p = np.empty_like(x)
-        fx = np.empty(self.S); fp = np.empty(self.S)
+        D, S = self.D[k], int(self.Ss[k])
+        x = np.empty((S, D)); v = np.empty_like(x); p = np.empty_like(x)
+        fx = np.empty(S); fp = np.empty(S)
         _cabi.check(self._lib.nmrfit_batch_get_state(self._h, int(k), _cabi.ptr(x), _cabi.ptr(v), _cabi.ptr(p),
                                                      _cabi.ptr(fx), _cabi.ptr(fp)))
         return dict(x=x, v=v, p=p, fx=fx, fp=fp)

@@ -40,8 +40,8 @@ def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, generate=Fa
 
     How the jobs run:
 
-    * ``batch=True`` (default): jobs of equal grid length, swarm size, kernel variant and ``fit_im`` are fitted as
-      ONE device batch -- one kernel launch per swarm generation for all of them (nmrfit_amd.batch.FitBatch,
+    * ``batch=True`` (default): jobs of equal kernel variant, ``fit_im``, ``maxiter`` and ``check_every`` -- grid lengths,
+      peak counts and swarm sizes may differ -- are fitted as ONE device batch -- one kernel launch per swarm generation for all of them (nmrfit_amd.batch.FitBatch,
       csrc/batch.hip).  A 204-particle swarm fills a fraction of an MI355X; a batch fills it.  Each fit's ``params`` and
       ``error`` are bit-identical to what ``fit`` returns for it alone with the same ``options['seed']``.  Job lists go
       through batches of a quarter of the list, between 40 and 200 jobs (``nmrfit_amd.core.BATCH_JOBS`` overrides),
@@ -292,7 +292,8 @@ def _fit_many_local(jobs, threads, batch, kwargs, generate=False):
 def _batch_create(fits, plans, key):
     """The device state of one batch (spectra, weights, boxes, swarms) -- everything up to the first launch."""
     from .batch import FitBatch
-    device, _, swarmsize, variant, _, _, fit_im = key
+    device, _, _, variant, _, _, fit_im = key
+    swarmsize = [int(p['swarmsize']) for p in plans]
     spectra = [(f.data.w, f.data.u, f.data.v, f.weights) for f in fits]
     kw = {name: [p['kw'][name] for p in plans] for name in ("omega", "phip", "phig", "minstep", "minfunc")}
     fb = FitBatch(spectra, [f.lower for f in fits], [f.upper for f in fits], swarmsize=swarmsize,

@@ -32,7 +32,9 @@ struct BatchPart {
     hipStream_t stream = nullptr;
     int32_t K = 0;
     int64_t N = 0;                       // the fits' common grid length, or 0 when they differ (ragged: wave = particle form only)
-    int64_t S = 0, n_chunks = 0;         // particles per fit; chunks of the LONGEST grid
+    int64_t S = 0, n_chunks = 0;         // particles per fit, or 0 when the swarms differ in size (wave = particle form only); chunks of the LONGEST grid
+    std::vector<int64_t> Sk;             // per fit: swarm size
+    int64_t Smax = 0, Ssum = 0;
     std::vector<int64_t> Nk, noff;       // per fit: grid length; offset of its first point in the concatenated arrays (+ total)
     int64_t Nmax = 0;
     int variant = NMRFIT_VARIANT_DEFAULT;
@@ -116,16 +118,14 @@ __global__ void batch_chunk_minmax_kernel(PrepareArgs a)
 }
 
 // generation 0 of every swarm: x ~ U(lb, ub), v ~ U(-|ub - lb|, |ub - lb|), p = 0, fp = +inf (pso.hip, pso_init_kernel)
-__global__ void batch_init_kernel(const BatchFit *__restrict__ fits, int K, int64_t S, int64_t Dmax)
+__global__ void batch_init_kernel(const BatchFit *__restrict__ fits, int64_t Dmax)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t per_fit = S * Dmax;
-    if (idx >= (int64_t)K * per_fit) return;
-    const int k = (int)(idx / per_fit);
-    const int64_t r = idx - (int64_t)k * per_fit;
+    const BatchFit &f = fits[blockIdx.y];
+    const int64_t S = f.S;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= S * Dmax) return;
     const int64_t i = r / Dmax;
     const int d = (int)(r - i * Dmax);
-    const BatchFit &f = fits[k];
     const int64_t D = 4 + 3 * (int64_t)f.P;
     if (d >= D) return;
     const PsoFused &u = f.upd;
@@ -139,7 +139,7 @@ __global__ void batch_init_kernel(const BatchFit *__restrict__ fits, int K, int6
     double *p = const_cast<double *>(u.p);
     p[e] = 0.0;
     if (d == 0) p[S * D + i] = INFINITY;
-    if (idx - (int64_t)k * per_fit == 0) {
+    if (r == 0) {
         const_cast<long long *>(u.flags)[0] = 0;
         const_cast<long long *>(u.flags)[1] = 0;
     }
@@ -150,13 +150,13 @@ enum { kBatchPbest = 1, kBatchArgmin = 2, kBatchApply = 4 };
 // One workgroup per fit: what follows an objective launch that did not finish the generation itself -- personal bests
 // (generation 0), argmin over fp -> candidate record, fold with pyswarm's rule -- and the fit's line of the summary
 // the host reads (generations, stop code, fg, best value, best position).  Same device bodies as pso_tail_kernel.
-__global__ __launch_bounds__(1024) void batch_tail_kernel(const BatchFit *__restrict__ fits, int64_t S, int phases, int is_init,
+__global__ __launch_bounds__(1024) void batch_tail_kernel(const BatchFit *__restrict__ fits, int phases, int is_init,
                                                           double *__restrict__ summary, double *__restrict__ bestx,
                                                           const int64_t *__restrict__ boff)
 {
     const BatchFit &f = fits[blockIdx.x];
     const PsoFused &u = f.upd;
-    const int64_t D = 4 + 3 * (int64_t)f.P;
+    const int64_t D = 4 + 3 * (int64_t)f.P, S = f.S;
     long long *flags = const_cast<long long *>(u.flags);
     double *best = const_cast<double *>(u.best);
     double *p = const_cast<double *>(u.p), *fp = p + S * D;
@@ -205,7 +205,7 @@ int launch_tail(BatchPart *b, int phases, int is_init)
 {
     // the table of the CURRENT phases: x_in / p are the buffers the last launch wrote, best / flags the current block
     const BatchFit *t = table(b, b->xp + 2 * b->b);
-    hipLaunchKernelGGL(batch_tail_kernel, dim3((unsigned)b->K), dim3(1024), 0, b->stream, t, b->S, phases, is_init,
+    hipLaunchKernelGGL(batch_tail_kernel, dim3((unsigned)b->K), dim3(1024), 0, b->stream, t, phases, is_init,
                        b->d_summary, b->d_bestx, reinterpret_cast<const int64_t *>(b->d_bestx + b->Dsum));
     NMRFIT_HIP(hipGetLastError());
     return NMRFIT_OK;
@@ -236,7 +236,7 @@ void plan_geometry(BatchPart *b)
         g = BatchLaunch{};
         g.stream = b->stream;
         g.K = b->K;
-        g.S = b->S;
+        g.S = b->Smax;
         g.N = N;
         g.blk_chunks = blk_chunks;
         g.n_blocks = (int)n_blocks;
@@ -252,7 +252,7 @@ void plan_geometry(BatchPart *b)
             int64_t seg_len = 0;
             for (int w : {kWideWaves, kWavesPerBlock}) {
                 if (b->fit_im != NMRFIT_FIT_IM_OFF) continue;   // (the imaginary channel: wave = particle only)
-                if (b->N == 0) continue;                        // (fits of different lengths: wave = particle only)
+                if (b->N == 0 || b->S == 0) continue;           // (fits of different lengths or swarm sizes: wave = particle only)
                 if (n_blocks < w) continue;
                 const int64_t sl = ((n_blocks + w - 1) / w) * blk_len;
                 if ((N + sl - 1) / sl != w) continue;
@@ -279,7 +279,7 @@ void plan_geometry(BatchPart *b)
             g.seg_len = n_blocks * blk_len;
             g.seg_blocks = (int)n_blocks;
             g.wave_swarm = true;
-            g.blocks_per_fit = (b->S + kWavesPerBlock - 1) / kWavesPerBlock;
+            g.blocks_per_fit = (b->Smax + kWavesPerBlock - 1) / kWavesPerBlock;
             slices = kWavesPerBlock;
             rows = 14;   // >= 4 x (3 D + 2) doubles for every D >= 4
             row_bytes = (size_t)kWavesPerBlock * (3 * (size_t)Dmax + 2) * sizeof(double);
@@ -339,20 +339,20 @@ static int part_destroy(BatchPart *b);
 // (w, u, v, weights: the part's fits one after the other, fit k's Nk[k] points at offset sum_{i<k} Nk[i])
 static int part_create(int device, int32_t K, const int64_t *Nk, const double *w, const double *u, const double *v,
                        const double *weights, const int32_t *P, const double *lower, const double *upper,
-                       int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im, BatchPart **out)
+                       const int64_t *swarm, const nmrfit_pso_params *params, int variant, int fit_im, BatchPart **out)
 {
     if (!out) {
         set_error("null out pointer");
         return NMRFIT_E_INVALID;
     }
     *out = nullptr;
-    if (K <= 0 || !Nk || swarmsize <= 0 || !w || !u || !v || !weights || !P || !lower || !upper || !params) {
+    if (K <= 0 || !Nk || !swarm || !w || !u || !v || !weights || !P || !lower || !upper || !params) {
         set_error("nmrfit_batch_create: K, N, swarmsize must be > 0 and every array non-null");
         return NMRFIT_E_INVALID;
     }
     for (int32_t k = 0; k < K; ++k)
-        if (Nk[k] <= 0) {
-            set_error("nmrfit_batch_create: every grid length must be > 0");
+        if (Nk[k] <= 0 || swarm[k] <= 0 || swarm[k] > 0x7fffffffLL / 8) {
+            set_error("nmrfit_batch_create: every grid length and swarm size must be > 0 (and a swarm below 2^28 particles)");
             return NMRFIT_E_INVALID;
         }
     if (variant != NMRFIT_VARIANT_DEFAULT && variant != NMRFIT_VARIANT_FARFIELD) {
@@ -363,8 +363,8 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
         set_error("fit_im must be 0 (real part), 1 (reference fit_im=True) or 2 (all-peak imaginary model)");
         return NMRFIT_E_INVALID;
     }
-    if (swarmsize > 0x7fffffffLL / 8 || K > 65535) {
-        set_error("nmrfit_batch_create: swarm too large, or more than 65535 fits in one part");
+    if (K > 65535) {
+        set_error("nmrfit_batch_create: more than 65535 fits in one part");
         return NMRFIT_E_INVALID;
     }
     int n = 0;
@@ -402,7 +402,13 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
         b->Nmax = std::max(b->Nmax, Nk[k]);
         if (Nk[k] != Nk[0]) b->N = 0;   // ragged
     }
-    b->S = swarmsize;
+    b->Sk.assign(swarm, swarm + K);
+    b->S = swarm[0];
+    for (int32_t k = 0; k < K; ++k) {
+        b->Smax = std::max(b->Smax, swarm[k]);
+        b->Ssum += swarm[k];
+        if (swarm[k] != swarm[0]) b->S = 0;   // swarms of different sizes
+    }
     b->n_chunks = (b->Nmax + kChunk - 1) / kChunk;
     b->variant = variant;
     b->fit_im = fit_im;
@@ -448,7 +454,6 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
     }
     // ---- one allocation: per fit the four padded grid arrays + chunk table + swarm state; then the summary, the best
     // rows (+ their offsets), the descriptor tables, and the landing buffer of the upload
-    const int64_t S = b->S;
     const int64_t Nsum = b->noff[(size_t)K];
     auto chunks_of = [&](int32_t k) { return (b->Nk[(size_t)k] + kChunk - 1) / kChunk; };
     auto padded_of = [&](int32_t k) { return (((size_t)chunks_of(k) * kChunk * sizeof(double)) + 255) & ~(size_t)255; };
@@ -458,6 +463,7 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
     std::vector<size_t> state_bytes((size_t)K);
     for (int32_t k = 0; k < K; ++k) {
         const size_t D = (size_t)b->D[(size_t)k];
+        const int64_t S = b->Sk[(size_t)k];
         o_grid[(size_t)k] = c.take(4 * padded_of(k));
         o_chunk[(size_t)k] = c.take((size_t)chunks_of(k) * sizeof(double2));
         o_x[(size_t)k] = c.take(4 * (((size_t)S * D * sizeof(double) + 255) & ~(size_t)255));
@@ -487,6 +493,7 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
     std::vector<BatchFit> tabs((size_t)9 * (size_t)K);
     for (int32_t k = 0; k < K; ++k) {
         const size_t D = (size_t)b->D[(size_t)k];
+        const int64_t S = b->Sk[(size_t)k];
         FitMem &m = mem[(size_t)k];
         const size_t pad_al = padded_of(k);
         m.wc = reinterpret_cast<double *>(base + o_grid[(size_t)k]);
@@ -528,6 +535,7 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
             f.n_blocks = (int32_t)n_blocks;
             f.seg_len = n_blocks * (int64_t)blk_chunks * kChunk;
             f.raw_off = b->noff[(size_t)k];
+            f.S = S;
         }
         f.fx = m.fx;
         f.P = b->P[(size_t)k];
@@ -577,7 +585,7 @@ static int part_create(int device, int32_t K, const int64_t *Nk, const double *w
         // grids have longer waves: there the wave form waits until every SIMD has one.  NMRFIT_BATCH_WAVE_MIN overrides.
         int64_t wave_min = (b->n_chunks <= 16) ? 512 : 1024;
         if (const char *e = getenv("NMRFIT_BATCH_WAVE_MIN")) wave_min = atoll(e);
-        if (b->geom_ok[1] && (int64_t)K * S >= wave_min) b->mode = 1;
+        if (b->geom_ok[1] && b->Ssum >= wave_min) b->mode = 1;
     }
     for (int t = 0; t < 8; ++t)
         for (int32_t k = 0; k < K; ++k) tabs[(size_t)t * (size_t)K + (size_t)k].upd.xrow_off = xrow_offset(b, b->mode);
@@ -626,8 +634,8 @@ static int batch_init(BatchPart *b)
     b->xp = b->b = 0;
     b->fold_pending = false;
     const int64_t Dmax = 4 + 3 * (int64_t)b->Pmax;
-    const int64_t n = (int64_t)b->K * b->S * Dmax;
-    hipLaunchKernelGGL(batch_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, table(b, 0), (int)b->K, b->S, Dmax);
+    const int64_t n = b->Smax * Dmax;
+    hipLaunchKernelGGL(batch_init_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)b->K), dim3(256), 0, b->stream, table(b, 0), Dmax);
     NMRFIT_HIP(hipGetLastError());
     BatchLaunch g = b->geom[b->mode];
     g.fits = table(b, 8);
@@ -861,13 +869,14 @@ static int part_get_state(BatchPart *b, int32_t k, double *x, double *v, double 
     if ((rc = flush_fold(b)) != NMRFIT_OK) return rc;
     BatchFit f;
     NMRFIT_HIP(hipMemcpy(&f, table(b, b->xp + 2 * b->b) + k, sizeof f, hipMemcpyDeviceToHost));
-    const size_t sd = (size_t)(b->S * b->D[(size_t)k]) * sizeof(double), s1 = (size_t)b->S * sizeof(double);
+    const int64_t S = b->Sk[(size_t)k];
+    const size_t sd = (size_t)(S * b->D[(size_t)k]) * sizeof(double), s1 = (size_t)S * sizeof(double);
     hipStream_t st = b->stream;
     if (x) NMRFIT_HIP(hipMemcpyAsync(x, f.upd.x_in, sd, hipMemcpyDeviceToHost, st));
     if (v) NMRFIT_HIP(hipMemcpyAsync(v, f.upd.v_in, sd, hipMemcpyDeviceToHost, st));
     if (p) NMRFIT_HIP(hipMemcpyAsync(p, f.upd.p, sd, hipMemcpyDeviceToHost, st));
     if (fx) NMRFIT_HIP(hipMemcpyAsync(fx, f.fx, s1, hipMemcpyDeviceToHost, st));
-    if (fp) NMRFIT_HIP(hipMemcpyAsync(fp, f.upd.p + b->S * b->D[(size_t)k], s1, hipMemcpyDeviceToHost, st));
+    if (fp) NMRFIT_HIP(hipMemcpyAsync(fp, f.upd.p + S * b->D[(size_t)k], s1, hipMemcpyDeviceToHost, st));
     NMRFIT_HIP(hipStreamSynchronize(st));
     return NMRFIT_OK;
 }
@@ -916,14 +925,14 @@ extern "C" {
 
 int nmrfit_batch_create_ragged(int device, int32_t K, const int64_t *N, const double *w, const double *u, const double *v,
                                const double *weights, const int32_t *P, const double *lower, const double *upper,
-                               int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im, nmrfit_batch **out)
+                               const int64_t *swarmsize, const nmrfit_pso_params *params, int variant, int fit_im, nmrfit_batch **out)
 {
     if (!out) {
         set_error("null out pointer");
         return NMRFIT_E_INVALID;
     }
     *out = nullptr;
-    if (K <= 0 || !N || swarmsize <= 0 || !w || !u || !v || !weights || !P || !lower || !upper || !params) {
+    if (K <= 0 || !N || !swarmsize || !w || !u || !v || !weights || !P || !lower || !upper || !params) {
         set_error("nmrfit_batch_create: K, N, swarmsize must be > 0 and every array non-null");
         return NMRFIT_E_INVALID;
     }
@@ -951,7 +960,7 @@ int nmrfit_batch_create_ragged(int device, int32_t K, const int64_t *N, const do
         const int64_t n0 = b->noff[(size_t)f0];
         BatchPart *part = nullptr;
         const int rc = part_create(device, f1 - f0, N + f0, w + n0, u + n0, v + n0, weights + n0, P + f0,
-                                   lower + b->boff[(size_t)f0], upper + b->boff[(size_t)f0], swarmsize, params + f0, variant,
+                                   lower + b->boff[(size_t)f0], upper + b->boff[(size_t)f0], swarmsize + f0, params + f0, variant,
                                    fit_im, &part);
         if (rc != NMRFIT_OK) {
             nmrfit_batch_destroy(b);
@@ -967,13 +976,13 @@ int nmrfit_batch_create(int device, int32_t K, int64_t N, const double *w, const
                         const double *weights, const int32_t *P, const double *lower, const double *upper,
                         int64_t swarmsize, const nmrfit_pso_params *params, int variant, int fit_im, nmrfit_batch **out)
 {
-    if (K <= 0 || N <= 0) {
+    if (K <= 0 || N <= 0 || swarmsize <= 0) {
         if (out) *out = nullptr;
         set_error("nmrfit_batch_create: K, N, swarmsize must be > 0 and every array non-null");
         return NMRFIT_E_INVALID;
     }
-    const std::vector<int64_t> lengths((size_t)K, N);
-    return nmrfit_batch_create_ragged(device, K, lengths.data(), w, u, v, weights, P, lower, upper, swarmsize, params, variant,
+    const std::vector<int64_t> lengths((size_t)K, N), swarms((size_t)K, swarmsize);
+    return nmrfit_batch_create_ragged(device, K, lengths.data(), w, u, v, weights, P, lower, upper, swarms.data(), params, variant,
                                       fit_im, out);
 }
 

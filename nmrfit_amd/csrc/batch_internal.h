@@ -22,6 +22,7 @@ struct BatchFit {
     int64_t N, seg_len;
     int32_t blk_chunks, n_blocks;
     int64_t raw_off;
+    int64_t S;           // the fit's swarm size (round 6: may differ between the fits of a batch, wave = particle geometry)
     PsoFused upd;        // x_in == null: plain evaluation of X
 };
 
@@ -29,7 +30,7 @@ struct BatchLaunch {
     hipStream_t stream;
     const BatchFit *fits;   // device, K records
     int32_t K;
-    int64_t S;              // particles per fit
+    int64_t S;              // particles per fit (the LARGEST swarm of the batch: the wave form reads BatchFit::S)
     int64_t N;              // (the workgroup = particle form: equal for every fit; the wave form reads BatchFit::N)
     int nseg;
     int64_t seg_len;

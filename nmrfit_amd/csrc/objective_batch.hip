@@ -9,8 +9,8 @@
 //   workgroup = particle  its 4 or 8 waves are the particle's grid segments (what a lone default fit uses): few fits
 //   wave = particle       one segment, the wave does the particle's whole step (swarm_prologue_wave): many fits -- one
 //                         prologue per 8 chunks instead of per 1, no idle waves while wave 0 folds and moves
-// Fits of one batch share N, the swarm size, the kernel variant and the imaginary-channel mode; peak counts may differ
-// (the dynamic LDS is sized for the largest).  This unit holds the real-part-only forms, objective_batch_im.hip the others.
+// Fits of one batch share the kernel variant and the imaginary-channel mode; peak counts may differ (the dynamic LDS is
+// sized for the largest) and, in the wave = particle geometry, so may grid lengths and swarm sizes (round 6).  This unit holds the real-part-only forms, objective_batch_im.hip the others.
 #include "objective_batch_kernel.h"
 
 namespace nmrfit {

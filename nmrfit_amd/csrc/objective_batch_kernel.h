@@ -44,7 +44,8 @@ __global__ __launch_bounds__(kWave *WPB, (WPB != kWavesPerBlock) ? 2 : (FIT_IM =
     if constexpr (WAVE_SWARM) {
         // one particle per wave, one segment: the grid's length and block structure are the FIT's (scalar loads from its
         // record) -- the fits of a batch may differ in length
-        objective_body<VARIANT, false, FIT_IM, WPB, true>(lds_raw, g, lblock, d.wc, d.u, d.v, d.wt, d.chunk, d.X, S, P, d.N, d.w0,
+        // (... and in swarm size: a fit smaller than the largest leaves the workgroups beyond its last particle idle)
+        objective_body<VARIANT, false, FIT_IM, WPB, true>(lds_raw, g, lblock, d.wc, d.u, d.v, d.wt, d.chunk, d.X, d.S, P, d.N, d.w0,
                                                           d.wspan, 1, d.seg_len, d.blk_chunks, d.n_blocks, d.n_blocks, d.lane_step,
                                                           d.rec_devk, d.fx, nullptr, nullptr, d.upd, aux_off, wsums);
     } else {

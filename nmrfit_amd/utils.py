@@ -207,16 +207,15 @@ class FitUtility:
 
     def _batch_key(self, plan):
         """The key under which core.fit_many may put this fit into a device batch with others (csrc/batch.hip: equal
-        swarm size, kernel variant and imaginary-channel mode; the grids may differ in length) -- or None when it must
-        run on its own."""
+        kernel variant, imaginary-channel mode, maxiter and check_every; grid lengths, peak counts and swarm sizes may
+        differ) -- or None when it must run on its own."""
         opt = self.options
         mode = equations.fit_im_mode(self.fit_im)
         if opt.get('exchange') is not None:
             return None
         if plan['variant'] not in (_cabi.VARIANT_DEFAULT, _cabi.VARIANT_FARFIELD) or len(self.lower) > 400:
             return None
-        return (self._device(), None, int(plan['swarmsize']), plan['variant'], int(plan['maxiter']),
-                int(plan['check_every']), mode)
+        return (self._device(), None, None, plan['variant'], int(plan['maxiter']), int(plan['check_every']), mode)
 
     def _finish(self, xopt, fopt):
         self.params = xopt

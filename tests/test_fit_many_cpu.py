@@ -37,7 +37,8 @@ def test_batch_key_groups_equal_shapes_only():
     big = _job(32768, 12, 4)
     ka, kb, kc = key(a), key(b), key(c)
     assert ka is not None and ka == kb == kc                        # peak counts and (round 6) grid lengths may differ
-    assert key(a, options={"swarmsize": 100}) != ka
+    assert key(a, options={"swarmsize": 100}) == ka                  # (round 6: swarm sizes may differ too)
+    assert key(a, options={"maxiter": 100}) != ka and key(a, options={"check_every": 8}) != ka
     assert key(a, fit_im=True) not in (None, ka) and key(a, fit_im="sum") not in (None, ka, key(a, fit_im=True))
     assert key(big, fit_im="sum")[3] == _cabi.VARIANT_FARFIELD         # (every peak's imaginary line on a large grid: the far-field
                                                                        # kernel, batched too since round 6)
@@ -122,9 +123,9 @@ def test_long_job_lists_go_through_spans_and_leftovers_find_partners(monkeypatch
     batched with the leftovers of the other spans, and what stays alone goes through fit() with the plan made for it."""
     monkeypatch.setattr(core, "BATCH_JOBS", 4)
     made, ran, collected, lone, batches = _fake_pipeline(monkeypatch)
-    # 10 jobs -> 3 spans of 4, 4, 2.  Swarm sizes (a batch's fits share one): span 0 = [A A A B], span 1 = [A A B C], span 2 = [A A]
+    # 10 jobs -> 3 spans of 4, 4, 2.  maxiter (a batch's fits share one): span 0 = [A A A B], span 1 = [A A B C], span 2 = [A A]
     sizes = [100, 100, 100, 50, 100, 100, 50, 25, 100, 100]
-    jobs = [_job(1024, 2, 20 + k, options={"tag": k, "swarmsize": n}) for k, n in enumerate(sizes)]
+    jobs = [_job(1024, 2, 20 + k, options={"tag": k, "maxiter": n}) for k, n in enumerate(sizes)]
     out = core.fit_many(jobs, threads=1)
     assert [f.options["tag"] for f in out] == list(range(10)) and all(f.error == 0.0 for f in out)
     me = threading.get_ident()
@@ -134,7 +135,7 @@ def test_long_job_lists_go_through_spans_and_leftovers_find_partners(monkeypatch
     assert [tags for _, tags, _ in collected] == [tags for _, tags in ran]       # read back in the order they ran ...
     assert len({tid for tid, _, _ in collected}) == 1 and collected[0][0] not in (me, made[0][0])   # ... on a third thread
     assert all(scale is False for _, _, scale in collected) and all(b.closed for b in batches)
-    assert lone == [(7, True)]                                                   # the only 25-particle job: its plan is reused
+    assert lone == [(7, True)]                                                   # the only maxiter = 25 job: its plan is reused
     assert not hasattr(out[7], "generated")
 
 
@@ -142,7 +143,7 @@ def test_generate_reaches_batches_and_lone_fits(monkeypatch):
     """generate=True / a scale: the batches' read-back gets the scale, fits that ran alone get generate_result(scale)."""
     monkeypatch.setattr(core, "BATCH_JOBS", 4)
     made, ran, collected, lone, _ = _fake_pipeline(monkeypatch)
-    jobs = [_job(1024, 2, 40 + k, options={"tag": k, "swarmsize": n}) for k, n in enumerate([100, 100, 50])]
+    jobs = [_job(1024, 2, 40 + k, options={"tag": k, "maxiter": n}) for k, n in enumerate([100, 100, 50])]
     out = core.fit_many(jobs, threads=1, generate=True)
     assert [(tags, scale) for _, tags, scale in collected] == [([0, 1], 1)] and out[2].generated == 1
     collected.clear()
@@ -156,7 +157,7 @@ def test_a_batch_the_device_refuses_runs_as_lone_fits(monkeypatch):
     monkeypatch.setattr(core, "BATCH_JOBS", 8)
     made, ran, collected, lone, batches = _fake_pipeline(monkeypatch, refuse={2})
     sizes = [100, 100, 50, 50, 50]
-    jobs = [_job(1024, 2, 60 + k, options={"tag": k, "swarmsize": n}) for k, n in enumerate(sizes)]
+    jobs = [_job(1024, 2, 60 + k, options={"tag": k, "maxiter": n}) for k, n in enumerate(sizes)]
     out = core.fit_many(jobs, threads=1)
     assert [tags for _, tags in ran] == [[0, 1]]
     assert sorted(t for t, _ in lone) == [2, 3, 4] and all(had_plan for _, had_plan in lone)

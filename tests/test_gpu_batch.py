@@ -382,6 +382,51 @@ def test_ragged_batch_trajectories_equal_lone_swarms_bit_for_bit(fit_im, variant
         _close(evs, sws)
 
 
+def test_batch_with_swarms_of_different_sizes():
+    """Round 6: the swarms of a batch may differ in size (options['swarmsize'] is per fit, nmrfit/utils.py:177) -- with
+    grids of different lengths on top: the launch has room for the largest swarm, the smaller ones' spare workgroups
+    idle; every fit still follows its lone swarm bit for bit and stops by its own rule."""
+    lengths = [4096, 3000, 700, 5000, 4096, 2048, 6000]
+    sizes = [204, 17, 64, 100, 3, 260, 51]
+    K = len(lengths)
+    problems = [synth.make_spectrum(n, 1 + (2 * k) % 6, seed=170 + k) for k, n in enumerate(lengths)]
+    seeds = [900 + k for k in range(K)]
+    evs, sws = [], []
+    try:
+        for sp, seed, S in zip(problems, seeds, sizes):
+            ev = Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"])
+            evs.append(ev)
+            sws.append(pso.DeviceSwarm(ev, sp["lower"], sp["upper"], S, seed=seed))
+        with FitBatch([(sp["w"], sp["u"], sp["v"], sp["weights"]) for sp in problems], [sp["lower"] for sp in problems],
+                      [sp["upper"] for sp in problems], swarmsize=sizes, seeds=seeds) as fb:
+            assert fb.S is None and fb.N is None and fb.geometry()["mode"] == "wave"
+            fb.step()
+            for sw in sws:
+                sw.init()
+                sw.step()
+            for upto in range(1, 4):
+                fb.step()
+                for sw in sws:
+                    sw.step()
+                for k, sw in enumerate(sws):
+                    a, b = fb.state(k), sw.state()
+                    assert a["x"].shape == (sizes[k], len(problems[k]["lower"]))
+                    for name in ("x", "v", "p", "fp", "fx"):
+                        np.testing.assert_array_equal(a[name], b[name], err_msg="fit %d %s after %d" % (k, name, upto))
+            fb.run(150, 16)
+            for sw in sws:
+                sw.run(150, 16)
+            st = fb.status()
+            for k, ((x, f), sw) in enumerate(zip(fb.best(), sws)):
+                ls = sw.status()
+                assert (st[k]["iteration"], st[k]["stop"]) == (ls["iteration"], ls["stop"]), k
+                xb, fbest = sw.best()
+                np.testing.assert_array_equal(x, xb)
+                assert f == fbest
+    finally:
+        _close(evs, sws)
+
+
 def test_fit_many_batches_spectra_of_different_lengths():
     """fit_many: jobs whose spectra differ in length share a device batch (the key no longer holds N); results equal the
     plain loop's bit for bit, with and without the reconstruction."""
@@ -392,7 +437,7 @@ def test_fit_many_batches_spectra_of_different_lengths():
 
     def jobs():
         return [dict(data=synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"]), lower=list(sp["lower"]), upper=list(sp["upper"]),
-                     options={"seed": 40 + k, "swarmsize": 60, "maxiter": 90}) for k, sp in enumerate(specs)]
+                     options={"seed": 40 + k, "swarmsize": 60 + 7 * (k % 3), "maxiter": 90}) for k, sp in enumerate(specs)]
     from nmrfit_amd import utils
     keys = set()
     for j in jobs():

@@ -328,13 +328,15 @@ def test_fit_many_over_the_devices_of_one_process():
         sp = synth.make_spectrum(4096, 3 + k % 4, seed=120 + k)
         jobs.append(dict(data=synth.SynthData(sp["w"], sp["u"], sp["v"], sp["peaks"]), lower=list(sp["lower"]),
                          upper=list(sp["upper"]), options={"seed": 700 + k, "maxiter": 50, "swarmsize": 64}))
-    want = nmrfit_amd.fit_many(jobs)
-    got = nmrfit_amd.fit_many(jobs, devices=[0, 0])
-    also = nmrfit_amd.fit_many(jobs, devices="all")
+    want = nmrfit_amd.fit_many(jobs, generate=True)
+    got = nmrfit_amd.fit_many(jobs, devices=[0, 0], generate=True)      # (two host threads, each with its own pipeline; the
+    also = nmrfit_amd.fit_many(jobs, devices="all")                     # staged copies back share one pinned buffer pair per device)
     for a, b, c in zip(want, got, also):
         np.testing.assert_array_equal(a.params, b.params)
         np.testing.assert_array_equal(a.params, c.params)
         assert a.error == b.error == c.error
+        np.testing.assert_array_equal(a.u, b.u)
+        np.testing.assert_array_equal(np.stack(a.imag_contribs), np.stack(b.imag_contribs))
     with pytest.raises(ValueError):
         nmrfit_amd.fit_many(jobs, devices=[0], shard=True)
     with pytest.raises(ValueError):

@@ -78,3 +78,56 @@ def test_device_batched_default_fits_stay_fast():
         us = (time.perf_counter() - t0) / 500 / K * 1e6
     print("device batch of %d default fits: %.2f us per fit and generation" % (K, us))
     assert us <= 2.7, us
+
+
+@pytest.mark.xfail(strict=False, reason="wall-clock guard, non-gating")
+def test_farfield_kernel_with_the_all_peak_imaginary_model_stays_at_three_waves():
+    """Round 6: the far-field kernel with fit_im="sum" at C3 (4096 x 65536 x 24): 3.03 ms up to round 5 (190 VGPRs, two
+    waves per SIMD), 1.63-1.68 ms with the pair expansions and the quarter-interval Dawson table."""
+    from nmrfit_amd import equations, synth
+    sp, X = synth.make_workload("C3")
+    S, D = X.shape
+    with equations.Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        ev.set_variant(_cabi.VARIANT_FARFIELD)
+        ev.set_fit_im("sum")
+        dX, df = ev.dev_alloc(X.nbytes), ev.dev_alloc(8 * S)
+        ev.upload(dX, X)
+        for _ in range(30):
+            ev.objective_batch_dev(S, (D - 4) // 3, dX, df)
+        ev.prof_enable(10)
+        for _ in range(10):
+            ev.objective_batch_dev(S, (D - 4) // 3, dX, df)
+        ms = float(np.median(ev.prof_read()[0]))
+        ev.prof_enable(0)
+        ev.dev_free(dX)
+        ev.dev_free(df)
+    print("far-field kernel, fit_im='sum', C3: %.3f ms" % ms)
+    assert ms <= 1.9, ms
+
+
+@pytest.mark.xfail(strict=False, reason="wall-clock guard, non-gating")
+def test_readme_pipeline_keeps_up_with_the_fits():
+    """Round 6: fit -> generate_result -> area fractions for 200 default spectra through fit_many(generate=True) against
+    fit_many alone, pyswarm's rule on (best of two each): the bar of VERDICT r5 is 0.8 (measured 0.82-0.95)."""
+    import contextlib
+    import io
+    import time
+    import nmrfit_amd
+    from nmrfit_amd import synth
+    specs = [synth.make_spectrum(4096, 6, seed=100 + k % 8) for k in range(8)]
+
+    def jobs():
+        return [dict(data=synth.SynthData(specs[k % 8]["w"], specs[k % 8]["u"], specs[k % 8]["v"], specs[k % 8]["peaks"]),
+                     lower=list(specs[k % 8]["lower"]), upper=list(specs[k % 8]["upper"]), options={"seed": 7 + k}) for k in range(200)]
+    best = {False: 1e9, True: 1e9}
+    with contextlib.redirect_stdout(io.StringIO()):
+        nmrfit_amd.fit_many(jobs()[:8], generate=True)
+        for _ in range(2):
+            for gen in (False, True):
+                t0 = time.perf_counter()
+                res = nmrfit_amd.fit_many(jobs(), generate=gen)
+                if gen:
+                    [f.calculate_area_fraction() for f in res]
+                best[gen] = min(best[gen], time.perf_counter() - t0)
+    print("200 default spectra: fit only %.0f /s, with the reconstruction %.0f /s (%.2f)" % (200 / best[False], 200 / best[True], best[False] / best[True]))
+    assert best[False] / best[True] >= 0.8

@@ -201,3 +201,34 @@ def test_fit_many_generate_equals_the_readme_loop(monkeypatch, capsys):
     # without generate nothing of it exists
     plain = nmrfit_amd.fit_many(jobs())
     assert not hasattr(plain[0], "real_contribs") and np.array_equal(plain[0].params, loop[0].params)
+
+
+def test_reconstruction_entry_points_validate_their_arguments():
+    """Error codes, never crashes: null handles, one of real / imaginary without the other, output lengths without grids."""
+    import ctypes
+    from nmrfit_amd import _cabi
+    L = _cabi.lib()
+    sp = synth.make_spectrum(1024, 2, seed=3)
+    x = _cabi.f64(sp["x_true"])
+    out = np.empty((2, 1024))
+    assert L.nmrfit_generate_result(None, 2, _cabi.ptr(x), 0, None, _cabi.ptr(out), _cabi.ptr(out), None, None) == _cabi.E_INVALID
+    assert L.nmrfit_batch_contributions(None, None, None, None, None, None, None) == _cabi.E_INVALID
+    with Evaluator(sp["w"], sp["u"], sp["v"], sp["weights"]) as ev:
+        h = ev.handle
+        assert L.nmrfit_generate_result(h, 2, None, 0, None, _cabi.ptr(out), _cabi.ptr(out), None, None) == _cabi.E_INVALID
+        assert L.nmrfit_generate_result(h, 2, _cabi.ptr(x), 0, None, _cabi.ptr(out), None, None, None) == _cabi.E_INVALID   # real without imag
+        assert L.nmrfit_generate_result(h, -1, _cabi.ptr(x), 0, None, None, None, None, None) == _cabi.E_INVALID
+        assert L.nmrfit_generate_result(h, 2, _cabi.ptr(x), 0, None, None, None, None, None) == _cabi.OK                     # nothing asked for
+        fit = np.empty((4, 1024))
+        assert L.nmrfit_generate_result(h, 2, _cabi.ptr(x), 0, None, None, None, _cabi.ptr(fit), None) == _cabi.OK           # the sums alone
+        real, imag, fit2, _ = ev.generate_result(x)
+        np.testing.assert_array_equal(fit, fit2)
+    with FitBatch([(sp["w"], sp["u"], sp["v"], sp["weights"])], [sp["lower"]], [sp["upper"]], swarmsize=8, seeds=[1]) as fb:
+        fb.run(2, 2)
+        n = np.array([1024], dtype=np.int64)
+        assert L.nmrfit_batch_contributions(fb._h, _cabi.ptr(n), None, _cabi.ptr(out), _cabi.ptr(out), None, None) == _cabi.E_INVALID   # lengths without grids
+        assert L.nmrfit_batch_contributions(fb._h, None, None, _cabi.ptr(out), None, None, None) == _cabi.E_INVALID               # real without imag
+        assert L.nmrfit_batch_contributions(fb._h, None, None, None, None, None, None) == _cabi.OK
+        neg = np.array([-5], dtype=np.int64)
+        assert L.nmrfit_batch_contributions(fb._h, _cabi.ptr(neg), _cabi.ptr(out), None, None, _cabi.ptr(out), None) == _cabi.E_INVALID
+        assert len(fb.generate()) == 1                    # (the batch is still usable after the refused calls)

@@ -18,7 +18,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 constexpr double kInvPi = 0.31830988618379067154;
 constexpr double kSqrtLn2OverPi = 0.46971863934982566689;   // sqrt(ln2/pi)
-// Settled tuning constants (each was an A/B knob in rounds 1-4; the measurements are in DESIGN.md 4.4 and git history)
+// Settled tuning constants (each was an A/B knob in rounds 1-4; the measurements are in profiles/r05/DESIGN_r05.md 4.4 and git history)
 constexpr int kInterleave = 4;       // points the scheduler may interleave inside a Lorentzian group (1, 2, 4, 8: +-0.4 % at C3)
 constexpr int kGroupSize = 8;        // Lorentzians sharing one reciprocal (6 or 12: +1.2 % / +1.3 %)
 constexpr int kBatchInv = 4;         // points sharing one reciprocal in the scaled pair form

@@ -42,4 +42,6 @@ fail=0
 for p in "${pids[@]}"; do wait "$p" || fail=1; done
 [ "$fail" = 0 ] || { echo "compilation failed" >&2; exit 1; }
 "$HIPCC" --offload-arch=gfx950 -fPIC -shared "$OBJ"/*.o -ldl -o "$OUT/$LIBNAME"
+# a stamp written by __graft_entry__.build() describes the libraries it built: it no longer describes this one
+case "$LIBNAME" in libnmrfit_amd.so|libnmrfit_amd_ab.so) rm -f "$OUT/BUILD_STAMP.json" ;; esac
 echo "built $OUT/$LIBNAME"

@@ -765,6 +765,29 @@ def main():
     except Exception as e:      # an extra must never cost the run its headline line
         extras_errors.append("variants: %r" % (e,))
         variants = farfield = None
+    # the imaginary channel (fit_im=True: the reference's last-peak-only term, nmrfit/equations.py:197-209; "sum": every
+    # peak's Kramers-Kronig partner) on the same positions: kernel alone, both kernels fit() can select -- never `value`
+    imag = None
+    try:
+        if rank == 0 and args.variant == 0 and not args.no_extras:
+            imag = {}
+            for name, vid in (("default", _cabi.VARIANT_DEFAULT), ("farfield", _cabi.VARIANT_FARFIELD)):
+                ev.set_variant(vid)
+                for mode, key in ((True, "fit_im_true_ms"), ("sum", "fit_im_sum_ms")):
+                    ev.set_fit_im(mode)
+                    imag.setdefault(name, {})[key] = time_objective(ev, S_local, P, d_x, d_f, 8, heat_s=0.1)
+            ev.set_fit_im(False)
+            ev.set_variant(args.variant)
+            imag["note"] = ("objective kernel with the imaginary channel, mean of 8 HIP-event pairs: closed-form Kramers-Kronig "
+                            "partner (Lorentzian dispersion + Dawson's integral) instead of the reference's quadrature per "
+                            "point; fit() selects the far-field kernel at this size in every mode (round 6: its all-peak form "
+                            "runs three waves per SIMD -- 3.03 ms in round 5)")
+    except Exception as e:      # an extra must never cost the run its headline line
+        extras_errors.append("imaginary_channel: %r" % (e,))
+        imag = None
+    finally:
+        ev.set_fit_im(False)
+        ev.set_variant(args.variant)
     # the same kernels on a DENSE spectrum of the same shape (broad overlapping lines: no Gaussian window misses a
     # chunk, no peak is far from any chunk): the headline's rate is a property of the sparse-line spectrum SURVEY
     # 8(d) prescribes as much as of the kernel, so the other end of the range is reported beside it -- never `value`
@@ -1307,6 +1330,8 @@ def main():
                                   "units_per_s": units_launch / (variants["noskip_ms"] * 1e-3),
                                   "roofline": counters_of("sq_noskip", units_launch, None),
                                   "note": "every (particle, point, peak) unit evaluated: no Gaussian window skip"}
+        if imag is not None:
+            line["imaginary_channel"] = imag
         if dense is not None:
             dense["roofline"] = counters_of("sq_dense", units_launch, None)
             dense["farfield"]["roofline"] = counters_of("sq_dense_farfield", units_launch, None)

@@ -75,6 +75,8 @@ def test_bench_paths_agree():
     ds = plain["dense_spectrum"]
     assert ds["kernel_ms"] > 0 and ds["units_per_s"] == pytest.approx(512 * 4096 * 6 / (ds["kernel_ms"] * 1e-3))
     assert ds["farfield"]["kernel_ms"] > 0 and "broad overlapping" in ds["spectrum"]
+    ic = plain["imaginary_channel"]      # round 6: the imaginary-channel kernels ride in the line
+    assert all(ic[v][k] > plain["kernel_ms"]["mean"] * 0.3 for v in ("default", "farfield") for k in ("fit_im_true_ms", "fit_im_sum_ms"))
     # socket power and shader clock from the device's hwmon files (null where they are not readable): this run's own
     # evidence that the part sits at its power cap under the fp64 load and the clock is what is left
     assert "power" in plain

@@ -46,7 +46,8 @@ def fit_many(jobs, threads=4, batch=True, shard=False, devices=None, generate=Fa
       ``error`` are bit-identical to what ``fit`` returns for it alone with the same ``options['seed']``.  Job lists go
       through batches of a quarter of the list, between 40 and 200 jobs (``nmrfit_amd.core.BATCH_JOBS`` overrides),
       three stages in flight: a second host thread prepares the next batch (error weights, plans, device state) while
-      the device runs the current one and a third reads back the one before.
+      the device runs two batches side by side (the tail of one -- its last swarms to stop -- overlaps with the other)
+      and another thread reads back the one before.
     * ``generate=True`` (or a number: the ``scale`` of ``FitUtility.generate_result``): the rest of the reference's
       per-spectrum script, README.md:64-72 -- every returned fit has had ``generate_result(scale)`` called on it
       (nmrfit/utils.py:226-295: ``u, v, V, I, w, real_contribs, imag_contribs``; ``calculate_area_fraction()`` then
@@ -183,6 +184,15 @@ def _cabi_device_count():
 # BATCH_JOBS = None: that rule (a quarter of the list, between 40 and 200); a number: batches of about that many.
 BATCH_JOBS = None
 BATCH_JOBS_MIN, BATCH_JOBS_MAX, PIPELINE_BATCHES = 40, 200, 4
+# Device batches driven at the same time.  With pyswarm's rule the swarms of a batch stop at different generations (112
+# ... 411 for default fits) and the batch's last generations hold a few swarms each, at a launch's latency; a second
+# batch running beside it fills the device meanwhile: 4 batches of 50 default fits 93.7 -> 82.4 ms (2134 -> 2427 fits/s
+# on the device), three at a time 79.8 (tools/concurrent_batches.py, profiles/r06/concurrent_batches.txt).
+RUN_AT_ONCE = 2
+# End to end (tools/pipeline_ab.py, profiles/r06/fit_many_pipeline_ab.txt; one box, best of three): 200 default jobs with
+# pyswarm's rule 1924 -> 2038 fits/s, 1000 jobs 2349 -> 2405 -- less than on the device alone, the rest of the call being
+# the first batch's preparation and the last one's read-back; with the reconstruction 1707 -> 1728 / 2146 -> 2120 (noise).
+READ_ON_RUNNER = False    # A/B knob: the read-back on the thread that ran the batch instead of the storing thread (same rates)
 
 
 def _batch_jobs(n):
@@ -232,21 +242,47 @@ def _fit_many_local(jobs, threads, batch, kwargs, generate=False):
         leftover = []
         batched = set()
         made = []          # every batch created and not yet closed (closed by _batch_collect, or below on an error)
-        with ThreadPoolExecutor(max_workers=1) as host, ThreadPoolExecutor(max_workers=1) as post:
+        import collections
+        with ThreadPoolExecutor(max_workers=1) as host, ThreadPoolExecutor(max_workers=1) as post, \
+                ThreadPoolExecutor(max_workers=RUN_AT_ONCE) as runner:
             pending = host.submit(prepare, spans[0])
             posted = []
+            inflight = collections.deque()      # (future of a batch's run, the batch), in job order
             try:
+                def drain(limit):
+                    """Wait for the oldest runs until at most ``limit`` are in flight; what each read back goes to the
+                    thread that stores results, in job order (pyswarm's closing lines print in job order)."""
+                    while len(inflight) > limit:
+                        fut, (fb, bfits, bplans, key, _) = inflight.popleft()
+                        got = fut.result()
+                        if got is None:
+                            posted.append(post.submit(_batch_collect, fb, bfits, bplans, key, scale, threads))
+                        else:
+                            posted.append(post.submit(_batch_store, bfits, bplans, key, got[0], got[1], got[2], scale, threads))
+
+                def run_and_read(fb, bfits, key):
+                    fb.run(key[4], key[5])                      # (maxiter, check_every)
+                    if not READ_ON_RUNNER:
+                        return None
+                    return _batch_read(fb, bfits, scale)        # status, best rows, reconstruction; closes the batch
+
                 def run(ready, last=False):
                     made.extend(r[0] for r in ready)
-                    for n, (fb, bfits, bplans, key, idx) in enumerate(ready):
-                        fb.run(key[4], key[5])           # (maxiter, check_every): the device's generations, this thread
-                        if last and n == len(ready) - 1 and not posted:
-                            # the only batch of the call: nothing to overlap its read-back with -- here, without a
-                            # thread's first HIP call in the way (a 40-job list is 30 ms in all)
-                            _batch_collect(fb, bfits, bplans, key, scale, threads)
-                        else:
-                            posted.append(post.submit(_batch_collect, fb, bfits, bplans, key, scale, threads))
+                    for n, b in enumerate(ready):
+                        fb, bfits, bplans, key, idx = b
                         batched.update(idx)
+                        if last and n == len(ready) - 1 and not posted and not inflight:
+                            # the only batch of the call: nothing to overlap it with -- run and read back here, without
+                            # a thread's first HIP call in the way (a 40-job list is 30 ms in all)
+                            fb.run(key[4], key[5])
+                            _batch_collect(fb, bfits, bplans, key, scale, threads)
+                            continue
+                        # RUN_AT_ONCE batches are driven at the same time (threads of their own: the C calls release
+                        # the GIL): while the last swarms of one batch finish -- a generation of three swarms costs a
+                        # launch of 8-20 us whatever it holds -- or its results travel to the host, the other batch
+                        # fills the device
+                        drain(RUN_AT_ONCE - 1)
+                        inflight.append((runner.submit(run_and_read, fb, bfits, key), b))
                 for c in range(len(spans)):
                     ready, single = pending.result()
                     pending = host.submit(prepare, spans[c + 1]) if c + 1 < len(spans) else None
@@ -255,12 +291,18 @@ def _fit_many_local(jobs, threads, batch, kwargs, generate=False):
                 # what found no partner inside its span may have one in another
                 ready, _ = group([(i, key) for i, key in leftover if key is not None])
                 run(ready, last=True)
+                drain(0)
                 for p in posted:
                     p.result()
             except BaseException:
                 if pending is not None:      # (batches made for a span that will not run)
                     try:
                         made.extend(r[0] for r in pending.result()[0])
+                    except Exception:
+                        pass
+                for fut, _ in inflight:      # (runs in flight: let them end before their batches are closed)
+                    try:
+                        fut.result()
                     except Exception:
                         pass
                 for p in posted:
@@ -313,18 +355,30 @@ def _fit_batch(fits, plans, key, generate=False):
     _batch_collect(fb, fits, plans, key, 1 if generate is True else generate)
 
 
+def _batch_read(fb, fits, scale=False):
+    """What is read from the device after a batch's generations: stop codes, best positions and -- ``scale`` not False --
+    the reconstruction of every fit in one launch (FitBatch.generate).  Closes the batch."""
+    polished = sum(1 for f in fits if f.options.get('polish', False))
+    with fb:
+        status = fb.status()
+        best = fb.best()
+        results = fb.generate(scale) if scale is not False and polished < len(fits) else None
+    return status, best, results
+
+
 def _batch_collect(fb, fits, plans, key, scale=False, threads=1):
-    """What follows a batch's generations: stop codes, best positions and -- ``scale`` not False -- the reconstruction
-    of every fit in one launch (FitBatch.generate), stored into the FitUtility objects; closes the batch.  Fits with
+    """Read back (``_batch_read``) and store (``_batch_store``) in one go."""
+    status, best, results = _batch_read(fb, fits, scale)
+    _batch_store(fits, plans, key, status, best, results, scale, threads)
+
+
+def _batch_store(fits, plans, key, status, best, results, scale=False, threads=1):
+    """A batch's results into the FitUtility objects (what FitUtility.fit and generate_result leave behind).  Fits with
     options['polish'] are refined first (FitUtility._polish, ``threads`` at a time) and reconstructed from the refined
     parameters."""
     from .pso import STOP_MESSAGES
     maxiter = key[4]
     polished = [k for k, f in enumerate(fits) if f.options.get('polish', False)]
-    with fb:
-        status = fb.status()
-        best = fb.best()
-        results = fb.generate(scale) if scale is not False and len(polished) < len(fits) else None
     if polished:
         def refine(k):
             return fits[k]._polish(best[k][0], best[k][1], plans[k])

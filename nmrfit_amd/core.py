@@ -192,6 +192,7 @@ RUN_AT_ONCE = 2
 # End to end (tools/pipeline_ab.py, profiles/r06/fit_many_pipeline_ab.txt; one box, best of three): 200 default jobs with
 # pyswarm's rule 1924 -> 2038 fits/s, 1000 jobs 2349 -> 2405 -- less than on the device alone, the rest of the call being
 # the first batch's preparation and the last one's read-back; with the reconstruction 1707 -> 1728 / 2146 -> 2120 (noise).
+# (measured and not kept: the first batch of a list cut in two halves to start the device sooner -- no difference.)
 READ_ON_RUNNER = False    # A/B knob: the read-back on the thread that ran the batch instead of the storing thread (same rates)
 
 
